@@ -1,0 +1,168 @@
+/*
+ * lcs_hip.h -- C ABI of the MI355X-native FTLE engine (liblcs_hip.so).
+ *
+ * Drop-in boundary for the parcel-advection -> flow-map-gradient -> sigma_max
+ * hot path of gabrielmpp/LagrangianCoherence.  The reference is pure Python
+ * (no FFI of its own), so every entry point below names the reference Python
+ * function it replaces (file:line relative to the reference checkout).  The
+ * reference-side binding a maintainer would add is a ctypes stub; it is shown
+ * in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, doubles.  No torch / C++ types.
+ *   - every function returns an lc_status (0 = ok, <0 = error) and records a
+ *     message retrievable with lc_last_error() (thread-local).
+ *   - "dev" pointers are HIP device pointers valid on the context's device;
+ *     "host" pointers are ordinary process memory.  The library never keeps a
+ *     caller pointer after the call returns and never hands out memory it
+ *     owns, except through lc_malloc (freed with lc_free).
+ *   - arrays are C-contiguous; fields are (time, latitude, longitude) with
+ *     latitude and longitude ASCENDING (what the reference reaches after its
+ *     sortby calls, LCS/trajectory.py:49-52, LCS/LCS.py:101-104).
+ *   - dtype selects the arithmetic type of fields AND positions:
+ *     LC_F32 (all float) or LC_F64 (all double).
+ *   - device work is enqueued on the context's stream and is asynchronous
+ *     unless stated; lc_sync() waits for it.
+ */
+#ifndef LCS_HIP_H
+#define LCS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_VERSION 100 /* 0.1.0 */
+
+typedef struct lc_ctx lc_ctx;
+
+enum lc_dtype { LC_F32 = 0, LC_F64 = 1 };
+
+enum lc_status {
+    LC_OK = 0,
+    LC_EINVAL = -1,       /* bad argument (null pointer, bad size, bad enum) */
+    LC_EUNSUPPORTED = -2, /* e.g. interp_order not in {1,3}                  */
+    LC_EHIP = -3,         /* a HIP runtime call failed                       */
+    LC_ENOMEM = -4
+};
+
+enum lc_tensor_layout {
+    LC_LAYOUT_REFERENCE = 0, /* 9 comps reshaped row-major to 3x3 (LCS/LCS.py:152-153) */
+    LC_LAYOUT_PHYSICAL = 1   /* Jacobian d(X,Y,Z)/d(x,y); NOT reference behaviour      */
+};
+
+/* ---- library / context ------------------------------------------------- */
+int lc_version(void);
+const char *lc_last_error(void);
+
+/* One context per device; distinct contexts may be used from distinct host
+ * threads.  The context owns one HIP stream unless lc_ctx_set_stream lends it
+ * an external one (e.g. the stream a host framework is already using). */
+int lc_ctx_create(int device, lc_ctx **out);
+int lc_ctx_destroy(lc_ctx *ctx);
+int lc_ctx_set_stream(lc_ctx *ctx, void *hip_stream /* hipStream_t or NULL = own stream */);
+int lc_sync(lc_ctx *ctx);
+
+/* ---- device memory (so a ctypes-only host needs nothing else) ---------- */
+int lc_malloc(lc_ctx *ctx, size_t bytes, void **dev_out);
+int lc_free(lc_ctx *ctx, void *dev);
+int lc_memcpy_h2d(lc_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes); /* synchronous */
+int lc_memcpy_d2h(lc_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes); /* synchronous */
+
+/* ---- field preparation --------------------------------------------------
+ * Replaces the per-call work of tools.xr_map_coordinates that does not depend
+ * on the seeds (LCS/tools.py:12-14 copies; for order 3 the whole-field spline
+ * prefilter scipy redoes inside every map_coordinates call, LCS/tools.py:26).
+ *
+ * Builds the gather-ready image of a wind time series: per time level a
+ * (ny_f+3) x (nx_f+3) array of interleaved (u,v) nodes -- 1 mirrored node in
+ * front and 2 behind on each axis, so the 2x2 / 4x4 tap windows never need
+ * index logic.  order 1: raw values.  order 3: cubic B-spline coefficients
+ * (mirror-boundary prefilter, gain 6 per axis, exact-sum initialisation ==
+ * scipy.ndimage.spline_filter(mode='mirror')).
+ *
+ * lc_packed_elems() = number of dtype elements the image needs.            */
+size_t lc_packed_elems(int nt, int ny_f, int nx_f);
+int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype,
+                  int nt, int ny_f, int nx_f, int interp_order, void *packed_dev);
+
+/* ---- K1: parcel advection ------------------------------------------------
+ * Replaces trajectory.parcel_propagation (LCS/trajectory.py:8-144) together
+ * with every tools.xr_map_coordinates call it makes (LCS/tools.py:11-41):
+ * Euler + settls_order accumulate-"SETTLS" sub-steps per time level, latitude
+ * clamp, cyclic (+-180) or clamped longitude, all nsteps fused in one launch.
+ *
+ *   packed_lin   image from lc_field_pack(order=1)   (always required: the
+ *                first/last interp_order seed rows use order 1 + 'constant')
+ *   packed_cub   image from lc_field_pack(order=3), or NULL when interp_order==1
+ *   lat_min..lon_max   extremes of the FIELD coordinates (index scale, tools.py:21-22,
+ *                and the clamp bounds, trajectory.py:63-66)
+ *   seed_lat[ny], seed_lon[nx]   seed coordinates (dtype elements, device).  The
+ *                reference seeds at the field nodes (trajectory.py:68-70): pass the
+ *                field coordinates for that.
+ *   row0, ny_global   this call advects seed rows [row0, row0+ny) of a grid of
+ *                ny_global rows (row sharding across GPUs); the pole-row rule
+ *                applies to the global row index.  Single GPU: 0, ny.
+ *   timestep     seconds, sign = direction; fields are always consumed in stored
+ *                order t0, t0+1, ... (trajectory.py:58-60,80)
+ *   t0, nsteps   first time level and number of steps (t0+nsteps <= nt-1);
+ *                the reference is t0=0, nsteps=nt-1
+ *   x_out,y_out  [ny*nx] departure longitude / latitude, degrees
+ *   traj_x,traj_y  NULL, or [(nsteps+1)*ny*nx]: positions after every step,
+ *                entry 0 = seed grid (return_traj=True, trajectory.py:125-139)
+ */
+int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype,
+              int nt, int ny_f, int nx_f,
+              double lat_min, double lat_max, double lon_min, double lon_max,
+              const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx,
+              int row0, int ny_global,
+              double timestep, int settls_order, int interp_order, int cyclic_x,
+              int t0, int nsteps,
+              void *x_out, void *y_out, void *traj_x, void *traj_y);
+
+/* ---- K3: flow-map gradient + largest singular value ------------------------
+ * Replaces LCS.flowmap_gradient (LCS/LCS.py:171-225), tools.derivative_spherical_coords
+ * + tools.fourth_order_derivative (LCS/tools.py:248-267, 190-228) and the eigen
+ * step of LCS.__call__ (LCS/LCS.py:145-157) in one fused kernel.
+ *
+ *   x_dep,y_dep  [n_in_rows*nx] departure points for global seed rows
+ *                [in_row0, in_row0+n_in_rows)
+ *   out_row0, n_out_rows   rows to produce; each needs rows r-2..r+2 inside the
+ *                input window unless it is one of the 2 first / 2 last GLOBAL rows
+ *                (one-sided rule, tools.py:210-217)
+ *   seed_lat     [n_in_rows] latitude of the input rows (dtype elements, device)
+ *   dlat, dlon   seed spacing in degrees (lat[1]-lat[0], lon[1]-lon[0]; tools.py:255-256)
+ *   fd_fp32_cast 1 = round X,Y,Z to float before differencing (reference, tools.py:258)
+ *   sigma_out    [n_out_rows*nx]
+ */
+int lc_sigma(lc_ctx *ctx, const void *x_dep, const void *y_dep, int dtype,
+             int in_row0, int n_in_rows, int nx, int ny_global,
+             const void *seed_lat_dev, double dlat, double dlon,
+             int fd_fp32_cast, int tensor_layout,
+             int out_row0, int n_out_rows, void *sigma_out);
+
+/* ---- optional smoothing of the departure fields ----------------------------
+ * Replaces scipy.ndimage.gaussian_filter(x, sigma) at LCS/LCS.py:187-190
+ * (truncate=4.0, mode='reflect', separable).  In place is not allowed. */
+int lc_gaussian_filter(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int nx,
+                       double sigma, void *tmp_dev, void *out_dev);
+
+/* ---- one-call host entry point ----------------------------------------------
+ * What a reference-side binding would call from LCS.__call__ (LCS/LCS.py:129-157):
+ * host arrays in, host arrays out; upload, pack, advect, sigma, download, sync.
+ * Any of sigma_out / x_out / y_out / traj_x / traj_y may be NULL. */
+int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, int dtype,
+                int nt, int ny_f, int nx_f,
+                const void *lat_f_host, const void *lon_f_host,
+                const void *seed_lat_host, int ny, const void *seed_lon_host, int nx,
+                double timestep, int settls_order, int interp_order, int cyclic_x,
+                int t0, int nsteps, double gauss_sigma /* <=0: none */,
+                int fd_fp32_cast, int tensor_layout,
+                void *sigma_out, void *x_out, void *y_out, void *traj_x, void *traj_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCS_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of liblcs_hip.so -- one prototype per symbol of include/lcs_hip.h.
+
+The library is the product; there is no Python or CPU fallback.  If it is not
+built, loading fails loudly with the command that builds it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblcs_hip.so")
+
+LC_F32, LC_F64 = 0, 1
+LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM = 0, -1, -2, -3, -4
+LC_LAYOUT_REFERENCE, LC_LAYOUT_PHYSICAL = 0, 1
+
+_vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/lcs_hip.h declaration by declaration
+PROTOTYPES = {
+    "lc_version": (_i, []),
+    "lc_last_error": (C.c_char_p, []),
+    "lc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "lc_ctx_destroy": (_i, [_vp]),
+    "lc_ctx_set_stream": (_i, [_vp, _vp]),
+    "lc_sync": (_i, [_vp]),
+    "lc_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "lc_free": (_i, [_vp, _vp]),
+    "lc_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "lc_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "lc_packed_elems": (_sz, [_i, _i, _i]),
+    "lc_field_pack": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "lc_advect": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i,
+                       _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lc_sigma": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _d, _d, _i, _i, _i, _i, _vp]),
+    "lc_gaussian_filter": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp]),
+    "lc_lcs_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i,
+                         _d, _i, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class LCSError(RuntimeError):
+    """A C-ABI call returned LC_EHIP / LC_ENOMEM."""
+
+
+def load(path: str | None = None):
+    """Load liblcs_hip.so and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} is missing: the HIP extension is the only compute path of this package "
+            "(no CPU fallback). Build it with `python -m lagrangiancoherence_amd.build`.")
+    lib = C.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status: int, lib=None):
+    """Translate an lc_status into the exception the reference would raise."""
+    if status == LC_OK:
+        return
+    lib = lib or load()
+    msg = lib.lc_last_error().decode("utf-8", "replace")
+    if status in (LC_EINVAL, LC_EUNSUPPORTED):
+        raise ValueError(msg)
+    if status == LC_ENOMEM:
+        raise MemoryError(msg)
+    raise LCSError(msg)

@@ -1,0 +1,334 @@
+// K1 -- parcel advection: Euler + K accumulate-"SETTLS" sub-steps per time level,
+// all time levels fused in one launch, one thread per seed, positions in registers.
+//
+// Restates trajectory.parcel_propagation (LCS/trajectory.py:55-126) and the
+// tools.xr_map_coordinates calls inside it (LCS/tools.py:19-39), including the
+// reference's quirks:
+//   Q2  index scale n, not n-1                      tools.py:21-22
+//   Q3  first/last `order` seed rows: order 1, 'constant'; others `order`, 'wrap'
+//   Q4  every SETTLS iteration ADDS to the position  trajectory.py:110-112
+//   Q5  conversion_x from the SEED latitude          trajectory.py:56-57
+//   Q6  fields consumed in stored order for dt<0     trajectory.py:58-60,80
+//   Q7  cyclic wrap hard-coded to +-180, floor-mod   trajectory.py:93-94
+//   Q8  NaN latitude -> y_min                        trajectory.py:89-90
+// Floating-point operation ORDER follows numpy/scipy where it is cheap to do so
+// (contraction off in the position update and the double-precision tap sum), so
+// the float64 path agrees with the CPU oracle to rounding, not merely to
+// truncation error.
+//
+// Gather source: the padded interleaved image built by lc_field_pack (pack.hip):
+// the 2x2 (order 1) or 4x4 (order 3) tap window of a wrapped coordinate is
+// always in range and its (u,v) pairs are contiguous along x, so one sample
+// position costs 2 (order 1, float) wide loads per level instead of 8 scalars.
+#include "lcs_common.h"
+
+namespace {
+
+constexpr int TILE_W = 16;
+constexpr int TILE_H = 16;
+constexpr int BLOCK = TILE_W * TILE_H;
+
+template <typename T>
+struct AdvectArgs {
+    const T *lin;  // order-1 image (raw values)
+    const T *img;  // image for the interior rows (== lin for order 1, coefficients for order 3)
+    size_t level_elems;
+    int pitch;  // nodes per padded row
+    int ny_f, nx_f;
+    T lat_min, lat_span, lon_min, lon_span;  // index transform (Q2)
+    T y_min, y_max, x_min, x_max;            // clamp bounds = field coordinate extremes
+    const T *seed_lat, *seed_lon;
+    int ny, nx;          // local seed block
+    int row0, ny_global; // pole rule uses the global row index
+    T dt, half_dt;       // T(timestep), T(0.5*timestep)
+    T dtcy, hdtcy;       // T(timestep*conversion_y), T((0.5*timestep)*conversion_y)
+    int K, order, cyclic, t0, nsteps;
+    T *x_out, *y_out, *traj_x, *traj_y;
+    int ntx, ntiles;
+};
+
+template <typename T>
+struct Pair {
+    T u, v;
+};
+
+// scipy NI_EXTEND_WRAP coordinate map (ni_interpolation.c map_coordinate):
+// identity on [0, n-1], otherwise periodic with period n-1.
+template <typename T>
+__device__ __forceinline__ T wrap_coord(T c, T sz) {
+    if (c < T(0))
+        c += sz * (trunc(-c / sz) + T(1));
+    else if (c > sz)
+        c -= sz * trunc(c / sz);
+    return c;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// python/numpy float floor-mod by 180 (npy_divmod): exact, fmod based.
+template <typename T>
+__device__ __forceinline__ T pymod180(T x) {
+    T m = fmod(x, T(180));
+    if (m != T(0)) {
+        if (m < T(0)) m += T(180);
+    } else {
+        m = T(0);
+    }
+    return m;
+}
+
+// ---- order 1 ---------------------------------------------------------------
+template <typename T, bool WRAP>
+__device__ __forceinline__ Pair<T> sample1(const T *__restrict__ lvl, int pitch, int ny_f, int nx_f, T cy, T cx) {
+#pragma clang fp contract(off)
+    Pair<T> r;
+    if (WRAP) {
+        cy = wrap_coord<T>(cy, T(ny_f - 1));
+        cx = wrap_coord<T>(cx, T(nx_f - 1));
+    } else {
+        // 'constant': exactly cval=0 outside [0, n-1] (no interpolation towards cval)
+        if (cy < T(0) || cy > T(ny_f - 1) || cx < T(0) || cx > T(nx_f - 1)) {
+            r.u = T(0);
+            r.v = T(0);
+            return r;
+        }
+    }
+    const T fy = floor(cy), fx = floor(cx);
+    const int y0 = clampi((int)fy, 0, ny_f - 1);  // clamp: memory safety for NaN/inf/rounding
+    const int x0 = clampi((int)fx, 0, nx_f - 1);
+    const T ty = cy - fy, tx = cx - fx;
+    const T wy0 = T(1) - ty, wy1 = T(1) - wy0;  // scipy: last weight = 1 - sum(others)
+    const T wx0 = T(1) - tx, wx1 = T(1) - wx0;
+    const T *p0 = lvl + ((size_t)(y0 + LC_PAD_LO) * pitch + (x0 + LC_PAD_LO)) * 2;
+    const T *p1 = p0 + (size_t)pitch * 2;
+    T a[4], b[4];
+    __builtin_memcpy(a, p0, sizeof(a));  // {u00, v00, u01, v01}
+    __builtin_memcpy(b, p1, sizeof(b));  // {u10, v10, u11, v11}
+    // scipy tap order (last axis fastest); per tap ((value*wy)*wx), summed from 0
+    T su = T(0), sv = T(0);
+    su += (a[0] * wy0) * wx0;
+    sv += (a[1] * wy0) * wx0;
+    su += (a[2] * wy0) * wx1;
+    sv += (a[3] * wy0) * wx1;
+    su += (b[0] * wy1) * wx0;
+    sv += (b[1] * wy1) * wx0;
+    su += (b[2] * wy1) * wx1;
+    sv += (b[3] * wy1) * wx1;
+    r.u = su;
+    r.v = sv;
+    return r;
+}
+
+// ---- order 3 ('wrap' only: pole rows always use order 1) -------------------
+template <typename T>
+__device__ __forceinline__ void cubic_weights(T t, T w[4]) {
+#pragma clang fp contract(off)
+    // scipy get_spline_interpolation_weights, order 3
+    const T y = t, z = T(1) - t;
+    w[1] = (y * y * (y - T(2)) * T(3) + T(4)) / T(6);
+    w[2] = (z * z * (z - T(2)) * T(3) + T(4)) / T(6);
+    w[0] = z * z * z / T(6);
+    w[3] = T(1) - w[0] - w[1] - w[2];
+}
+
+template <typename T>
+__device__ __forceinline__ Pair<T> sample3(const T *__restrict__ lvl, int pitch, int ny_f, int nx_f, T cy, T cx) {
+#pragma clang fp contract(off)
+    cy = wrap_coord<T>(cy, T(ny_f - 1));
+    cx = wrap_coord<T>(cx, T(nx_f - 1));
+    const T fy = floor(cy), fx = floor(cx);
+    const int y0 = clampi((int)fy, 0, ny_f - 1);
+    const int x0 = clampi((int)fx, 0, nx_f - 1);
+    T wy[4], wx[4];
+    cubic_weights<T>(cy - fy, wy);
+    cubic_weights<T>(cx - fx, wx);
+    // window starts at (y0-1, x0-1) -> padded (y0, x0)
+    const T *p = lvl + ((size_t)y0 * pitch + x0) * 2;
+    T su = T(0), sv = T(0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        T row[8];
+        __builtin_memcpy(row, p + (size_t)a * pitch * 2, sizeof(row));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            su += (row[2 * b] * wy[a]) * wx[b];
+            sv += (row[2 * b + 1] * wy[a]) * wx[b];
+        }
+    }
+    Pair<T> r;
+    r.u = su;
+    r.v = sv;
+    return r;
+}
+
+template <typename T, int ORDER, bool WRAP>
+__device__ __forceinline__ Pair<T> sample(const T *__restrict__ lvl, const AdvectArgs<T> &A, T x, T y) {
+#pragma clang fp contract(off)
+    // tools.py:21-22: (n * (x - min)) / (max - min)
+    const T cx = (T(A.nx_f) * (x - A.lon_min)) / A.lon_span;
+    const T cy = (T(A.ny_f) * (y - A.lat_min)) / A.lat_span;
+    if (ORDER == 3) return sample3<T>(lvl, A.pitch, A.ny_f, A.nx_f, cy, cx);
+    return sample1<T, WRAP>(lvl, A.pitch, A.ny_f, A.nx_f, cy, cx);
+}
+
+template <typename T>
+__device__ __forceinline__ void clamp_position(const AdvectArgs<T> &A, T &x, T &y) {
+    // trajectory.py:89-90 -- where(y > y_min, y, y_min): NaN -> y_min (Q8)
+    y = (y > A.y_min) ? y : A.y_min;
+    y = (y < A.y_max) ? y : A.y_max;
+    if (A.cyclic) {
+        // trajectory.py:93-94 (Q7)
+        if (!(x > T(-180))) x = pymod180<T>(x);
+        if (!(x < T(180))) x = T(-180) + pymod180<T>(x);
+    } else {
+        // per-point clamp (documented divergence from the outer-indexing defect Q9)
+        if (x < A.x_min) x = A.x_min;
+        if (x > A.x_max) x = A.x_max;
+    }
+}
+
+template <typename T, int ORDER, bool WRAP>
+__device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image, int iy, int ix) {
+#pragma clang fp contract(off)
+    T x = A.seed_lon[ix];
+    T y = A.seed_lat[iy];
+    // trajectory.py:56 -- 180 / (pi * R * |cos(lat * pi / 180)|), seed latitude (Q5)
+    const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((y * T(3.141592653589793)) / T(180))));
+    const T dtcx = A.dt * cx_conv;        // timestep * conversion_x
+    const T hdtcx = A.half_dt * cx_conv;  // (0.5 * timestep) * conversion_x
+    const size_t idx = (size_t)iy * A.nx + ix;
+    const size_t plane = (size_t)A.ny * A.nx;
+    if (A.traj_x) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const T *lvl = image + (size_t)A.t0 * A.level_elems;
+    for (int s = 0; s < A.nsteps; ++s) {
+        const T *nxt = lvl + A.level_elems;
+        const Pair<T> e = sample<T, ORDER, WRAP>(lvl, A, x, y);  // trajectory.py:82-84
+        y = y + A.dtcy * e.v;                                    // :86
+        x = x + dtcx * e.u;                                      // :87
+        clamp_position<T>(A, x, y);
+        for (int k = 0; k < A.K; ++k) {                          // :100
+            const Pair<T> c = sample<T, ORDER, WRAP>(lvl, A, x, y);  // :105,107
+            const Pair<T> n = sample<T, ORDER, WRAP>(nxt, A, x, y);  // :106,108
+            y = y + A.hdtcy * ((e.v + T(2) * c.v) - n.v);            // :110
+            x = x + hdtcx * ((e.u + T(2) * c.u) - n.u);              // :112
+            clamp_position<T>(A, x, y);
+        }
+        if (A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl = nxt;
+    }
+    A.x_out[idx] = x;
+    A.y_out[idx] = y;
+}
+
+template <typename T, int ORDER>
+__global__ void __launch_bounds__(BLOCK) advect_kernel(const AdvectArgs<T> A) {
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give
+    // XCD k the k-th contiguous eighth of the tile list -- its L2 then serves one latitude band.
+    const int per_xcd = (A.ntiles + 7) / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile >= A.ntiles) return;
+    const int tyi = tile / A.ntx, txi = tile - tyi * A.ntx;
+    const int ix = txi * TILE_W + (threadIdx.x % TILE_W);
+    const int iy = tyi * TILE_H + (threadIdx.x / TILE_W);
+    if (ix >= A.nx || iy >= A.ny) return;
+    const int grow = A.row0 + iy;
+    const bool pole = grow < A.order || grow >= A.ny_global - A.order;  // tools.py:24-33 (Q3)
+    if (pole)
+        advect_seed<T, 1, false>(A, A.lin, iy, ix);
+    else
+        advect_seed<T, ORDER, true>(A, A.img, iy, ix);
+}
+
+template <typename T>
+int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int nt, int ny_f, int nx_f,
+                double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
+                const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
+                int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y) {
+    AdvectArgs<T> A;
+    A.lin = (const T *)packed_lin;
+    A.img = (order == 3) ? (const T *)packed_cub : (const T *)packed_lin;
+    A.level_elems = lc_level_elems(ny_f, nx_f);
+    A.pitch = nx_f + LC_PAD;
+    A.ny_f = ny_f;
+    A.nx_f = nx_f;
+    A.lat_min = (T)lat_min;
+    A.lon_min = (T)lon_min;
+    A.lat_span = (T)lat_max - (T)lat_min;
+    A.lon_span = (T)lon_max - (T)lon_min;
+    A.y_min = (T)lat_min;
+    A.y_max = (T)lat_max;
+    A.x_min = (T)lon_min;
+    A.x_max = (T)lon_max;
+    A.seed_lat = (const T *)seed_lat;
+    A.seed_lon = (const T *)seed_lon;
+    A.ny = ny;
+    A.nx = nx;
+    A.row0 = row0;
+    A.ny_global = ny_global;
+    const double conv_y = 180.0 / (6371000.0 * 3.141592653589793);  // trajectory.py:55
+    A.dt = (T)timestep;
+    A.half_dt = (T)(0.5 * timestep);
+    A.dtcy = (T)(timestep * conv_y);
+    A.hdtcy = (T)((0.5 * timestep) * conv_y);
+    A.K = K;
+    A.order = order;
+    A.cyclic = cyclic;
+    A.t0 = t0;
+    A.nsteps = nsteps;
+    A.x_out = (T *)x_out;
+    A.y_out = (T *)y_out;
+    A.traj_x = (T *)traj_x;
+    A.traj_y = (T *)traj_y;
+    A.ntx = (nx + TILE_W - 1) / TILE_W;
+    const int nty = (ny + TILE_H - 1) / TILE_H;
+    A.ntiles = A.ntx * nty;
+    const int grid = ((A.ntiles + 7) / 8) * 8;
+    if (order == 3)
+        hipLaunchKernelGGL((advect_kernel<T, 3>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+    else
+        hipLaunchKernelGGL((advect_kernel<T, 1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+    LC_HIP_CHECK(hipGetLastError());
+    return LC_OK;
+}
+
+}  // namespace
+
+extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype, int nt, int ny_f,
+                         int nx_f, double lat_min, double lat_max, double lon_min, double lon_max,
+                         const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx, int row0, int ny_global,
+                         double timestep, int settls_order, int interp_order, int cyclic_x, int t0, int nsteps,
+                         void *x_out, void *y_out, void *traj_x, void *traj_y) {
+    LC_REQUIRE(ctx, "lc_advect: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_advect: bad dtype %d", dtype);
+    if (interp_order != 1 && interp_order != 3) {
+        lc_set_error("lc_advect: interp_order %d unsupported (1 and 3 are implemented; 0 fails in the reference too)",
+                     interp_order);
+        return LC_EUNSUPPORTED;
+    }
+    LC_REQUIRE(packed_lin, "lc_advect: packed_lin is required (pole rows use order 1)");
+    LC_REQUIRE(interp_order == 1 || packed_cub, "lc_advect: interp_order 3 needs packed_cub");
+    LC_REQUIRE(nt >= 2 && ny_f >= 4 && nx_f >= 4, "lc_advect: field too small (nt=%d ny_f=%d nx_f=%d)", nt, ny_f, nx_f);
+    LC_REQUIRE(ny >= 1 && nx >= 1 && seed_lat_dev && seed_lon_dev, "lc_advect: bad seed grid");
+    LC_REQUIRE(row0 >= 0 && row0 + ny <= ny_global, "lc_advect: rows [%d,%d) outside global grid of %d rows", row0,
+               row0 + ny, ny_global);
+    LC_REQUIRE(settls_order >= 0, "lc_advect: SETTLS_order must be >= 0");
+    LC_REQUIRE(t0 >= 0 && nsteps >= 0 && t0 + nsteps <= nt - 1, "lc_advect: steps [%d,%d) need levels up to %d, have %d",
+               t0, t0 + nsteps, t0 + nsteps, nt);
+    LC_REQUIRE(x_out && y_out, "lc_advect: null output");
+    LC_REQUIRE((traj_x == nullptr) == (traj_y == nullptr), "lc_advect: traj_x and traj_y must both be set or both NULL");
+    LC_REQUIRE(lat_max > lat_min && lon_max > lon_min, "lc_advect: field coordinates must be ascending");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (dtype == LC_F32)
+        return advect_impl<float>(ctx, packed_lin, packed_cub, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
+                                  seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
+                                  interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y);
+    return advect_impl<double>(ctx, packed_lin, packed_cub, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
+                               seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
+                               interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y);
+}

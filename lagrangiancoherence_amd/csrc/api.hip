@@ -1,0 +1,326 @@
+// C ABI glue: contexts, device memory, error strings, field packing entry point,
+// Gaussian smoothing of the departure fields, and the one-call host entry point.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "lcs_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void lc_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *lc_last_error(void) { return g_err; }
+extern "C" int lc_version(void) { return LC_VERSION; }
+
+extern "C" int lc_ctx_create(int device, lc_ctx **out) {
+    LC_REQUIRE(out, "lc_ctx_create: null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    LC_HIP_CHECK(hipGetDeviceCount(&ndev));
+    LC_REQUIRE(device >= 0 && device < ndev, "lc_ctx_create: device %d not in [0,%d)", device, ndev);
+    LC_HIP_CHECK(hipSetDevice(device));
+    lc_ctx *c = new (std::nothrow) lc_ctx;
+    if (!c) {
+        lc_set_error("lc_ctx_create: out of host memory");
+        return LC_ENOMEM;
+    }
+    c->device = device;
+    c->own_stream = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        lc_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete c;
+        return LC_EHIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
+    if (!ctx) return LC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_set_stream(lc_ctx *ctx, void *hip_stream) {
+    LC_REQUIRE(ctx, "lc_ctx_set_stream: null context");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return LC_OK;
+}
+
+extern "C" int lc_sync(lc_ctx *ctx) {
+    LC_REQUIRE(ctx, "lc_sync: null context");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LC_OK;
+}
+
+extern "C" int lc_malloc(lc_ctx *ctx, size_t bytes, void **dev_out) {
+    LC_REQUIRE(ctx && dev_out, "lc_malloc: null argument");
+    *dev_out = nullptr;
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dev_out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        lc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? LC_ENOMEM : LC_EHIP;
+    }
+    return LC_OK;
+}
+
+extern "C" int lc_free(lc_ctx *ctx, void *dev) {
+    LC_REQUIRE(ctx, "lc_free: null context");
+    if (!dev) return LC_OK;
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    LC_HIP_CHECK(hipFree(dev));
+    return LC_OK;
+}
+
+extern "C" int lc_memcpy_h2d(lc_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+    LC_REQUIRE(ctx && (bytes == 0 || (dev_dst && host_src)), "lc_memcpy_h2d: null argument");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    LC_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LC_OK;
+}
+
+extern "C" int lc_memcpy_d2h(lc_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+    LC_REQUIRE(ctx && (bytes == 0 || (host_dst && dev_src)), "lc_memcpy_d2h: null argument");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    LC_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LC_OK;
+}
+
+extern "C" size_t lc_packed_elems(int nt, int ny_f, int nx_f) {
+    if (nt < 1 || ny_f < 1 || nx_f < 1) return 0;
+    return (size_t)nt * lc_level_elems(ny_f, nx_f);
+}
+
+extern "C" int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype, int nt, int ny_f, int nx_f,
+                             int interp_order, void *packed_dev) {
+    LC_REQUIRE(ctx, "lc_field_pack: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_field_pack: bad dtype %d", dtype);
+    LC_REQUIRE(u_dev && v_dev && packed_dev, "lc_field_pack: null pointer");
+    LC_REQUIRE(nt >= 1 && ny_f >= 4 && nx_f >= 4, "lc_field_pack: field too small (nt=%d ny_f=%d nx_f=%d)", nt, ny_f,
+               nx_f);
+    if (interp_order != 1 && interp_order != 3) {
+        lc_set_error("lc_field_pack: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
+        return LC_EUNSUPPORTED;
+    }
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    return lc_launch_pack(ctx, u_dev, v_dev, dtype, nt, ny_f, nx_f, interp_order, packed_dev);
+}
+
+// ---------------------------------------------------------------------------
+// Gaussian smoothing (LCS/LCS.py:187-190 -> scipy.ndimage.gaussian_filter defaults:
+// truncate=4.0, mode='reflect', axis 0 then axis 1, output dtype = input dtype,
+// accumulation in double, symmetric-kernel summation order of ni_filters.c).
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int GAUSS_MAX_RADIUS = 256;
+
+struct GaussW {
+    double w[GAUSS_MAX_RADIUS + 1];  // w[0] centre ... w[radius]
+    int radius;
+};
+
+__device__ __forceinline__ int reflect_index(int i, int n) {
+    // scipy 'reflect' (d c b a | a b c d | d c b a), any distance
+    if (n == 1) return 0;
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+template <typename T, int AXIS>
+__global__ void gauss_kernel(const T *__restrict__ in, T *__restrict__ out, int ny, int nx, const GaussW G) {
+    const size_t total = (size_t)ny * nx;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / nx), x = (int)(i - (size_t)y * nx);
+        double acc = (double)in[i] * G.w[0];
+        for (int j = G.radius; j >= 1; --j) {  // outermost pair first, as correlate1d does
+            double lo, hi;
+            if (AXIS == 0) {
+                lo = (double)in[(size_t)reflect_index(y - j, ny) * nx + x];
+                hi = (double)in[(size_t)reflect_index(y + j, ny) * nx + x];
+            } else {
+                lo = (double)in[(size_t)y * nx + reflect_index(x - j, nx)];
+                hi = (double)in[(size_t)y * nx + reflect_index(x + j, nx)];
+            }
+            acc += (lo + hi) * G.w[j];
+        }
+        out[i] = (T)acc;
+    }
+}
+
+template <typename T>
+int gauss_impl(lc_ctx *ctx, const T *in, int ny, int nx, const GaussW &G, T *tmp, T *out) {
+    const size_t total = (size_t)ny * nx;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((gauss_kernel<T, 0>), dim3(blocks), dim3(256), 0, ctx->stream, in, tmp, ny, nx, G);
+    hipLaunchKernelGGL((gauss_kernel<T, 1>), dim3(blocks), dim3(256), 0, ctx->stream, (const T *)tmp, out, ny, nx, G);
+    LC_HIP_CHECK(hipGetLastError());
+    return LC_OK;
+}
+
+}  // namespace
+
+extern "C" int lc_gaussian_filter(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int nx, double sigma,
+                                  void *tmp_dev, void *out_dev) {
+    LC_REQUIRE(ctx, "lc_gaussian_filter: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_gaussian_filter: bad dtype %d", dtype);
+    LC_REQUIRE(in_dev && tmp_dev && out_dev && in_dev != out_dev && in_dev != tmp_dev && tmp_dev != out_dev,
+               "lc_gaussian_filter: in, tmp and out must be three distinct buffers");
+    LC_REQUIRE(ny >= 1 && nx >= 1 && sigma > 0, "lc_gaussian_filter: bad size or sigma");
+    GaussW G;
+    G.radius = (int)(4.0 * sigma + 0.5);  // scipy: int(truncate * sd + 0.5)
+    if (G.radius > GAUSS_MAX_RADIUS) {
+        lc_set_error("lc_gaussian_filter: sigma %g needs radius %d > %d", sigma, G.radius, GAUSS_MAX_RADIUS);
+        return LC_EUNSUPPORTED;
+    }
+    // scipy _gaussian_kernel1d: phi = exp(-0.5/sigma^2 * x^2); phi /= phi.sum()
+    double sum = 0.0;
+    std::vector<double> phi(2 * G.radius + 1);
+    for (int k = -G.radius; k <= G.radius; ++k) phi[k + G.radius] = std::exp(-0.5 / (sigma * sigma) * (double)k * k);
+    for (double p : phi) sum += p;
+    for (int k = 0; k <= G.radius; ++k) G.w[k] = phi[k + G.radius] / sum;
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (dtype == LC_F32) return gauss_impl<float>(ctx, (const float *)in_dev, ny, nx, G, (float *)tmp_dev, (float *)out_dev);
+    return gauss_impl<double>(ctx, (const double *)in_dev, ny, nx, G, (double *)tmp_dev, (double *)out_dev);
+}
+
+// ---------------------------------------------------------------------------
+// One-call host entry point (LCS/LCS.py:129-157 on host arrays).
+// ---------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) {
+            lc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            p = nullptr;
+            return e == hipErrorOutOfMemory ? LC_ENOMEM : LC_EHIP;
+        }
+        return LC_OK;
+    }
+};
+
+template <typename T>
+void coord_extremes(const void *lat, int n, double *lo, double *hi) {
+    const T *p = (const T *)lat;
+    *lo = (double)p[0];
+    *hi = (double)p[n - 1];
+}
+}  // namespace
+
+#define LC_TRY(expr)              \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != LC_OK) return _s; \
+    } while (0)
+
+extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, int dtype, int nt, int ny_f, int nx_f,
+                           const void *lat_f_host, const void *lon_f_host, const void *seed_lat_host, int ny,
+                           const void *seed_lon_host, int nx, double timestep, int settls_order, int interp_order,
+                           int cyclic_x, int t0, int nsteps, double gauss_sigma, int fd_fp32_cast, int tensor_layout,
+                           void *sigma_out, void *x_out, void *y_out, void *traj_x, void *traj_y) {
+    LC_REQUIRE(ctx, "lc_lcs_host: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_lcs_host: bad dtype %d", dtype);
+    LC_REQUIRE(u_host && v_host && lat_f_host && lon_f_host && seed_lat_host && seed_lon_host,
+               "lc_lcs_host: null input pointer");
+    LC_REQUIRE(nt >= 2 && ny_f >= 4 && nx_f >= 4 && ny >= 1 && nx >= 1, "lc_lcs_host: bad sizes");
+    LC_REQUIRE((traj_x == nullptr) == (traj_y == nullptr), "lc_lcs_host: traj_x/traj_y must be set together");
+    LC_REQUIRE(!sigma_out || (ny >= 5 && nx >= 5), "lc_lcs_host: sigma needs at least a 5x5 seed grid");
+    if (interp_order != 1 && interp_order != 3) {
+        lc_set_error("lc_lcs_host: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
+        return LC_EUNSUPPORTED;
+    }
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t es = dtype == LC_F32 ? 4 : 8;
+    const size_t fbytes = (size_t)nt * ny_f * nx_f * es;
+    const size_t pbytes = lc_packed_elems(nt, ny_f, nx_f) * es;
+    const size_t sbytes = (size_t)ny * nx * es;
+    double lat_min, lat_max, lon_min, lon_max, s_lat0, s_lat1, s_lon0, s_lon1;
+    if (dtype == LC_F32) {
+        coord_extremes<float>(lat_f_host, ny_f, &lat_min, &lat_max);
+        coord_extremes<float>(lon_f_host, nx_f, &lon_min, &lon_max);
+        s_lat0 = ((const float *)seed_lat_host)[0];
+        s_lat1 = ((const float *)seed_lat_host)[ny > 1 ? 1 : 0];
+        s_lon0 = ((const float *)seed_lon_host)[0];
+        s_lon1 = ((const float *)seed_lon_host)[nx > 1 ? 1 : 0];
+    } else {
+        coord_extremes<double>(lat_f_host, ny_f, &lat_min, &lat_max);
+        coord_extremes<double>(lon_f_host, nx_f, &lon_min, &lon_max);
+        s_lat0 = ((const double *)seed_lat_host)[0];
+        s_lat1 = ((const double *)seed_lat_host)[ny > 1 ? 1 : 0];
+        s_lon0 = ((const double *)seed_lon_host)[0];
+        s_lon1 = ((const double *)seed_lon_host)[nx > 1 ? 1 : 0];
+    }
+    // spacing in the coordinate dtype, as lat[1]-lat[0] evaluates in numpy (tools.py:255-256)
+    const double dlat = dtype == LC_F32 ? (double)((float)s_lat1 - (float)s_lat0) : s_lat1 - s_lat0;
+    const double dlon = dtype == LC_F32 ? (double)((float)s_lon1 - (float)s_lon0) : s_lon1 - s_lon0;
+
+    DevBuf u, v, lin, cub, slat, slon, x, y, tx, ty, sig, gx, gy, gtmp;
+    LC_TRY(u.alloc(fbytes));
+    LC_TRY(v.alloc(fbytes));
+    LC_TRY(lin.alloc(pbytes));
+    if (interp_order == 3) LC_TRY(cub.alloc(pbytes));
+    LC_TRY(slat.alloc(ny * es));
+    LC_TRY(slon.alloc(nx * es));
+    LC_TRY(x.alloc(sbytes));
+    LC_TRY(y.alloc(sbytes));
+    if (traj_x) {
+        LC_TRY(tx.alloc(sbytes * (size_t)(nsteps + 1)));
+        LC_TRY(ty.alloc(sbytes * (size_t)(nsteps + 1)));
+    }
+    hipStream_t st = ctx->stream;
+    LC_HIP_CHECK(hipMemcpyAsync(u.p, u_host, fbytes, hipMemcpyHostToDevice, st));
+    LC_HIP_CHECK(hipMemcpyAsync(v.p, v_host, fbytes, hipMemcpyHostToDevice, st));
+    LC_HIP_CHECK(hipMemcpyAsync(slat.p, seed_lat_host, ny * es, hipMemcpyHostToDevice, st));
+    LC_HIP_CHECK(hipMemcpyAsync(slon.p, seed_lon_host, nx * es, hipMemcpyHostToDevice, st));
+    LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p));
+    if (interp_order == 3) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 3, cub.p));
+    LC_TRY(lc_advect(ctx, lin.p, cub.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p,
+                     nx, 0, ny, timestep, settls_order, interp_order, cyclic_x, t0, nsteps, x.p, y.p, tx.p, ty.p));
+    if (sigma_out) {
+        LC_TRY(sig.alloc(sbytes));
+        const void *xs = x.p, *ys = y.p;
+        if (gauss_sigma > 0) {
+            LC_TRY(gx.alloc(sbytes));
+            LC_TRY(gy.alloc(sbytes));
+            LC_TRY(gtmp.alloc(sbytes));
+            LC_TRY(lc_gaussian_filter(ctx, x.p, dtype, ny, nx, gauss_sigma, gtmp.p, gx.p));
+            LC_TRY(lc_gaussian_filter(ctx, y.p, dtype, ny, nx, gauss_sigma, gtmp.p, gy.p));
+            xs = gx.p;
+            ys = gy.p;
+        }
+        LC_TRY(lc_sigma(ctx, xs, ys, dtype, 0, ny, nx, ny, slat.p, dlat, dlon, fd_fp32_cast, tensor_layout, 0, ny,
+                        sig.p));
+        LC_HIP_CHECK(hipMemcpyAsync(sigma_out, sig.p, sbytes, hipMemcpyDeviceToHost, st));
+    }
+    if (x_out) LC_HIP_CHECK(hipMemcpyAsync(x_out, x.p, sbytes, hipMemcpyDeviceToHost, st));
+    if (y_out) LC_HIP_CHECK(hipMemcpyAsync(y_out, y.p, sbytes, hipMemcpyDeviceToHost, st));
+    if (traj_x) {
+        LC_HIP_CHECK(hipMemcpyAsync(traj_x, tx.p, sbytes * (size_t)(nsteps + 1), hipMemcpyDeviceToHost, st));
+        LC_HIP_CHECK(hipMemcpyAsync(traj_y, ty.p, sbytes * (size_t)(nsteps + 1), hipMemcpyDeviceToHost, st));
+    }
+    LC_HIP_CHECK(hipStreamSynchronize(st));
+    return LC_OK;  // DevBuf destructors free after the sync
+}

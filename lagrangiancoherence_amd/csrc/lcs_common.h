@@ -1,0 +1,47 @@
+// Internal header shared by the HIP translation units of liblcs_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/lcs_hip.h"
+
+struct lc_ctx {
+    int device;
+    hipStream_t own_stream;
+    hipStream_t stream;  // the one work is enqueued on (own or borrowed)
+};
+
+void lc_set_error(const char *fmt, ...);
+
+#define LC_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            lc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                         __LINE__);                                                     \
+            return LC_EHIP;                                                             \
+        }                                                                               \
+    } while (0)
+
+#define LC_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            lc_set_error(__VA_ARGS__); \
+            return LC_EINVAL;          \
+        }                              \
+    } while (0)
+
+// Padded gather image geometry (see lc_field_pack in lcs_hip.h).
+constexpr int LC_PAD_LO = 1;
+constexpr int LC_PAD_HI = 2;
+constexpr int LC_PAD = LC_PAD_LO + LC_PAD_HI;
+
+static inline size_t lc_level_elems(int ny_f, int nx_f) {
+    return (size_t)(ny_f + LC_PAD) * (size_t)(nx_f + LC_PAD) * 2;
+}
+
+// kernel launchers implemented in the .hip files
+int lc_launch_pack(lc_ctx *ctx, const void *u, const void *v, int dtype, int nt, int ny_f, int nx_f,
+                   int order, void *packed);

@@ -1,0 +1,159 @@
+// Field preparation kernels: interleave (u,v), cubic B-spline prefilter, mirror pads.
+//
+// Replaces the seed-independent work the reference repeats inside every
+// tools.xr_map_coordinates call (LCS/tools.py:12-14, and for order 3 the spline
+// prefilter scipy.ndimage.map_coordinates runs on the whole field each call,
+// LCS/tools.py:26-30).  Done once per wind time series here.
+//
+// Image layout per time level: (ny_f+3) x (nx_f+3) nodes, node = {u, v}.
+// Node (y, x) of the field sits at padded position (y+1, x+1).  Pad nodes hold
+// the mirrored interior value (i -> |i| reflected about 0 and n-1), which is
+// the tap rule scipy applies to out-of-range spline taps.
+#include "lcs_common.h"
+
+namespace {
+
+__device__ __forceinline__ int mirror_index(int i, int n) {
+    // scipy ni_interpolation.c tap mirroring; here |i| never exceeds n+1
+    if (i < 0) i = -i;
+    if (i > n - 1) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// interior nodes: packed[t][y+1][x+1] = {u[t][y][x], v[t][y][x]}
+template <typename T>
+__global__ void pack_interior_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ packed,
+                                     int ny, int nx, size_t n_nodes_total) {
+    const size_t plane = (size_t)ny * nx;
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_nodes_total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / plane;
+        const size_t r = i - t * plane;
+        const int y = (int)(r / nx);
+        const int x = (int)(r - (size_t)y * nx);
+        const size_t o = (t * level + (size_t)(y + LC_PAD_LO) * pitch + (x + LC_PAD_LO)) * 2;
+        packed[o] = u[i];
+        packed[o + 1] = v[i];
+    }
+}
+
+// pad nodes <- mirrored interior nodes (runs after the interior is final)
+template <typename T>
+__global__ void fill_pads_kernel(T *__restrict__ packed, int nt, int ny, int nx) {
+    const int pitch = nx + LC_PAD;
+    const int prow = ny + LC_PAD;
+    const size_t level = (size_t)prow * pitch;
+    const size_t total = level * nt;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / level;
+        const size_t r = i - t * level;
+        const int py = (int)(r / pitch);
+        const int px = (int)(r - (size_t)py * pitch);
+        const int y = py - LC_PAD_LO, x = px - LC_PAD_LO;
+        if (y >= 0 && y < ny && x >= 0 && x < nx) continue;
+        const int sy = mirror_index(y, ny), sx = mirror_index(x, nx);
+        const size_t s = (t * level + (size_t)(sy + LC_PAD_LO) * pitch + (sx + LC_PAD_LO)) * 2;
+        packed[2 * i] = packed[s];
+        packed[2 * i + 1] = packed[s + 1];
+    }
+}
+
+// One line of the separable cubic B-spline prefilter, in place, mirror boundary.
+// Same recursion as scipy ni_splines.c (_apply_filter_gain, _init_causal_mirror,
+// _init_anticausal_mirror) for the single cubic pole z = sqrt(3) - 2.
+// Arithmetic in double whatever T is; the stored coefficients are T.
+template <typename T>
+__device__ void prefilter_line(T *c, size_t stride, int n) {
+    const double z = -0.26794919243112270647;  // sqrt(3) - 2
+    const double gain = 6.0;                   // (1 - z)(1 - 1/z)
+    if (n < 2) return;
+    // causal initialisation: exact sum over the mirrored line
+    const double zn1 = pow(z, (double)(n - 1));
+    const double last = gain * (double)c[(size_t)(n - 1) * stride];
+    double c0 = gain * (double)c[0] + zn1 * last;
+    double zi = z;
+    for (int i = 1; i < n - 1; ++i) {
+        if (zi == 0.0) break;  // every remaining term is exactly zero
+        c0 += zi * (gain * (double)c[(size_t)i * stride] + zn1 * gain * (double)c[(size_t)(n - 1 - i) * stride]);
+        zi *= z;
+    }
+    c0 /= (1.0 - zn1 * zn1);
+    double prev = c0;
+    c[0] = (T)prev;
+    for (int i = 1; i < n; ++i) {
+        prev = gain * (double)c[(size_t)i * stride] + z * prev;
+        c[(size_t)i * stride] = (T)prev;
+    }
+    // anticausal
+    double cn1 = (double)c[(size_t)(n - 1) * stride];
+    double cn2 = (double)c[(size_t)(n - 2) * stride];
+    double next = (z * cn2 + cn1) * z / (z * z - 1.0);
+    c[(size_t)(n - 1) * stride] = (T)next;
+    for (int i = n - 2; i >= 0; --i) {
+        next = z * (next - (double)c[(size_t)i * stride]);
+        c[(size_t)i * stride] = (T)next;
+    }
+}
+
+// axis 0 (latitude): one thread per (level, column, component); consecutive
+// threads touch consecutive elements, so every step of the march is coalesced.
+template <typename T>
+__global__ void prefilter_cols_kernel(T *__restrict__ packed, int nt, int ny, int nx) {
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
+    const size_t lines = (size_t)nt * nx * 2;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= lines) return;
+    const size_t t = i / ((size_t)nx * 2);
+    const size_t xc = i - t * (size_t)nx * 2;  // x*2 + component
+    T *c = packed + t * level + ((size_t)LC_PAD_LO * pitch + LC_PAD_LO) * 2 + xc;
+    prefilter_line<T>(c, (size_t)pitch * 2, ny);
+}
+
+// axis 1 (longitude): one thread per (level, row, component).
+template <typename T>
+__global__ void prefilter_rows_kernel(T *__restrict__ packed, int nt, int ny, int nx) {
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
+    const size_t lines = (size_t)nt * ny * 2;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= lines) return;
+    const size_t t = i / ((size_t)ny * 2);
+    const size_t r = i - t * (size_t)ny * 2;
+    const int y = (int)(r >> 1), comp = (int)(r & 1);
+    T *c = packed + t * level + ((size_t)(y + LC_PAD_LO) * pitch + LC_PAD_LO) * 2 + comp;
+    prefilter_line<T>(c, 2, nx);
+}
+
+template <typename T>
+int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int order, T *packed) {
+    const size_t nodes = (size_t)nt * ny * nx;
+    const int threads = 256;
+    const int blocks = (int)((nodes + threads - 1) / threads < 8192 ? (nodes + threads - 1) / threads : 8192);
+    hipLaunchKernelGGL(pack_interior_kernel<T>, dim3(blocks), dim3(threads), 0, ctx->stream, u, v, packed, ny, nx,
+                       nodes);
+    if (order == 3) {
+        // scipy filters axis 0 first, then axis 1 (spline_filter loops over axes in order)
+        size_t lines = (size_t)nt * nx * 2;
+        hipLaunchKernelGGL(prefilter_cols_kernel<T>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
+                           ctx->stream, packed, nt, ny, nx);
+        lines = (size_t)nt * ny * 2;
+        hipLaunchKernelGGL(prefilter_rows_kernel<T>, dim3((unsigned)((lines + 63) / 64)), dim3(64), 0, ctx->stream,
+                           packed, nt, ny, nx);
+    }
+    hipLaunchKernelGGL(fill_pads_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
+    LC_HIP_CHECK(hipGetLastError());
+    return LC_OK;
+}
+
+}  // namespace
+
+int lc_launch_pack(lc_ctx *ctx, const void *u, const void *v, int dtype, int nt, int ny_f, int nx_f, int order,
+                   void *packed) {
+    if (dtype == LC_F32)
+        return pack_impl<float>(ctx, (const float *)u, (const float *)v, nt, ny_f, nx_f, order, (float *)packed);
+    return pack_impl<double>(ctx, (const double *)u, (const double *)v, nt, ny_f, nx_f, order, (double *)packed);
+}

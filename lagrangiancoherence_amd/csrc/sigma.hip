@@ -1,0 +1,179 @@
+// K3 -- flow-map gradient + largest singular value, fused.
+//
+// Restates, per seed:
+//   LCS.flowmap_gradient            LCS/LCS.py:195-208   lon/lat -> X,Y,Z on the sphere
+//   tools.derivative_spherical_coords  LCS/tools.py:254-264  metric dx, dy
+//   tools.fourth_order_derivative   LCS/tools.py:202-228   5-point stencil, cyclic in
+//                                   longitude, one-sided/2 on the 2 first/last rows (Q12)
+//   eigen step of LCS.__call__      LCS/LCS.py:152-154   ||M||_2 of the 3x3 built by a
+//                                   row-major reshape of the 9 components (Q13)
+// The reference materialises X,Y,Z, six derivative fields, three zero fields and a
+// pandas MultiIndex; here a workgroup computes X,Y,Z once for its tile plus a 2-cell
+// halo into LDS (as float when fd_fp32_cast, Q11), differences from LDS and solves the
+// 2x2 Gram eigenproblem in closed form.  HBM traffic: read x_dep,y_dep once (+halo
+// re-reads served by L2), write sigma once.
+#include "lcs_common.h"
+
+namespace {
+
+constexpr int SW = 64;  // tile width  (longitude)
+constexpr int SH = 16;  // tile height (latitude)
+constexpr int HALO = 2;
+constexpr int LW = SW + 2 * HALO;
+constexpr int LH = SH + 2 * HALO;
+constexpr int SBLOCK = 256;
+
+__device__ __forceinline__ void sincos_t(float a, float *s, float *c) { sincosf(a, s, c); }
+__device__ __forceinline__ void sincos_t(double a, double *s, double *c) { sincos(a, s, c); }
+
+template <typename T>
+struct SigmaArgs {
+    const T *x_dep, *y_dep, *seed_lat;
+    int in_row0, n_in_rows, nx, ny_global;
+    T dlat, dlon;
+    int layout;
+    int out_row0, n_out_rows;
+    T *sigma;
+};
+
+// T: arithmetic type of positions; S: type X,Y,Z are differenced in
+template <typename T, typename S>
+__global__ void __launch_bounds__(SBLOCK) sigma_kernel(const SigmaArgs<T> A) {
+#pragma clang fp contract(off)
+    __shared__ S sX[LH][LW + 1];
+    __shared__ S sY[LH][LW + 1];
+    __shared__ S sZ[LH][LW + 1];
+    const int ntx = (A.nx + SW - 1) / SW;
+    const int tyi = blockIdx.x / ntx, txi = blockIdx.x - tyi * ntx;
+    const int gy0 = A.out_row0 + tyi * SH;  // global row of the tile's first output row
+    const int gx0 = txi * SW;
+    const T PI = T(3.141592653589793);
+    const T R = T(6371000);
+
+    // stage X,Y,Z for the tile + halo
+    for (int i = threadIdx.x; i < LW * LH; i += SBLOCK) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = gy0 - HALO + ly;            // global row
+        int gx = gx0 - HALO + lx;                  // cyclic column (tools.py:225-228)
+        gx %= A.nx;
+        if (gx < 0) gx += A.nx;
+        const int ry = gy - A.in_row0;             // row inside the input window
+        S vx = S(0), vy = S(0), vz = S(0);
+        if (gy >= 0 && gy < A.ny_global && ry >= 0 && ry < A.n_in_rows) {
+            const size_t o = (size_t)ry * A.nx + gx;
+            const T lon = (A.x_dep[o] * PI) / T(180);            // LCS.py:195
+            const T lat = ((A.y_dep[o] - T(90)) * PI) / T(180);  // LCS.py:196 (colatitude - pi)
+            T sl, cl, so, co;
+            sincos_t(lat, &sl, &cl);
+            sincos_t(lon, &so, &co);
+            vx = (S)((R * sl) * co);  // LCS.py:197
+            vy = (S)((R * sl) * so);  // LCS.py:198
+            vz = (S)(R * cl);         // LCS.py:199
+        }
+        sX[ly][lx] = vx;
+        sY[ly][lx] = vy;
+        sZ[ly][lx] = vz;
+    }
+    __syncthreads();
+
+    const T dy = ((PI / T(180)) * A.dlat) * R;  // tools.py:256
+    for (int i = threadIdx.x; i < SW * SH; i += SBLOCK) {
+        const int oy = i / SW, ox = i - oy * SW;
+        const int gy = gy0 + oy, gx = gx0 + ox;
+        if (gy >= A.out_row0 + A.n_out_rows || gx >= A.nx) continue;
+        const int ly = oy + HALO, lx = ox + HALO;
+        // numba typing of tools.py:204-207: S differences, double scaling, S store
+        auto centred = [](S p1, S m1, S p2, S m2) -> S {
+            const S d1 = p1 - m1, d2 = p2 - m2;
+            return (S)((4.0 / 3.0) * (double)d1 / 2.0 - (1.0 / 3.0) * (double)d2 / 4.0);
+        };
+        auto ddx = [&](S(*a)[LW + 1]) -> S {
+            return centred(a[ly][lx + 1], a[ly][lx - 1], a[ly][lx + 2], a[ly][lx - 2]);
+        };
+        auto ddy = [&](S(*a)[LW + 1]) -> S {
+            if (gy < 2) return (S)((double)(a[ly + 1][lx] - a[ly][lx]) / 2.0);                  // tools.py:210-213
+            if (gy >= A.ny_global - 2) return (S)((double)(a[ly][lx] - a[ly - 1][lx]) / 2.0);  // tools.py:214-217
+            return centred(a[ly + 1][lx], a[ly - 1][lx], a[ly + 2][lx], a[ly - 2][lx]);
+        };
+        const T latr = (A.seed_lat[gy - A.in_row0] * PI) / T(180);  // tools.py:254
+        const T dx = (((PI / T(180)) * A.dlon) * R) * cos(latr);   // tools.py:255
+        // derivative / metric: the division is done in T (float64 / float32 as numpy would)
+        const double a_ = (double)((T)ddx(sX) / dx);  // dXdx
+        const double b_ = (double)((T)ddy(sX) / dy);  // dXdy
+        const double c_ = (double)((T)ddx(sY) / dx);  // dYdx
+        const double d_ = (double)((T)ddy(sY) / dy);  // dYdy
+        const double e_ = (double)((T)ddx(sZ) / dx);  // dZdx
+        const double f_ = (double)((T)ddy(sZ) / dy);  // dZdy
+        double p, q, r;
+        if (A.layout == LC_LAYOUT_REFERENCE) {
+            // M = [[a,b,c],[d,e,f],[0,0,0]] (LCS.py:153): Gram matrix of its two non-zero rows
+            p = a_ * a_ + b_ * b_ + c_ * c_;
+            q = d_ * d_ + e_ * e_ + f_ * f_;
+            r = a_ * d_ + b_ * e_ + c_ * f_;
+        } else {
+            // Jacobian [[a,b],[c,d],[e,f]]: F^T F
+            p = a_ * a_ + c_ * c_ + e_ * e_;
+            q = b_ * b_ + d_ * d_ + f_ * f_;
+            r = a_ * b_ + c_ * d_ + e_ * f_;
+        }
+        const double dpq = p - q;
+        const double disc = sqrt(dpq * dpq + 4.0 * r * r);
+        const double lam = 0.5 * ((p + q) + disc);
+        A.sigma[(size_t)(gy - A.out_row0) * A.nx + gx] = (T)sqrt(lam);  // NaN in -> NaN out (Q14)
+    }
+}
+
+template <typename T>
+int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, int n_in_rows, int nx, int ny_global,
+               const void *seed_lat, double dlat, double dlon, int fd_fp32_cast, int layout, int out_row0,
+               int n_out_rows, void *sigma_out) {
+    SigmaArgs<T> A;
+    A.x_dep = (const T *)x_dep;
+    A.y_dep = (const T *)y_dep;
+    A.seed_lat = (const T *)seed_lat;
+    A.in_row0 = in_row0;
+    A.n_in_rows = n_in_rows;
+    A.nx = nx;
+    A.ny_global = ny_global;
+    A.dlat = (T)dlat;
+    A.dlon = (T)dlon;
+    A.layout = layout;
+    A.out_row0 = out_row0;
+    A.n_out_rows = n_out_rows;
+    A.sigma = (T *)sigma_out;
+    const int ntx = (nx + SW - 1) / SW, nty = (n_out_rows + SH - 1) / SH;
+    if (fd_fp32_cast || sizeof(T) == 4)
+        hipLaunchKernelGGL((sigma_kernel<T, float>), dim3(ntx * nty), dim3(SBLOCK), 0, ctx->stream, A);
+    else
+        hipLaunchKernelGGL((sigma_kernel<T, double>), dim3(ntx * nty), dim3(SBLOCK), 0, ctx->stream, A);
+    LC_HIP_CHECK(hipGetLastError());
+    return LC_OK;
+}
+
+}  // namespace
+
+extern "C" int lc_sigma(lc_ctx *ctx, const void *x_dep, const void *y_dep, int dtype, int in_row0, int n_in_rows,
+                        int nx, int ny_global, const void *seed_lat_dev, double dlat, double dlon, int fd_fp32_cast,
+                        int tensor_layout, int out_row0, int n_out_rows, void *sigma_out) {
+    LC_REQUIRE(ctx, "lc_sigma: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_sigma: bad dtype %d", dtype);
+    LC_REQUIRE(x_dep && y_dep && seed_lat_dev && sigma_out, "lc_sigma: null pointer");
+    LC_REQUIRE(nx >= 5 && ny_global >= 5, "lc_sigma: grid %dx%d too small for the 5-point stencil", ny_global, nx);
+    LC_REQUIRE(tensor_layout == LC_LAYOUT_REFERENCE || tensor_layout == LC_LAYOUT_PHYSICAL, "lc_sigma: bad layout");
+    LC_REQUIRE(n_in_rows >= 1 && in_row0 >= 0 && in_row0 + n_in_rows <= ny_global, "lc_sigma: bad input window");
+    LC_REQUIRE(n_out_rows >= 1 && out_row0 >= in_row0 && out_row0 + n_out_rows <= in_row0 + n_in_rows,
+               "lc_sigma: output rows outside the input window");
+    // every output row needs r-2..r+2 unless the global one-sided rule covers it
+    const int need_lo = out_row0 < 2 ? 0 : out_row0 - 2;
+    const int last = out_row0 + n_out_rows - 1;
+    const int need_hi = last >= ny_global - 2 ? ny_global - 1 : last + 2;
+    LC_REQUIRE(in_row0 <= need_lo && in_row0 + n_in_rows - 1 >= need_hi,
+               "lc_sigma: rows [%d,%d] need halo rows [%d,%d] but the input holds [%d,%d]", out_row0, last, need_lo,
+               need_hi, in_row0, in_row0 + n_in_rows - 1);
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (dtype == LC_F32)
+        return sigma_impl<float>(ctx, x_dep, y_dep, in_row0, n_in_rows, nx, ny_global, seed_lat_dev, dlat, dlon,
+                                 fd_fp32_cast, tensor_layout, out_row0, n_out_rows, sigma_out);
+    return sigma_impl<double>(ctx, x_dep, y_dep, in_row0, n_in_rows, nx, ny_global, seed_lat_dev, dlat, dlon,
+                              fd_fp32_cast, tensor_layout, out_row0, n_out_rows, sigma_out);
+}

@@ -1,0 +1,267 @@
+"""Array-level host API over the C ABI (include/lcs_hip.h).
+
+`Engine` keeps wind fields, seeds and results resident in HBM as torch tensors
+(torch is plumbing here: device memory, streams, torch.distributed) and calls
+the HIP kernels through ctypes on torch's current stream.  `lcs_host` is the
+torch-free route: host numpy arrays through the one-call entry point
+`lc_lcs_host`.
+
+Everything is arrays `(time, latitude, longitude)`, coordinates ascending; the
+xarray-facing drop-in surface (`LagrangianCoherence.LCS.*`) sits on top of this
+module in `dropin.py`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+
+__all__ = ["Engine", "PackedField", "lcs_host", "common_dtype"]
+
+_NP2LC = {np.dtype(np.float32): _capi.LC_F32, np.dtype(np.float64): _capi.LC_F64}
+_LAYOUTS = {"reference": _capi.LC_LAYOUT_REFERENCE, "physical": _capi.LC_LAYOUT_PHYSICAL}
+
+
+def common_dtype(*arrays) -> np.dtype:
+    """float32 only if every input is float32, else float64.
+
+    The reference lets numpy promote (fp32 wind on fp64 coordinates gives fp64
+    positions and fp32 velocities); the kernels have one arithmetic
+    type per call, so a mixed call is computed in float64.
+    """
+    dts = {np.dtype(getattr(a, "dtype", np.float64)) for a in arrays if a is not None}
+    return np.dtype(np.float32) if dts == {np.dtype(np.float32)} else np.dtype(np.float64)
+
+
+@dataclass
+class PackedField:
+    """Gather-ready image(s) of a wind time series, resident on the device."""
+    lin: "torch.Tensor"            # order-1 image, always present
+    cub: "torch.Tensor | None"     # order-3 coefficient image
+    nt: int
+    ny_f: int
+    nx_f: int
+    lat_min: float
+    lat_max: float
+    lon_min: float
+    lon_max: float
+    dtype: np.dtype
+
+
+class Engine:
+    """One context on one MI355X.  Not a CPU fallback: needs the HIP library and a GPU."""
+
+    def __init__(self, device: int | None = None):
+        import torch
+        self.torch = torch
+        self.lib = _capi.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("lagrangiancoherence_amd.Engine needs a GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU path")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        ctx = C.c_void_p()
+        _capi.check(self.lib.lc_ctx_create(self.device_index, C.byref(ctx)), self.lib)
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.lc_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _use_current_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        _capi.check(self.lib.lc_ctx_set_stream(self.ctx, C.c_void_p(s)), self.lib)
+
+    def to_device(self, a, dtype: np.dtype):
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=getattr(torch, np.dtype(dtype).name))
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.device)
+        return t.contiguous()
+
+    def _empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=getattr(self.torch, np.dtype(dtype).name), device=self.device)
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    # ------------------------------------------------------------------ field
+    def prepare_field(self, u, v, lat_f, lon_f, interp_order: int = 1, dtype=None) -> PackedField:
+        """Upload (if needed) and pack a wind series.  u, v: (nt, ny_f, nx_f)."""
+        if interp_order not in (1, 3):
+            raise ValueError(f"interp_order {interp_order} unsupported (1 and 3 are implemented; "
+                             "0 fails in the reference too, LCS/tools.py:24-30)")
+        lat_f = np.asarray(lat_f)
+        lon_f = np.asarray(lon_f)
+        dtype = np.dtype(dtype or common_dtype(u, v, lat_f, lon_f))
+        if tuple(u.shape) != tuple(v.shape) or len(u.shape) != 3:
+            raise ValueError("u and v must both be (time, latitude, longitude)")
+        nt, ny_f, nx_f = (int(s) for s in u.shape)
+        if lat_f.shape != (ny_f,) or lon_f.shape != (nx_f,):
+            raise ValueError("coordinate lengths do not match the field")
+        if not (np.all(np.diff(lat_f) > 0) and np.all(np.diff(lon_f) > 0)):
+            raise ValueError("latitude and longitude must be ascending (sort first)")
+        ud = self.to_device(u, dtype)
+        vd = self.to_device(v, dtype)
+        n = self.lib.lc_packed_elems(nt, ny_f, nx_f)
+        self._use_current_stream()
+        lin = self._empty((n,), dtype)
+        _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f, 1,
+                                           self._ptr(lin)), self.lib)
+        cub = None
+        if interp_order == 3:
+            cub = self._empty((n,), dtype)
+            _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f,
+                                               3, self._ptr(cub)), self.lib)
+        # coordinate extremes in the arithmetic dtype (what .min()/.max() give numpy)
+        la = lat_f.astype(dtype)
+        lo = lon_f.astype(dtype)
+        return PackedField(lin, cub, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype)
+
+    # ------------------------------------------------------------------ K1
+    def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
+               cyclic_xboundary=True, t0=0, nsteps=None, return_traj=False, row0=0, ny_global=None):
+        """Departure points of the seed rows given.  Returns (x, y[, traj_x, traj_y]) device tensors."""
+        if interp_order == 3 and field.cub is None:
+            raise ValueError("field was prepared for interp_order=1")
+        dtype = field.dtype
+        slat = self.to_device(seed_lat, dtype)
+        slon = self.to_device(seed_lon, dtype)
+        ny, nx = int(slat.numel()), int(slon.numel())
+        ny_global = ny if ny_global is None else int(ny_global)
+        nsteps = field.nt - 1 - t0 if nsteps is None else int(nsteps)
+        x = self._empty((ny, nx), dtype)
+        y = self._empty((ny, nx), dtype)
+        tx = ty = None
+        if return_traj:
+            tx = self._empty((nsteps + 1, ny, nx), dtype)
+            ty = self._empty((nsteps + 1, ny, nx), dtype)
+        self._use_current_stream()
+        _capi.check(self.lib.lc_advect(
+            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order == 3 else None), _NP2LC[dtype],
+            field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max,
+            self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, float(timestep), int(SETTLS_order),
+            int(interp_order), int(bool(cyclic_xboundary)), int(t0), nsteps, self._ptr(x), self._ptr(y),
+            self._ptr(tx), self._ptr(ty)), self.lib)
+        return (x, y, tx, ty) if return_traj else (x, y)
+
+    # ------------------------------------------------------------------ K3
+    def sigma(self, x_dep, y_dep, seed_lat_rows, dlat, dlon, ny_global=None, in_row0=0, out_row0=None,
+              n_out_rows=None, fd_fp32_cast=True, tensor_layout="reference"):
+        """sigma_max for rows [out_row0, out_row0+n_out_rows) of a global grid, from the
+        departure rows [in_row0, in_row0+x_dep.shape[0]) (which must include the 2-row halo)."""
+        torch = self.torch
+        dtype = np.dtype(str(x_dep.dtype).replace("torch.", "")) if isinstance(x_dep, torch.Tensor) \
+            else common_dtype(x_dep, y_dep)
+        xd = self.to_device(x_dep, dtype)
+        yd = self.to_device(y_dep, dtype)
+        n_in, nx = (int(s) for s in xd.shape)
+        slat = self.to_device(seed_lat_rows, dtype)
+        if slat.numel() != n_in:
+            raise ValueError("seed_lat_rows must have one latitude per input row")
+        ny_global = n_in if ny_global is None else int(ny_global)
+        out_row0 = in_row0 if out_row0 is None else int(out_row0)
+        n_out_rows = n_in if n_out_rows is None else int(n_out_rows)
+        sig = self._empty((n_out_rows, nx), dtype)
+        self._use_current_stream()
+        _capi.check(self.lib.lc_sigma(self.ctx, self._ptr(xd), self._ptr(yd), _NP2LC[dtype], int(in_row0), n_in, nx,
+                                      ny_global, self._ptr(slat), float(dlat), float(dlon), int(bool(fd_fp32_cast)),
+                                      _LAYOUTS[tensor_layout], out_row0, n_out_rows, self._ptr(sig)), self.lib)
+        return sig
+
+    def gaussian_filter(self, a, sigma):
+        """scipy.ndimage.gaussian_filter(a, sigma) on the device (LCS/LCS.py:187-190)."""
+        torch = self.torch
+        dtype = np.dtype(str(a.dtype).replace("torch.", "")) if isinstance(a, torch.Tensor) else common_dtype(a)
+        ad = self.to_device(a, dtype)
+        ny, nx = (int(s) for s in ad.shape)
+        tmp = self._empty((ny, nx), dtype)
+        out = self._empty((ny, nx), dtype)
+        self._use_current_stream()
+        _capi.check(self.lib.lc_gaussian_filter(self.ctx, self._ptr(ad), _NP2LC[dtype], ny, nx, float(sigma),
+                                                self._ptr(tmp), self._ptr(out)), self.lib)
+        return out
+
+    # ------------------------------------------------------------------ whole path
+    def lcs(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
+            cyclic_xboundary=True, t0=0, nsteps=None, gauss_sigma=None, fd_fp32_cast=True,
+            tensor_layout="reference", return_traj=False):
+        """advect -> (smooth) -> sigma on one GPU.  Returns dict of device tensors."""
+        dtype = field.dtype
+        seed_lat = np.asarray(seed_lat, dtype=dtype)
+        seed_lon = np.asarray(seed_lon, dtype=dtype)
+        res = self.advect(field, seed_lat, seed_lon, timestep, SETTLS_order, interp_order, cyclic_xboundary, t0,
+                          nsteps, return_traj)
+        x, y = res[0], res[1]
+        xs, ys = x, y
+        if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool):
+            xs = self.gaussian_filter(x, gauss_sigma)
+            ys = self.gaussian_filter(y, gauss_sigma)
+        # spacing evaluated in the coordinate dtype, as lat[1]-lat[0] is in numpy (tools.py:255-256)
+        dlat = float(seed_lat[1] - seed_lat[0])
+        dlon = float(seed_lon[1] - seed_lon[0])
+        sig = self.sigma(xs, ys, seed_lat, dlat, dlon, fd_fp32_cast=fd_fp32_cast, tensor_layout=tensor_layout)
+        out = {"sigma": sig, "x_dep": x, "y_dep": y}
+        if return_traj:
+            out["traj_x"], out["traj_y"] = res[2], res[3]
+        return out
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+# ---------------------------------------------------------------------------
+# torch-free route: host arrays through lc_lcs_host
+# ---------------------------------------------------------------------------
+def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cyclic_xboundary=False,
+             seed_lat=None, seed_lon=None, t0=0, nsteps=None, gauss_sigma=None, fd_fp32_cast=True,
+             tensor_layout="reference", return_traj=False, want_sigma=True, device=0):
+    """numpy in, numpy out, via the one-call C entry point.  Returns a dict."""
+    lib = _capi.load()
+    dtype = common_dtype(u, v, lat_f, lon_f, seed_lat, seed_lon)
+    u = np.ascontiguousarray(u, dtype=dtype)
+    v = np.ascontiguousarray(v, dtype=dtype)
+    if u.shape != v.shape or u.ndim != 3:
+        raise ValueError("u and v must both be (time, latitude, longitude)")
+    lat_f = np.ascontiguousarray(lat_f, dtype=dtype)
+    lon_f = np.ascontiguousarray(lon_f, dtype=dtype)
+    seed_lat = lat_f if seed_lat is None else np.ascontiguousarray(seed_lat, dtype=dtype)
+    seed_lon = lon_f if seed_lon is None else np.ascontiguousarray(seed_lon, dtype=dtype)
+    nt, ny_f, nx_f = u.shape
+    ny, nx = seed_lat.size, seed_lon.size
+    nsteps = nt - 1 - t0 if nsteps is None else int(nsteps)
+    out = {"x_dep": np.empty((ny, nx), dtype), "y_dep": np.empty((ny, nx), dtype)}
+    if want_sigma:
+        out["sigma"] = np.empty((ny, nx), dtype)
+    if return_traj:
+        out["traj_x"] = np.empty((nsteps + 1, ny, nx), dtype)
+        out["traj_y"] = np.empty((nsteps + 1, ny, nx), dtype)
+
+    def p(a):
+        return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+
+    ctx = C.c_void_p()
+    _capi.check(lib.lc_ctx_create(int(device), C.byref(ctx)), lib)
+    try:
+        gs = float(gauss_sigma) if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool) else 0.0
+        _capi.check(lib.lc_lcs_host(
+            ctx, p(u), p(v), _NP2LC[dtype], nt, ny_f, nx_f, p(lat_f), p(lon_f), p(seed_lat), ny, p(seed_lon), nx,
+            float(timestep), int(SETTLS_order), int(interp_order), int(bool(cyclic_xboundary)), int(t0), nsteps, gs,
+            int(bool(fd_fp32_cast)), _LAYOUTS[tensor_layout], p(out.get("sigma")), p(out["x_dep"]), p(out["y_dep"]),
+            p(out.get("traj_x")), p(out.get("traj_y"))), lib)
+    finally:
+        lib.lc_ctx_destroy(ctx)
+    return out

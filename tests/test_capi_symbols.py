@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads here (hipcc
+cross-compiles gfx950 without a GPU), exports every symbol include/lcs_hip.h
+declares, and the ctypes prototypes cover exactly that set.  No compute calls."""
+import os
+import re
+
+import pytest
+
+from lagrangiancoherence_amd import _capi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lcs_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lc_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_library(verbose=False)
+    return _capi.load()
+
+
+def test_header_and_prototypes_agree():
+    assert declared_symbols() == sorted(_capi.PROTOTYPES)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_version_and_error_string(lib):
+    assert lib.lc_version() == 100
+    assert isinstance(lib.lc_last_error(), bytes)
+
+
+def test_packed_elems_is_pure_arithmetic(lib):
+    assert lib.lc_packed_elems(97, 720, 1440) == 97 * 723 * 1443 * 2
+    assert lib.lc_packed_elems(0, 4, 4) == 0
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    # null context is rejected before any HIP call
+    assert lib.lc_sync(None) == _capi.LC_EINVAL
+    assert b"null context" in lib.lc_last_error()
+    with pytest.raises(ValueError):
+        _capi.check(lib.lc_advect(None, None, None, 0, 2, 4, 4, 0., 1., 0., 1., None, 1, None, 1, 0, 1,
+                                  1.0, 0, 1, 1, 0, 1, None, None, None, None), lib)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _capi.load(str(tmp_path / "liblcs_hip.so"))
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lagrangiancoherence_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Engine(0)

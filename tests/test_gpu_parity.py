@@ -1,0 +1,321 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs, and against the committed golden fixtures.
+
+Tolerances (stated here once):
+  float64  positions |dx|,|dy| <= 1e-9 degrees, sigma relative 1e-7 (the float32 cast
+           of X,Y,Z before differencing (Q11) amplifies 1e-13-degree position
+           differences: ulp(6.4e6f)=0.5 m over dx ~ 1e5 m), sigma w/o the cast 1e-9.
+  float32  judged against the float64 oracle on the same (float32-valued) inputs:
+           the GPU's error must be of the size of the float32 *oracle's* own error.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from lagrangiancoherence_amd import flows
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+POS_ATOL64 = 1e-9
+SIG_RTOL64 = 1e-7
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from lagrangiancoherence_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import lcs_oracle
+    return lcs_oracle
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _rand_field(seed, nt=4, ny=23, nx=31, dtype=np.float64, scale=20.0):
+    rng = np.random.default_rng(seed)
+    lat = np.linspace(-80, 80, ny).astype(dtype)
+    lon = (-180 + 360.0 / nx * np.arange(nx)).astype(dtype)
+    # smooth-ish random wind so trajectories stay sane
+    u = (scale * rng.standard_normal((nt, ny, nx))).astype(dtype)
+    v = (0.5 * scale * rng.standard_normal((nt, ny, nx))).astype(dtype)
+    return u, v, lat, lon
+
+
+# ------------------------------------------------------------------ field image
+def test_pack_order1_image(eng):
+    u, v, lat, lon = _rand_field(1)
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    nt, ny, nx = u.shape
+    img = _np(f.lin).reshape(nt, ny + 3, nx + 3, 2)
+    assert np.array_equal(img[:, 1:ny + 1, 1:nx + 1, 0], u)
+    assert np.array_equal(img[:, 1:ny + 1, 1:nx + 1, 1], v)
+
+    def mir(i, n):
+        i = abs(i)
+        return 2 * (n - 1) - i if i > n - 1 else i
+    for py in (0, ny + 1, ny + 2):
+        for px in (0, 5, nx + 1, nx + 2):
+            assert img[2, py, px, 0] == u[2, mir(py - 1, ny), mir(px - 1, nx)]
+    assert img[1, 4, 0, 1] == v[1, 3, 1] and img[1, 4, nx + 2, 1] == v[1, 3, nx - 3]
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 2e-13), (np.float32, 2e-5)])
+def test_prefilter_matches_scipy(eng, O, dtype, tol):
+    u, v, lat, lon = _rand_field(2, nt=2, ny=19, nx=37, dtype=dtype, scale=1.0)
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    nt, ny, nx = u.shape
+    img = _np(f.cub).reshape(nt, ny + 3, nx + 3, 2).astype(np.float64)
+    for t in range(nt):
+        np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 0], O.spline_prefilter_mirror(u[t]), atol=tol)
+        np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 1], O.spline_prefilter_mirror(v[t]), atol=tol)
+    # pads mirror the coefficients
+    assert np.array_equal(img[0, 0, 1:nx + 1, 0], img[0, 2, 1:nx + 1, 0])
+    assert np.array_equal(img[0, ny + 2, 1:nx + 1, 1], img[0, ny - 2, 1:nx + 1, 1])
+
+
+# ------------------------------------------------------------------ advection
+@pytest.mark.parametrize("order", [1, 3])
+@pytest.mark.parametrize("K", [0, 1, 4])
+@pytest.mark.parametrize("dt", [-3600.0, 5400.0])
+def test_advect_f64_random_field(eng, O, order, K, dt):
+    u, v, lat, lon = _rand_field(3 + K, nt=5)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    x, y = eng.advect(f, lat, lon, dt, SETTLS_order=K, interp_order=order, cyclic_xboundary=True)
+    xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=dt, SETTLS_order=K, interp_order=order,
+                                    cyclic_xboundary=True)
+    np.testing.assert_allclose(_np(y), yr_, rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(x), xr_, rtol=0, atol=POS_ATOL64)
+
+
+def test_advect_noncyclic_clamp(eng, O):
+    u, v, lat, lon = _rand_field(11, nt=4, scale=60.0)
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    x, y = eng.advect(f, lat, lon, 7200.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=False)
+    xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=7200.0, SETTLS_order=2, interp_order=1,
+                                    cyclic_xboundary=False, noncyclic_clamp="pointwise")
+    np.testing.assert_allclose(_np(x), xr_, rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(y), yr_, rtol=0, atol=POS_ATOL64)
+    assert _np(x).min() >= lon.min() and _np(x).max() <= lon.max()
+
+
+def test_kat_zero_wind_and_uniform_wind(eng):
+    # KAT-1 / KAT-2 straight on the GPU
+    lat = np.linspace(-80, 80, 21)
+    lon = -180 + 10.0 * np.arange(36)
+    U0 = np.zeros((4, 21, 36))
+    f = eng.prepare_field(U0, U0, lat, lon, 1)
+    x, y = eng.advect(f, lat, lon, -3600.0, SETTLS_order=2, interp_order=1)
+    X, Y = np.meshgrid(lon, lat)
+    exp = X.copy()
+    exp[X == -180] = 0.0                       # Q7
+    assert np.array_equal(_np(x), exp) and np.array_equal(_np(y), Y)
+    u0, dt, K = 7.0, 600.0, 4
+    f = eng.prepare_field(np.full_like(U0, u0), U0, lat, lon, 1)
+    x, y = eng.advect(f, lat, lon, dt, SETTLS_order=K, interp_order=1)
+    dlon = (1 + K) * dt * u0 * 180 / (np.pi * 6371000 * np.abs(np.cos(np.deg2rad(lat))))   # Q4
+    moved = _np(x) - X
+    np.testing.assert_allclose(moved[1:-1, 1:], np.broadcast_to((3 * dlon)[1:-1, None], (19, 35)), rtol=1e-12)
+    assert np.array_equal(moved[-1, 1:], np.zeros(35))      # Q2+Q3: last row sees cval=0
+    assert np.array_equal(_np(y), Y)
+
+
+def test_seed_grid_and_t0_window(eng, O):
+    u, v, lat, lon = _rand_field(21, nt=7, ny=25, nx=40)
+    slat = np.linspace(lat[0], lat[-1], 37)
+    slon = np.linspace(lon[0], lon[-1], 53)
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    for order in (1, 3):
+        x, y = eng.advect(f, slat, slon, -1800.0, SETTLS_order=2, interp_order=order, t0=2, nsteps=3)
+        xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=-1800.0, SETTLS_order=2, interp_order=order,
+                                        cyclic_xboundary=True, seed_lat=slat, seed_lon=slon, t0=2, nsteps=3)
+        np.testing.assert_allclose(_np(x), xr_, rtol=0, atol=POS_ATOL64)
+        np.testing.assert_allclose(_np(y), yr_, rtol=0, atol=POS_ATOL64)
+
+
+def test_return_traj(eng, O):
+    u, v, lat, lon = _rand_field(31, nt=5)
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    x, y, tx, ty = eng.advect(f, lat, lon, 3600.0, SETTLS_order=1, interp_order=1, return_traj=True)
+    txr, tyr = O.parcel_propagation(u, v, lat, lon, timestep=3600.0, SETTLS_order=1, interp_order=1,
+                                    cyclic_xboundary=True, return_traj=True)
+    assert tuple(tx.shape) == txr.shape
+    np.testing.assert_allclose(_np(tx), txr, rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(ty), tyr, rtol=0, atol=POS_ATOL64)
+    assert np.array_equal(_np(tx[-1]), _np(x)) and np.array_equal(_np(ty[0]), np.meshgrid(lon, lat)[1])
+
+
+def test_row_sharded_advect_is_bit_identical(eng):
+    # rows advected as three blocks (with global row offsets) == rows advected at once
+    u, v, lat, lon = _rand_field(41, nt=4, ny=29, nx=33)
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    x, y = eng.advect(f, lat, lon, -3600.0, SETTLS_order=2, interp_order=3)
+    for lo, hi in ((0, 9), (9, 20), (20, 29)):
+        xb, yb = eng.advect(f, lat[lo:hi], lon, -3600.0, SETTLS_order=2, interp_order=3, row0=lo, ny_global=29)
+        assert np.array_equal(_np(xb), _np(x)[lo:hi]) and np.array_equal(_np(yb), _np(y)[lo:hi])
+
+
+# ------------------------------------------------------------------ sigma
+@pytest.mark.parametrize("layout", ["reference", "physical"])
+def test_sigma_f64_vs_oracle(eng, O, layout):
+    rng = np.random.default_rng(5)
+    lat = np.linspace(-70, 70, 45)
+    lon = -180 + 4.0 * np.arange(90)
+    X, Y = np.meshgrid(lon, lat)
+    xd = X + rng.uniform(-3, 3, X.shape)
+    yd = np.clip(Y + rng.uniform(-3, 3, X.shape), -70, 70)
+    dt_ = O.flowmap_gradient(xd, yd, lat, lon)
+    ref = O.sigma_max(dt_, layout)
+    sig = _np(eng.sigma(xd, yd, lat, lat[1] - lat[0], lon[1] - lon[0], tensor_layout=layout))
+    np.testing.assert_allclose(sig, ref, rtol=SIG_RTOL64)
+    # without the Q11 cast the stencil is clean float64
+    ref2 = O.sigma_max(O.flowmap_gradient(xd, yd, lat, lon, fd_fp32_cast=False), layout)
+    sig2 = _np(eng.sigma(xd, yd, lat, lat[1] - lat[0], lon[1] - lon[0], tensor_layout=layout, fd_fp32_cast=False))
+    np.testing.assert_allclose(sig2, ref2, rtol=1e-9)
+
+
+def test_sigma_nan_in_nan_out(eng):
+    lat = np.linspace(-40, 40, 21)
+    lon = -180 + 10.0 * np.arange(36)
+    X, Y = np.meshgrid(lon, lat)
+    xd = X.copy()
+    xd[10, 7] = np.nan
+    sig = _np(eng.sigma(xd, Y, lat, lat[1] - lat[0], lon[1] - lon[0]))
+    bad = np.argwhere(np.isnan(sig))
+    # the NaN poisons exactly the stencil footprint: +-2 along each axis through (10,7)
+    exp = {(10 + d, 7) for d in (-2, -1, 1, 2)} | {(10, 7 + d) for d in (-2, -1, 1, 2)}
+    assert {tuple(b) for b in bad} == exp
+
+
+def test_sigma_row_window_with_halo(eng):
+    rng = np.random.default_rng(6)
+    lat = np.linspace(-60, 60, 41)
+    lon = -180 + 5.0 * np.arange(72)
+    X, Y = np.meshgrid(lon, lat)
+    xd = X + rng.uniform(-2, 2, X.shape)
+    yd = Y + rng.uniform(-2, 2, X.shape)
+    dlat, dlon = lat[1] - lat[0], lon[1] - lon[0]
+    full = _np(eng.sigma(xd, yd, lat, dlat, dlon))
+    # block rows [15,30) computed from rows [13,32)
+    blk = _np(eng.sigma(xd[13:32], yd[13:32], lat[13:32], dlat, dlon, ny_global=41, in_row0=13, out_row0=15,
+                        n_out_rows=15))
+    assert np.array_equal(blk, full[15:30])
+    # first block [0,15) needs rows [0,17); last block [30,41) needs [28,41)
+    b0 = _np(eng.sigma(xd[:17], yd[:17], lat[:17], dlat, dlon, ny_global=41, in_row0=0, out_row0=0, n_out_rows=15))
+    b2 = _np(eng.sigma(xd[28:], yd[28:], lat[28:], dlat, dlon, ny_global=41, in_row0=28, out_row0=30, n_out_rows=11))
+    assert np.array_equal(b0, full[:15]) and np.array_equal(b2, full[30:])
+    with pytest.raises(ValueError):   # missing halo is an error, not a silent wrong answer
+        eng.sigma(xd[15:30], yd[15:30], lat[15:30], dlat, dlon, ny_global=41, in_row0=15, out_row0=15, n_out_rows=15)
+
+
+def test_gaussian_filter_vs_scipy(eng):
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((37, 53))
+    for s in (0.8, 2.0):
+        np.testing.assert_allclose(_np(eng.gaussian_filter(a, s)), gaussian_filter(a, sigma=s), rtol=0, atol=1e-14)
+    a32 = a.astype(np.float32)
+    np.testing.assert_allclose(_np(eng.gaussian_filter(a32, 1.5)), gaussian_filter(a32, sigma=1.5), rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------ golden fixtures (whole path)
+def _load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+@pytest.mark.parametrize("tag,dt,K", [("bwd_k4", -21600, 4), ("fwd_k2", 21600, 2), ("fwd_k4", 21600, 4)])
+@pytest.mark.parametrize("order", [3, 1])
+def test_golden_config1(eng, tag, dt, K, order):
+    g = _load(f"g1_{tag}_o{order}")
+    u, v, lat, lon = flows.config1()
+    f = eng.prepare_field(u, v, lat, lon, order)
+    r = eng.lcs(f, lat, lon, dt, SETTLS_order=K, interp_order=order, cyclic_xboundary=True)
+    np.testing.assert_allclose(_np(r["x_dep"]), g["x_dep"], rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(r["y_dep"]), g["y_dep"], rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(r["sigma"]), g["sigma"], rtol=SIG_RTOL64)
+
+
+def test_golden_config1_trajectories(eng):
+    g = _load("g1_traj_bwd_k4_o3")
+    u, v, lat, lon = flows.config1()
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    x, y, tx, ty = eng.advect(f, lat, lon, -21600, SETTLS_order=4, interp_order=3, return_traj=True)
+    np.testing.assert_allclose(_np(tx), g["traj_x"], rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(ty), g["traj_y"], rtol=0, atol=POS_ATOL64)
+
+
+def test_golden_config2_downsampled(eng):
+    g = _load("g2_c2_128_k4_o1")
+    u, v, lat, lon = flows.config2(n=128, nt=21)
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    r = eng.lcs(f, lat, lon, -900, SETTLS_order=4, interp_order=1, cyclic_xboundary=True)
+    np.testing.assert_allclose(_np(r["x_dep"]), g["x_dep"], rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(r["y_dep"]), g["y_dep"], rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(r["sigma"]), g["sigma"], rtol=SIG_RTOL64)
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_golden_config3_mini_f32(eng, order):
+    """float32 path: error vs the float64 answer must be of the size of the float32 oracle's own error."""
+    g = _load(f"g3_c3mini_k4_o{order}")
+    u, v, lat, lon = flows.era5_like(nt=13, ny=72, nx=144)
+    slat, slon = flows.seed_grid(96, 160, lat, lon)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    assert f.dtype == np.float32
+    r = eng.lcs(f, slat, slon, -900, SETTLS_order=4, interp_order=order, cyclic_xboundary=True)
+    x, y, s = (_np(r[k]).astype(np.float64) for k in ("x_dep", "y_dep", "sigma"))
+    ex_o = np.abs(g["x_dep"] - g["x_dep64"])
+    ey_o = np.abs(g["y_dep"] - g["y_dep64"])
+    ex_g = np.abs(x - g["x_dep64"])
+    ey_g = np.abs(y - g["y_dep64"])
+    print(f"order {order}: oracle32 err x {ex_o.max():.3e} y {ey_o.max():.3e}; gpu32 err x {ex_g.max():.3e} y {ey_g.max():.3e}")
+    # the east-most seed column sits on the +-180 seam where 1 ulp flips the cyclic rewrite: compare mod 360 there
+    ex_g = np.minimum(ex_g, np.abs(ex_g - 360))
+    assert ex_g.max() <= max(4 * ex_o.max(), 2e-4) and ey_g.max() <= max(4 * ey_o.max(), 1e-4)
+    es_o = np.abs(g["sigma"] - g["sigma64"]) / g["sigma64"]
+    es_g = np.abs(s - g["sigma64"]) / g["sigma64"]
+    print(f"          sigma rel err oracle32 median {np.median(es_o):.3e} max {es_o.max():.3e}; "
+          f"gpu32 median {np.median(es_g):.3e} max {es_g.max():.3e}")
+    assert np.median(es_g) <= max(4 * np.median(es_o), 1e-4)
+    assert np.percentile(es_g, 99) <= max(4 * np.percentile(es_o, 99), 1e-3)
+
+
+# ------------------------------------------------------------------ one-call host route + errors
+def test_lcs_host_route_matches_engine(eng):
+    from lagrangiancoherence_amd.engine import lcs_host
+    u, v, lat, lon = flows.config1()
+    out = lcs_host(u, v, lat, lon, -21600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True, return_traj=True)
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    r = eng.lcs(f, lat, lon, -21600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
+    assert np.array_equal(out["x_dep"], _np(r["x_dep"])) and np.array_equal(out["sigma"], _np(r["sigma"]))
+    assert out["traj_x"].shape == (8, 89, 180) and np.array_equal(out["traj_x"][-1], out["x_dep"])
+
+
+def test_gauss_sigma_path(eng, O):
+    u, v, lat, lon = flows.config1()
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    r = eng.lcs(f, lat, lon, -21600, SETTLS_order=2, interp_order=1, gauss_sigma=1.5)
+    s, _, _ = O.lcs(u, v, lat, lon, timestep=-21600, SETTLS_order=2, interp_order=1, cyclic_xboundary=True,
+                    gauss_sigma=1.5)
+    np.testing.assert_allclose(_np(r["sigma"]), s, rtol=SIG_RTOL64)
+
+
+def test_errors(eng):
+    u, v, lat, lon = _rand_field(51)
+    with pytest.raises(ValueError):
+        eng.prepare_field(u, v, lat, lon, 0)           # reference: slice(0,-0) empty -> reshape error
+    with pytest.raises(ValueError):
+        eng.prepare_field(u, v, lat[::-1], lon, 1)     # must be ascending
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    with pytest.raises(ValueError):
+        eng.advect(f, lat, lon, 3600.0, interp_order=3)    # no coefficient image
+    with pytest.raises(ValueError):
+        eng.advect(f, lat, lon, 3600.0, interp_order=1, t0=2, nsteps=5)   # runs past the last level
