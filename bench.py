@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Benchmark of the FTLE hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the whole hot path over one batch of synthetic input:
+pack the wind series into the gather image, advect every seed through all time
+levels (fused kernel), exchange the 2-row halo (N>1), compute sigma_max.  Inputs
+(u, v, seeds) are resident in HBM before the timed region.
+
+Workload (BASELINE.json configs[2], the 4096^2 grid the metric is quoted on):
+4096x4096 seeds per GPU on a 720x1440 synthetic ERA5-like field, 97 time levels
+(96 steps of 15 min), float32, SETTLS_order K=4, interp_order=1, cyclic.
+N>1: the seed grid is (4096*N) x 4096, row-sharded (weak scaling), wind replicated.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def b_adv(K: int, order: int, s_p: int, s_f: int) -> int:
+    """Algorithmic bytes per particle-timestep."""
+    taps = 4 if order == 1 else 16
+    return 4 * s_p + taps * (2 + 4 * K) * s_f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seeds", type=int, default=4096, help="seed rows per GPU and seed columns")
+    ap.add_argument("--nt", type=int, default=97)
+    ap.add_argument("--settls", type=int, default=4)
+    ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lagrangiancoherence_amd import flows, sharded
+    from lagrangiancoherence_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    K, order, nt = args.settls, args.order, args.nt
+    nsteps = nt - 1
+    ny_local = nx = args.seeds
+    ny_global = ny_local * world
+    dt = -900.0
+
+    # ---- synthetic input, then resident in HBM -------------------------------------------
+    u, v, lat, lon = flows.era5_like(nt=nt)                       # float32, 720x1440
+    slat, slon = flows.seed_grid(ny_global, nx, lat, lon)
+    eng = Engine(local_rank)
+    ud = eng.to_device(u, np.float32)
+    vd = eng.to_device(v, np.float32)
+    lo, hi = sharded.row_partition(ny_global, world, rank)
+    torch.cuda.synchronize()
+
+    ev = {k: [] for k in ("pack", "advect", "halo", "sigma")}
+
+    def one_step(record: bool):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        marks[0].record()
+        field = eng.prepare_field(ud, vd, lat, lon, order)
+        marks[1].record()
+        x, y = eng.advect(field, slat[lo:hi], slon, dt, K, order, True, 0, nsteps, row0=lo, ny_global=ny_global)
+        marks[2].record()
+        x_ext, y_ext, in_row0 = sharded.halo_exchange(x, y, rank, world, ny_global, lo, hi)
+        marks[3].record()
+        sig = eng.sigma(x_ext, y_ext, slat[in_row0:in_row0 + x_ext.shape[0]], float(slat[1] - slat[0]),
+                        float(slon[1] - slon[0]), ny_global=ny_global, in_row0=in_row0, out_row0=lo,
+                        n_out_rows=hi - lo)
+        marks[4].record()
+        if record:
+            ev_marks.append(marks)
+        return sig
+
+    ev_marks = []
+    for _ in range(args.warmup):
+        one_step(False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sig = one_step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    for marks in ev_marks:
+        for i, k in enumerate(("pack", "advect", "halo", "sigma")):
+            ev[k].append(marks[i].elapsed_time(marks[i + 1]))     # ms, on the launch stream
+    ms = {k: float(np.mean(vv)) for k, vv in ev.items()}
+    assert bool(torch.isfinite(sig).all()), "non-finite sigma in the benchmark output"
+
+    pts_per_step = ny_global * nx * nsteps
+    value = pts_per_step * args.steps / elapsed
+    s_f = s_p = 4
+    bytes_pts = b_adv(K, order, s_p, s_f)
+    adv_s = ms["advect"] / 1e3
+    achieved = (ny_local * nx * nsteps) * bytes_pts / adv_s / 1e9            # per GPU, dominant kernel
+    sig_s = ms["sigma"] / 1e3
+    sigma_gbps = (ny_local * nx) * 3 * s_p / sig_s / 1e9
+
+    out = {
+        "metric": "particle-timesteps/sec (+ FTLE Mcells/sec) at 4096^2 seeds per GPU",
+        "value": value,
+        "unit": "particle-timesteps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[2]: {ny_local}x{nx} seeds per GPU (global {ny_global}x{nx}, row-sharded) on a "
+                        f"720x1440 synthetic ERA5-like wind series, {nt} levels ({nsteps} steps, dt=-900 s), fp32",
+            "SETTLS_order": K, "interp_order": order, "cyclic_xboundary": True,
+            "step": "pack + fused advect + halo exchange + sigma; u/v/seeds resident in HBM",
+        },
+        "advect_particle_timesteps_per_s": ny_global * nx * nsteps / adv_s,
+        "ftle_mcells_per_s": ny_global * nx / sig_s / 1e6,
+        "kernel_ms": ms,
+        "roofline": {
+            "bound": "hbm", "kernel": "advect_kernel<float,%d>" % order,
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_particle_timestep": bytes_pts,
+            "note": "achieved = B_adv(K,order) x seeds x steps / HIP-event duration of the fused advect launch "
+                    "(per GPU); the taps are served from L2/Infinity Cache, so this is an algorithmic, not an "
+                    "HBM-traffic, figure (SURVEY 8d)",
+        },
+        "roofline_sigma": {
+            "bound": "hbm", "kernel": "sigma_kernel<float,float>", "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "traffic": None,
+            "algorithmic_bytes_per_cell": 3 * s_p,
+        },
+    }
+
+    # ---- CPU baseline: the oracle (numpy+scipy port) on a bounded sample, rank 0, N=1 only ----
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        from oracle import lcs_oracle as O
+        n_s, st_s = 1024, 16
+        sl, so = flows.seed_grid(n_s, n_s, lat, lon)
+        c0 = time.perf_counter()
+        O.lcs(u[:st_s + 1], v[:st_s + 1], lat, lon, timestep=dt, SETTLS_order=K, interp_order=order,
+              cyclic_xboundary=True, seed_lat=sl, seed_lon=so)
+        c1 = time.perf_counter()
+        out["cpu_baseline"] = {
+            "value": n_s * n_s * st_s / (c1 - c0), "unit": "particle-timesteps/s", "cores": 1, "kind": "port",
+            "sample": f"{n_s}x{n_s} seeds x {st_s} steps of the same field and settings, advect+sigma, "
+                      f"oracle/lcs_oracle.py (scipy.ndimage.map_coordinates + LAPACK SVD, single thread), "
+                      f"{c1 - c0:.1f} s on a host with {os.cpu_count()} cores",
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

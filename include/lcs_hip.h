@@ -62,7 +62,8 @@ const char *lc_last_error(void);
  * an external one (e.g. the stream a host framework is already using). */
 int lc_ctx_create(int device, lc_ctx **out);
 int lc_ctx_destroy(lc_ctx *ctx);
-int lc_ctx_set_stream(lc_ctx *ctx, void *hip_stream /* hipStream_t or NULL = own stream */);
+int lc_ctx_set_stream(lc_ctx *ctx, void *hip_stream /* hipStream_t; NULL = the device's default stream */);
+int lc_ctx_use_own_stream(lc_ctx *ctx); /* back to the context's private stream */
 int lc_sync(lc_ctx *ctx);
 
 /* ---- device memory (so a ctypes-only host needs nothing else) ---------- */

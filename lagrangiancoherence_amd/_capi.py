@@ -24,6 +24,7 @@ PROTOTYPES = {
     "lc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "lc_ctx_destroy": (_i, [_vp]),
     "lc_ctx_set_stream": (_i, [_vp, _vp]),
+    "lc_ctx_use_own_stream": (_i, [_vp]),
     "lc_sync": (_i, [_vp]),
     "lc_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "lc_free": (_i, [_vp, _vp]),

@@ -54,7 +54,13 @@ extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
 
 extern "C" int lc_ctx_set_stream(lc_ctx *ctx, void *hip_stream) {
     LC_REQUIRE(ctx, "lc_ctx_set_stream: null context");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;  // NULL is the legacy default stream, a valid stream
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_use_own_stream(lc_ctx *ctx) {
+    LC_REQUIRE(ctx, "lc_ctx_use_own_stream: null context");
+    ctx->stream = ctx->own_stream;
     return LC_OK;
 }
 

@@ -32,7 +32,7 @@ def common_dtype(*arrays) -> np.dtype:
     positions and fp32 velocities); the kernels have one arithmetic
     type per call, so a mixed call is computed in float64.
     """
-    dts = {np.dtype(getattr(a, "dtype", np.float64)) for a in arrays if a is not None}
+    dts = {np.dtype(str(getattr(a, "dtype", "float64")).replace("torch.", "")) for a in arrays if a is not None}
     return np.dtype(np.float32) if dts == {np.dtype(np.float32)} else np.dtype(np.float64)
 
 

@@ -1,0 +1,116 @@
+"""Multi-GPU decomposition of the path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU tests).
+
+The reference has no parallelism at all (SURVEY.md sections 2, 5); this is new.
+
+* Advection is independent per seed (LCS/trajectory.py:80-126): the seed grid is
+  cut into contiguous blocks of latitude ROWS, longitude stays whole so the
+  stencil's cyclic ``% xsize`` (LCS/tools.py:225-228) is local.  The wind series
+  is replicated.  No communication.
+* The flow-map gradient couples rows r-2..r+2 (LCS/tools.py:202-207): ONE
+  neighbour exchange of 2 halo rows of (x_dep, y_dep) between advection and the
+  sigma kernel -- point-to-point send/recv with the previous / next rank only,
+  non-periodic (rank 0 and the last rank have one neighbour; the 2 first / last
+  global rows use the one-sided rule and need no halo).  No all-reduce anywhere.
+* Ensembles (BASELINE config 5) shard start times: no communication at all.
+"""
+from __future__ import annotations
+
+HALO = 2  # rows; LCS/tools.py:202-207 (4th-order, +-2 points), SURVEY Q12
+
+__all__ = ["HALO", "row_partition", "halo_rows", "halo_exchange", "ensemble_partition", "sharded_lcs"]
+
+
+def row_partition(ny_global: int, world: int, rank: int):
+    """Rows [lo, hi) owned by ``rank``: contiguous, sizes differ by at most 1."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} not in [0,{world})")
+    if ny_global < world * HALO:
+        raise ValueError(f"{ny_global} rows cannot be split over {world} ranks with a {HALO}-row halo")
+    base, rem = divmod(ny_global, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def halo_rows(ny_global: int, lo: int, hi: int):
+    """(rows needed below lo, rows needed above hi) for sigma on rows [lo, hi)."""
+    return min(HALO, lo), min(HALO, ny_global - hi)
+
+
+def ensemble_partition(n_members: int, world: int, rank: int):
+    """Member indices handled by ``rank`` (contiguous blocks)."""
+    base, rem = divmod(n_members, world)
+    lo = rank * base + min(rank, rem)
+    return list(range(lo, lo + base + (1 if rank < rem else 0)))
+
+
+def halo_exchange(x, y, rank: int, world: int, ny_global: int, lo: int, hi: int, group=None):
+    """Exchange the 2 boundary rows of the local (x_dep, y_dep) block with both neighbours.
+
+    ``x``, ``y``: ``(hi-lo, nx)`` tensors on the backend's device.  Returns
+    ``(x_ext, y_ext, in_row0)``: the block extended by the halo rows received,
+    and the global index of its first row -- the input window ``lc_sigma`` wants.
+    One message per neighbour per direction holds both arrays
+    (2 rows x nx x 2 arrays; 128 KiB at nx=8192 fp32 -- latency-bound on xGMI).
+    """
+    import torch
+    import torch.distributed as dist
+    n_lo, n_hi = halo_rows(ny_global, lo, hi)
+    if world == 1:
+        return x, y, lo
+    if x.shape[0] < HALO:
+        raise ValueError("local block thinner than the halo")
+    ops, recv_lo, recv_hi = [], None, None
+    if rank > 0:           # previous rank owns the rows just below lo
+        send = torch.stack([x[:HALO], y[:HALO]]).contiguous()
+        recv_lo = torch.empty_like(send)
+        ops += [dist.P2POp(dist.isend, send, rank - 1, group), dist.P2POp(dist.irecv, recv_lo, rank - 1, group)]
+    if rank < world - 1:   # next rank owns the rows from hi on
+        send2 = torch.stack([x[-HALO:], y[-HALO:]]).contiguous()
+        recv_hi = torch.empty_like(send2)
+        ops += [dist.P2POp(dist.isend, send2, rank + 1, group), dist.P2POp(dist.irecv, recv_hi, rank + 1, group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    xs, ys = [x], [y]
+    if recv_lo is not None:
+        assert n_lo == HALO
+        xs.insert(0, recv_lo[0])
+        ys.insert(0, recv_lo[1])
+    if recv_hi is not None:
+        assert n_hi == HALO
+        xs.append(recv_hi[0])
+        ys.append(recv_hi[1])
+    return torch.cat(xs), torch.cat(ys), lo - (HALO if recv_lo is not None else 0)
+
+
+def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, world: int, SETTLS_order=0,
+                interp_order=1, cyclic_xboundary=True, t0=0, nsteps=None, fd_fp32_cast=True,
+                tensor_layout="reference", group=None, redundant_halo=False):
+    """This rank's rows of (sigma, x_dep, y_dep) for a row-sharded seed grid.
+
+    ``redundant_halo=True`` advects the halo rows locally instead of exchanging them
+    (0.1 % extra work at 4096 rows/GPU); the results are bit-identical and the
+    tests use it to check the exchange.
+    """
+    import numpy as np
+    seed_lat_global = np.asarray(seed_lat_global, dtype=field.dtype)
+    seed_lon = np.asarray(seed_lon, dtype=field.dtype)
+    nyg = seed_lat_global.size
+    lo, hi = row_partition(nyg, world, rank)
+    n_lo, n_hi = halo_rows(nyg, lo, hi)
+    if redundant_halo:
+        a, b = lo - n_lo, hi + n_hi
+        x_ext, y_ext = engine.advect(field, seed_lat_global[a:b], seed_lon, timestep, SETTLS_order, interp_order,
+                                     cyclic_xboundary, t0, nsteps, row0=a, ny_global=nyg)
+        in_row0 = a
+        x, y = x_ext[n_lo:n_lo + hi - lo], y_ext[n_lo:n_lo + hi - lo]
+    else:
+        x, y = engine.advect(field, seed_lat_global[lo:hi], seed_lon, timestep, SETTLS_order, interp_order,
+                             cyclic_xboundary, t0, nsteps, row0=lo, ny_global=nyg)
+        x_ext, y_ext, in_row0 = halo_exchange(x, y, rank, world, nyg, lo, hi, group)
+    dlat = float(seed_lat_global[1] - seed_lat_global[0])
+    dlon = float(seed_lon[1] - seed_lon[0])
+    sig = engine.sigma(x_ext, y_ext, seed_lat_global[in_row0:in_row0 + x_ext.shape[0]], dlat, dlon, ny_global=nyg,
+                       in_row0=in_row0, out_row0=lo, n_out_rows=hi - lo, fd_fp32_cast=fd_fp32_cast,
+                       tensor_layout=tensor_layout)
+    return {"sigma": sig, "x_dep": x, "y_dep": y, "rows": (lo, hi)}
