@@ -123,6 +123,16 @@ int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int d
               int t0, int nsteps,
               void *x_out, void *y_out, void *traj_x, void *traj_y);
 
+/* One interpolation pass on its own: tools.xr_map_coordinates (LCS/tools.py:11-41) for the
+ * u and v fields of time level `level` at the given positions (degrees), same index
+ * scale, row classes and boundary modes as inside lc_advect.  pos_x/pos_y/out_u/out_v
+ * are [ny*nx] dtype elements on the device. */
+int lc_sample(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype,
+              int nt, int ny_f, int nx_f,
+              double lat_min, double lat_max, double lon_min, double lon_max, int level,
+              const void *pos_x_dev, const void *pos_y_dev, int ny, int nx,
+              int row0, int ny_global, int interp_order, void *out_u, void *out_v);
+
 /* ---- K3: flow-map gradient + largest singular value ------------------------
  * Replaces LCS.flowmap_gradient (LCS/LCS.py:171-225), tools.derivative_spherical_coords
  * + tools.fourth_order_derivative (LCS/tools.py:248-267, 190-228) and the eigen
@@ -143,6 +153,19 @@ int lc_sigma(lc_ctx *ctx, const void *x_dep, const void *y_dep, int dtype,
              const void *seed_lat_dev, double dlat, double dlon,
              int fd_fp32_cast, int tensor_layout,
              int out_row0, int n_out_rows, void *sigma_out);
+
+/* The 9-component "def_tensor" itself, for callers of LCS.flowmap_gradient
+ * (LCS/LCS.py:171-225): planes dXdx,dXdy,dYdx,dYdy,dZdx,dZdy,dXdr,dYdr,dZdr (the last
+ * three all zero, LCS.py:206-208), each [ny*nx], whole grid on one device. */
+int lc_flowmap_gradient(lc_ctx *ctx, const void *x_dep, const void *y_dep, int dtype,
+                        int ny, int nx, const void *seed_lat_dev, double dlat, double dlon,
+                        int fd_fp32_cast, void *def_tensor_out);
+
+/* tools.fourth_order_derivative (LCS/tools.py:190-228, the isglobal branch): 5-point
+ * index-space difference of a [ny*nx] array along dim 0 (latitude; one-sided/2 on the
+ * 2 first/last rows) or dim 1 (longitude, cyclic); result in the input dtype. */
+int lc_fourth_order_derivative(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int nx,
+                               int dim, void *out_dev);
 
 /* ---- optional smoothing of the departure fields ----------------------------
  * Replaces scipy.ndimage.gaussian_filter(x, sigma) at LCS/LCS.py:187-190

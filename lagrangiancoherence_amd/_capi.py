@@ -34,7 +34,10 @@ PROTOTYPES = {
     "lc_field_pack": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lc_advect": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i,
                        _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lc_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lc_sigma": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _d, _d, _i, _i, _i, _i, _vp]),
+    "lc_flowmap_gradient": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _d, _d, _i, _vp]),
+    "lc_fourth_order_derivative": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lc_gaussian_filter": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp]),
     "lc_lcs_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i,
                          _d, _i, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _vp]),

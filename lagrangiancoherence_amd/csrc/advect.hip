@@ -297,7 +297,81 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int
     return LC_OK;
 }
 
+// ---- a2 on its own: one interpolation pass at given positions (tools.py:11-41) ----
+template <typename T, int ORDER>
+__global__ void sample_kernel(const AdvectArgs<T> A, const T *__restrict__ px, const T *__restrict__ py, int level,
+                              T *__restrict__ out_u, T *__restrict__ out_v) {
+    const size_t n = (size_t)A.ny * A.nx;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int iy = (int)(i / A.nx);
+        const int grow = A.row0 + iy;
+        const bool pole = grow < A.order || grow >= A.ny_global - A.order;
+        Pair<T> r;
+        if (pole)
+            r = sample<T, 1, false>(A.lin + (size_t)level * A.level_elems, A, px[i], py[i]);
+        else
+            r = sample<T, ORDER, true>(A.img + (size_t)level * A.level_elems, A, px[i], py[i]);
+        out_u[i] = r.u;
+        out_v[i] = r.v;
+    }
+}
+
+template <typename T>
+int sample_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int ny_f, int nx_f, double lat_min,
+                double lat_max, double lon_min, double lon_max, int level, const void *px, const void *py, int ny,
+                int nx, int row0, int ny_global, int order, void *out_u, void *out_v) {
+    AdvectArgs<T> A = {};
+    A.lin = (const T *)packed_lin;
+    A.img = (order == 3) ? (const T *)packed_cub : (const T *)packed_lin;
+    A.level_elems = lc_level_elems(ny_f, nx_f);
+    A.pitch = nx_f + LC_PAD;
+    A.ny_f = ny_f;
+    A.nx_f = nx_f;
+    A.lat_min = (T)lat_min;
+    A.lon_min = (T)lon_min;
+    A.lat_span = (T)lat_max - (T)lat_min;
+    A.lon_span = (T)lon_max - (T)lon_min;
+    A.ny = ny;
+    A.nx = nx;
+    A.row0 = row0;
+    A.ny_global = ny_global;
+    A.order = order;
+    const size_t n = (size_t)ny * nx;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    if (order == 3)
+        hipLaunchKernelGGL((sample_kernel<T, 3>), dim3(blocks), dim3(256), 0, ctx->stream, A, (const T *)px,
+                           (const T *)py, level, (T *)out_u, (T *)out_v);
+    else
+        hipLaunchKernelGGL((sample_kernel<T, 1>), dim3(blocks), dim3(256), 0, ctx->stream, A, (const T *)px,
+                           (const T *)py, level, (T *)out_u, (T *)out_v);
+    LC_HIP_CHECK(hipGetLastError());
+    return LC_OK;
+}
+
 }  // namespace
+
+extern "C" int lc_sample(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype, int nt, int ny_f,
+                         int nx_f, double lat_min, double lat_max, double lon_min, double lon_max, int level,
+                         const void *pos_x_dev, const void *pos_y_dev, int ny, int nx, int row0, int ny_global,
+                         int interp_order, void *out_u, void *out_v) {
+    LC_REQUIRE(ctx, "lc_sample: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_sample: bad dtype %d", dtype);
+    if (interp_order != 1 && interp_order != 3) {
+        lc_set_error("lc_sample: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
+        return LC_EUNSUPPORTED;
+    }
+    LC_REQUIRE(packed_lin && (interp_order == 1 || packed_cub), "lc_sample: missing field image");
+    LC_REQUIRE(pos_x_dev && pos_y_dev && out_u && out_v, "lc_sample: null pointer");
+    LC_REQUIRE(level >= 0 && level < nt && ny_f >= 4 && nx_f >= 4 && ny >= 1 && nx >= 1, "lc_sample: bad sizes");
+    LC_REQUIRE(row0 >= 0 && row0 + ny <= ny_global, "lc_sample: rows outside the global grid");
+    LC_REQUIRE(lat_max > lat_min && lon_max > lon_min, "lc_sample: field coordinates must be ascending");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (dtype == LC_F32)
+        return sample_impl<float>(ctx, packed_lin, packed_cub, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, level,
+                                  pos_x_dev, pos_y_dev, ny, nx, row0, ny_global, interp_order, out_u, out_v);
+    return sample_impl<double>(ctx, packed_lin, packed_cub, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, level,
+                               pos_x_dev, pos_y_dev, ny, nx, row0, ny_global, interp_order, out_u, out_v);
+}
 
 extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype, int nt, int ny_f,
                          int nx_f, double lat_min, double lat_max, double lon_min, double lon_max,

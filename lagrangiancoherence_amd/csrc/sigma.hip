@@ -33,7 +33,8 @@ struct SigmaArgs {
     T dlat, dlon;
     int layout;
     int out_row0, n_out_rows;
-    T *sigma;
+    T *sigma;   // may be null
+    T *tensor;  // null, or 9 planes [n_out_rows*nx] in the reference's merge order (LCS.py:220)
 };
 
 // T: arithmetic type of positions; S: type X,Y,Z are differenced in
@@ -98,12 +99,24 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel(const SigmaArgs<T> A) {
         const T latr = (A.seed_lat[gy - A.in_row0] * PI) / T(180);  // tools.py:254
         const T dx = (((PI / T(180)) * A.dlon) * R) * cos(latr);   // tools.py:255
         // derivative / metric: the division is done in T (float64 / float32 as numpy would)
-        const double a_ = (double)((T)ddx(sX) / dx);  // dXdx
-        const double b_ = (double)((T)ddy(sX) / dy);  // dXdy
-        const double c_ = (double)((T)ddx(sY) / dx);  // dYdx
-        const double d_ = (double)((T)ddy(sY) / dy);  // dYdy
-        const double e_ = (double)((T)ddx(sZ) / dx);  // dZdx
-        const double f_ = (double)((T)ddy(sZ) / dy);  // dZdy
+        const T ta = (T)ddx(sX) / dx, tb = (T)ddy(sX) / dy;  // dXdx, dXdy
+        const T tc = (T)ddx(sY) / dx, td = (T)ddy(sY) / dy;  // dYdx, dYdy
+        const T te = (T)ddx(sZ) / dx, tf = (T)ddy(sZ) / dy;  // dZdx, dZdy
+        const size_t oidx = (size_t)(gy - A.out_row0) * A.nx + gx;
+        if (A.tensor) {
+            const size_t plane = (size_t)A.n_out_rows * A.nx;
+            A.tensor[oidx] = ta;
+            A.tensor[plane + oidx] = tb;
+            A.tensor[2 * plane + oidx] = tc;
+            A.tensor[3 * plane + oidx] = td;
+            A.tensor[4 * plane + oidx] = te;
+            A.tensor[5 * plane + oidx] = tf;
+            A.tensor[6 * plane + oidx] = T(0);  // dXdr, dYdr, dZdr (LCS.py:206-208)
+            A.tensor[7 * plane + oidx] = T(0);
+            A.tensor[8 * plane + oidx] = T(0);
+        }
+        if (!A.sigma) continue;
+        const double a_ = ta, b_ = tb, c_ = tc, d_ = td, e_ = te, f_ = tf;
         double p, q, r;
         if (A.layout == LC_LAYOUT_REFERENCE) {
             // M = [[a,b,c],[d,e,f],[0,0,0]] (LCS.py:153): Gram matrix of its two non-zero rows
@@ -119,14 +132,14 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel(const SigmaArgs<T> A) {
         const double dpq = p - q;
         const double disc = sqrt(dpq * dpq + 4.0 * r * r);
         const double lam = 0.5 * ((p + q) + disc);
-        A.sigma[(size_t)(gy - A.out_row0) * A.nx + gx] = (T)sqrt(lam);  // NaN in -> NaN out (Q14)
+        A.sigma[oidx] = (T)sqrt(lam);  // NaN in -> NaN out (Q14)
     }
 }
 
 template <typename T>
 int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, int n_in_rows, int nx, int ny_global,
                const void *seed_lat, double dlat, double dlon, int fd_fp32_cast, int layout, int out_row0,
-               int n_out_rows, void *sigma_out) {
+               int n_out_rows, void *sigma_out, void *tensor_out = nullptr) {
     SigmaArgs<T> A;
     A.x_dep = (const T *)x_dep;
     A.y_dep = (const T *)y_dep;
@@ -141,6 +154,7 @@ int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, i
     A.out_row0 = out_row0;
     A.n_out_rows = n_out_rows;
     A.sigma = (T *)sigma_out;
+    A.tensor = (T *)tensor_out;
     const int ntx = (nx + SW - 1) / SW, nty = (n_out_rows + SH - 1) / SH;
     if (fd_fp32_cast || sizeof(T) == 4)
         hipLaunchKernelGGL((sigma_kernel<T, float>), dim3(ntx * nty), dim3(SBLOCK), 0, ctx->stream, A);
@@ -150,7 +164,53 @@ int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, i
     return LC_OK;
 }
 
+// tools.fourth_order_derivative on its own (LCS/tools.py:190-228, isglobal branch): index-space
+// stencil on a 2-D array, numba typing (S differences, double scaling, S store).
+template <typename S>
+__global__ void index_derivative_kernel(const S *__restrict__ a, S *__restrict__ out, int ny, int nx, int dim) {
+#pragma clang fp contract(off)
+    const size_t n = (size_t)ny * nx;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / nx), x = (int)(i - (size_t)y * nx);
+        double r;
+        if (dim == 0) {
+            if (y < 2)
+                r = (double)(a[i + nx] - a[i]) / 2.0;
+            else if (y >= ny - 2)
+                r = (double)(a[i] - a[i - nx]) / 2.0;
+            else
+                r = (4.0 / 3.0) * (double)(a[i + nx] - a[i - nx]) / 2.0 -
+                    (1.0 / 3.0) * (double)(a[i + 2 * (size_t)nx] - a[i - 2 * (size_t)nx]) / 4.0;
+        } else {
+            const S *row = a + (size_t)y * nx;
+            const int xp1 = (x + 1) % nx, xm1 = (x - 1 + nx) % nx, xp2 = (x + 2) % nx, xm2 = (x - 2 + nx) % nx;
+            r = (4.0 / 3.0) * (double)(row[xp1] - row[xm1]) / 2.0 - (1.0 / 3.0) * (double)(row[xp2] - row[xm2]) / 4.0;
+        }
+        out[i] = (S)r;
+    }
+}
+
 }  // namespace
+
+extern "C" int lc_fourth_order_derivative(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int nx, int dim,
+                                          void *out_dev) {
+    LC_REQUIRE(ctx, "lc_fourth_order_derivative: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_fourth_order_derivative: bad dtype %d", dtype);
+    LC_REQUIRE(in_dev && out_dev && in_dev != out_dev, "lc_fourth_order_derivative: bad pointers");
+    LC_REQUIRE(ny >= 5 && nx >= 5, "lc_fourth_order_derivative: grid %dx%d too small", ny, nx);
+    LC_REQUIRE(dim == 0 || dim == 1, "Dim must be either 0 or 1.");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ny * nx;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    if (dtype == LC_F32)
+        hipLaunchKernelGGL(index_derivative_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           (const float *)in_dev, (float *)out_dev, ny, nx, dim);
+    else
+        hipLaunchKernelGGL(index_derivative_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
+                           (const double *)in_dev, (double *)out_dev, ny, nx, dim);
+    LC_HIP_CHECK(hipGetLastError());
+    return LC_OK;
+}
 
 extern "C" int lc_sigma(lc_ctx *ctx, const void *x_dep, const void *y_dep, int dtype, int in_row0, int n_in_rows,
                         int nx, int ny_global, const void *seed_lat_dev, double dlat, double dlon, int fd_fp32_cast,
@@ -176,4 +236,19 @@ extern "C" int lc_sigma(lc_ctx *ctx, const void *x_dep, const void *y_dep, int d
                                  fd_fp32_cast, tensor_layout, out_row0, n_out_rows, sigma_out);
     return sigma_impl<double>(ctx, x_dep, y_dep, in_row0, n_in_rows, nx, ny_global, seed_lat_dev, dlat, dlon,
                               fd_fp32_cast, tensor_layout, out_row0, n_out_rows, sigma_out);
+}
+
+extern "C" int lc_flowmap_gradient(lc_ctx *ctx, const void *x_dep, const void *y_dep, int dtype, int ny, int nx,
+                                   const void *seed_lat_dev, double dlat, double dlon, int fd_fp32_cast,
+                                   void *def_tensor_out) {
+    LC_REQUIRE(ctx, "lc_flowmap_gradient: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_flowmap_gradient: bad dtype %d", dtype);
+    LC_REQUIRE(x_dep && y_dep && seed_lat_dev && def_tensor_out, "lc_flowmap_gradient: null pointer");
+    LC_REQUIRE(nx >= 5 && ny >= 5, "lc_flowmap_gradient: grid %dx%d too small for the 5-point stencil", ny, nx);
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (dtype == LC_F32)
+        return sigma_impl<float>(ctx, x_dep, y_dep, 0, ny, nx, ny, seed_lat_dev, dlat, dlon, fd_fp32_cast,
+                                 LC_LAYOUT_REFERENCE, 0, ny, nullptr, def_tensor_out);
+    return sigma_impl<double>(ctx, x_dep, y_dep, 0, ny, nx, ny, seed_lat_dev, dlat, dlon, fd_fp32_cast,
+                              LC_LAYOUT_REFERENCE, 0, ny, nullptr, def_tensor_out);
 }

@@ -158,6 +158,25 @@ class Engine:
             self._ptr(tx), self._ptr(ty)), self.lib)
         return (x, y, tx, ty) if return_traj else (x, y)
 
+    def sample(self, field: PackedField, pos_x, pos_y, level=0, interp_order=1, row0=0, ny_global=None):
+        """tools.xr_map_coordinates for (u, v) of one time level at positions (ny, nx) in degrees."""
+        if interp_order == 3 and field.cub is None:
+            raise ValueError("field was prepared for interp_order=1")
+        dtype = field.dtype
+        px = self.to_device(pos_x, dtype)
+        py = self.to_device(pos_y, dtype)
+        ny, nx = (int(s) for s in px.shape)
+        ny_global = ny if ny_global is None else int(ny_global)
+        ou = self._empty((ny, nx), dtype)
+        ov = self._empty((ny, nx), dtype)
+        self._use_current_stream()
+        _capi.check(self.lib.lc_sample(
+            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order == 3 else None), _NP2LC[dtype],
+            field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max, int(level),
+            self._ptr(px), self._ptr(py), ny, nx, int(row0), ny_global, int(interp_order), self._ptr(ou),
+            self._ptr(ov)), self.lib)
+        return ou, ov
+
     # ------------------------------------------------------------------ K3
     def sigma(self, x_dep, y_dep, seed_lat_rows, dlat, dlon, ny_global=None, in_row0=0, out_row0=None,
               n_out_rows=None, fd_fp32_cast=True, tensor_layout="reference"):
@@ -181,6 +200,36 @@ class Engine:
                                       ny_global, self._ptr(slat), float(dlat), float(dlon), int(bool(fd_fp32_cast)),
                                       _LAYOUTS[tensor_layout], out_row0, n_out_rows, self._ptr(sig)), self.lib)
         return sig
+
+    def flowmap_gradient(self, x_dep, y_dep, seed_lat, dlat, dlon, fd_fp32_cast=True):
+        """The (9, ny, nx) def_tensor of LCS.flowmap_gradient (LCS/LCS.py:195-223) as a device tensor."""
+        torch = self.torch
+        dtype = np.dtype(str(x_dep.dtype).replace("torch.", "")) if isinstance(x_dep, torch.Tensor) \
+            else common_dtype(x_dep, y_dep)
+        xd = self.to_device(x_dep, dtype)
+        yd = self.to_device(y_dep, dtype)
+        ny, nx = (int(s) for s in xd.shape)
+        slat = self.to_device(seed_lat, dtype)
+        out = self._empty((9, ny, nx), dtype)
+        self._use_current_stream()
+        _capi.check(self.lib.lc_flowmap_gradient(self.ctx, self._ptr(xd), self._ptr(yd), _NP2LC[dtype], ny, nx,
+                                                 self._ptr(slat), float(dlat), float(dlon), int(bool(fd_fp32_cast)),
+                                                 self._ptr(out)), self.lib)
+        return out
+
+    def index_derivative(self, a, dim):
+        """tools.fourth_order_derivative(a, dim, isglobal=True) (LCS/tools.py:190-228); dtype preserved."""
+        torch = self.torch
+        dtype = np.dtype(str(a.dtype).replace("torch.", ""))
+        if dtype not in _NP2LC:
+            raise ValueError(f"dtype {dtype} unsupported (float32 / float64)")
+        ad = self.to_device(a, dtype)
+        ny, nx = (int(s) for s in ad.shape)
+        out = self._empty((ny, nx), dtype)
+        self._use_current_stream()
+        _capi.check(self.lib.lc_fourth_order_derivative(self.ctx, self._ptr(ad), _NP2LC[dtype], ny, nx, int(dim),
+                                                        self._ptr(out)), self.lib)
+        return out
 
     def gaussian_filter(self, a, sigma):
         """scipy.ndimage.gaussian_filter(a, sigma) on the device (LCS/LCS.py:187-190)."""

@@ -1,0 +1,100 @@
+"""A very small labelled-array container, used ONLY where xarray is not installed.
+
+The drop-in surface (`dropin.py`) is xarray-in / xarray-out like the reference.
+This image has no xarray, so the same code path is exercised in the tests with
+these stand-ins: they carry exactly what the adapter reads (``dims``, ``values``,
+per-dimension coordinates, scalar coordinates, ``name``) and nothing else.  When
+xarray is importable the adapter builds real ``xarray.DataArray`` objects and this
+module is not involved.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["DataArray", "Dataset"]
+
+
+class DataArray:
+    def __init__(self, data, dims, coords=None, name=None):
+        self.values = np.asarray(data)
+        self.dims = tuple(dims)
+        if self.values.ndim != len(self.dims):
+            raise ValueError(f"{self.values.ndim}-d data with dims {self.dims}")
+        self.coords = {}
+        for k, v in (coords or {}).items():
+            v = np.asarray(v)
+            if k in self.dims and v.shape != (self.values.shape[self.dims.index(k)],):
+                raise ValueError(f"coordinate {k!r} has shape {v.shape}")
+            self.coords[k] = v
+        self.name = name
+
+    # -- what the adapter and user code touch ---------------------------------
+    @property
+    def shape(self):
+        return self.values.shape
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            c = self.coords[key]
+            return DataArray(c, (key,) if c.ndim else (), {key: c} if c.ndim else {}, name=key)
+        raise TypeError("only coordinate lookup by name is supported")
+
+    def __getattr__(self, key):
+        coords = self.__dict__.get("coords", {})
+        if key in coords:
+            return self[key]
+        raise AttributeError(key)
+
+    def copy(self, data=None):
+        return DataArray(self.values.copy() if data is None else np.asarray(data), self.dims,
+                         {k: v.copy() for k, v in self.coords.items()}, self.name)
+
+    def transpose(self, *dims):
+        order = [self.dims.index(d) for d in dims]
+        return DataArray(self.values.transpose(order), dims, self.coords, self.name)
+
+    def sortby(self, dim):
+        idx = np.argsort(self.coords[dim], kind="stable")
+        coords = dict(self.coords)
+        coords[dim] = coords[dim][idx]
+        return DataArray(np.take(self.values, idx, axis=self.dims.index(dim)), self.dims, coords, self.name)
+
+    def isel(self, indexers=None, **kw):
+        indexers = {**(indexers or {}), **kw}
+        data, dims, coords = self.values, list(self.dims), dict(self.coords)
+        for d, i in indexers.items():
+            ax = dims.index(d)
+            data = np.take(data, i, axis=ax) if np.ndim(i) == 0 else data[(slice(None),) * ax + (i,)]
+            coords[d] = coords[d][i]
+            if np.ndim(i) == 0:
+                dims.pop(ax)
+        return DataArray(data, dims, coords, self.name)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.values, dtype=dtype)
+
+    def __repr__(self):
+        return f"<labelled.DataArray {self.name!r} dims={self.dims} shape={self.shape} dtype={self.dtype}>"
+
+
+class Dataset:
+    """Just enough for ``ds.u`` / ``ds.v`` / ``ds.copy()`` (LCS/LCS.py:81-83)."""
+
+    def __init__(self, data_vars):
+        self.data_vars = dict(data_vars)
+
+    def __getattr__(self, key):
+        dv = self.__dict__.get("data_vars", {})
+        if key in dv:
+            return dv[key]
+        raise AttributeError(key)
+
+    def __getitem__(self, key):
+        return self.data_vars[key]
+
+    def copy(self):
+        return Dataset({k: v.copy() for k, v in self.data_vars.items()})

@@ -1,0 +1,148 @@
+"""Drop-in surface on the GPU: the reference's own call forms (examples/ideal_vortex.py:262-288)
+through ``LagrangianCoherence.LCS.*``, checked against the golden fixtures and the oracle.
+
+xarray is not installed in this image, so inputs are ``labelled.DataArray`` stand-ins (same
+adapter code path; with xarray installed the same calls take and return xarray objects)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from lagrangiancoherence_amd import flows, labelled
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _dataset():
+    u, v, lat, lon = flows.config1()
+    # the example builds dims ['latitude','longitude','time'] (examples/ideal_vortex.py:124,203)
+    times = pd.date_range('2000-01-01', periods=u.shape[0], freq='6h').values
+    coords = {'latitude': lat, 'longitude': lon, 'time': times}
+    U = labelled.DataArray(u.transpose(1, 2, 0), ['latitude', 'longitude', 'time'], coords, name='u')
+    V = labelled.DataArray(v.transpose(1, 2, 0), ['latitude', 'longitude', 'time'], coords, name='v')
+    return labelled.Dataset({'u': U, 'v': V}), times, lat, lon
+
+
+def test_example_call_forms():
+    from LagrangianCoherence.LCS import LCS, trajectory
+    ds, times, lat, lon = _dataset()
+    # examples/ideal_vortex.py:262-270
+    x_dye, y_dye = trajectory.parcel_propagation(ds.u, ds.v, timestep=-6 * 3600, propdim='time', SETTLS_order=4,
+                                                 copy=True, return_traj=True, cyclic_xboundary=True, verbose=False)
+    g = np.load(os.path.join(GOLD, "g1_traj_bwd_k4_o3.npz"))
+    assert x_dye.dims == ('time', 'latitude', 'longitude') and x_dye.shape == (8, 89, 180)
+    np.testing.assert_allclose(x_dye.values, g["traj_x"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(y_dye.values, g["traj_y"], rtol=0, atol=1e-9)
+    # backward run: the time LABELS are reversed (trajectory.py:58-60,138)
+    assert x_dye['time'].values[0] == times[-1] and x_dye['time'].values[-1] == times[0]
+    # examples/ideal_vortex.py:286-288 (with the out-of-scope regrid/truncation switched off)
+    acs = LCS.LCS(timestep=-6 * 3600, timedim='time', SETTLS_order=4)
+    ftle_a = acs(ds.copy(), isglobal=True, interp_to_common_grid=False, truncation=None, verbose=False)
+    g = np.load(os.path.join(GOLD, "g1_bwd_k4_o3.npz"))
+    assert ftle_a.dims == ('time', 'latitude', 'longitude') and ftle_a.shape == (1, 89, 180)
+    np.testing.assert_allclose(ftle_a.values[0], g["sigma"], rtol=1e-7)
+    assert ftle_a['time'].values[0] == times[0]            # bwd -> first time (LCS.py:158)
+    ftle = np.log(ftle_a.values) / 2                       # caller-side FTLE (ideal_vortex.py:288)
+    assert np.isfinite(ftle).all()
+    # forward, K=2 (ideal_vortex.py:271-279) without trajectories: scalar time coordinate = last label
+    x, y = trajectory.parcel_propagation(ds.u, ds.v, timestep=6 * 3600, SETTLS_order=2, cyclic_xboundary=True,
+                                         verbose=False)
+    g = np.load(os.path.join(GOLD, "g1_fwd_k2_o3.npz"))
+    np.testing.assert_allclose(x.values, g["x_dep"], rtol=0, atol=1e-9)
+    assert x.dims == ('latitude', 'longitude') and x.coords['time'] == times.tolist()[-1]
+
+
+def test_return_variants_and_timestamp():
+    from LagrangianCoherence.LCS.LCS import LCS
+    ds, times, lat, lon = _dataset()
+    kw = dict(isglobal=True, interp_to_common_grid=False, truncation=None, verbose=False, traj_interp_order=1)
+    out = LCS(timestep=6 * 3600, SETTLS_order=4, return_dpts=True)(ds, return_traj=True, **kw)
+    assert len(out) == 5
+    eig, xd, yd, xt, yt = out
+    g = np.load(os.path.join(GOLD, "g1_fwd_k4_o1.npz"))
+    np.testing.assert_allclose(eig.values[0], g["sigma"], rtol=1e-7)
+    np.testing.assert_allclose(xd.values, g["x_dep"], rtol=0, atol=1e-9)
+    assert eig['time'].values[0] == times[-1]              # fwd -> last time
+    assert xt.shape == (8, 89, 180) and np.array_equal(xt.values[-1], xd.values)
+    assert len(LCS(timestep=6 * 3600, return_dpts=True)(ds, **kw)) == 3
+    assert len(LCS(timestep=6 * 3600)(ds, return_traj=True, **kw)) == 3
+    # u=, v= keywords instead of a dataset (LCS.py:48)
+    e2 = LCS(timestep=6 * 3600, SETTLS_order=4)(u=ds.u, v=ds.v, **kw)
+    assert np.array_equal(e2.values, eig.values)
+
+
+def test_unsorted_descending_latitude_is_sorted_like_the_reference():
+    from LagrangianCoherence.LCS import trajectory
+    ds, times, lat, lon = _dataset()
+    Ur = ds.u.isel(latitude=slice(None, None, -1))
+    Vr = ds.v.isel(latitude=slice(None, None, -1))
+    x, y = trajectory.parcel_propagation(Ur, Vr, timestep=6 * 3600, SETTLS_order=2, cyclic_xboundary=True,
+                                         verbose=False, interp_order=1)
+    x0, y0 = trajectory.parcel_propagation(ds.u, ds.v, timestep=6 * 3600, SETTLS_order=2, cyclic_xboundary=True,
+                                           verbose=False, interp_order=1)
+    assert np.array_equal(x.values, x0.values) and np.array_equal(x['latitude'].values, lat)
+
+
+def test_dims_assertions_and_unsupported_paths():
+    from LagrangianCoherence.LCS.LCS import LCS
+    ds, *_ = _dataset()
+    bad = labelled.DataArray(ds.u.values, ['lat', 'longitude', 'time'],
+                             {'lat': ds.u.coords['latitude'], 'longitude': ds.u.coords['longitude'],
+                              'time': ds.u.coords['time']})
+    with pytest.raises(AssertionError, match="u and v dims are different"):
+        LCS()(u=bad, v=ds.v, verbose=False)
+    with pytest.raises(AssertionError, match="array dims should be latitude and longitude only"):
+        LCS()(u=bad, v=bad, verbose=False)
+    with pytest.raises(NotImplementedError, match="truncation"):
+        LCS()(ds, isglobal=True, verbose=False)            # default regrid + T20 truncation: not in this engine
+    with pytest.raises(ValueError):
+        LCS()(ds, verbose=False, traj_interp_order=0)      # fails in the reference too (tools.py:24-30)
+
+
+def test_subdomain_crop_and_flowmap_gradient():
+    from LagrangianCoherence.LCS.LCS import LCS, flowmap_gradient
+    from oracle import lcs_oracle as O
+    ds, times, lat, lon = _dataset()
+    sub = {'latitude': slice(-20, 20), 'longitude': slice(-60, -20)}
+    e = LCS(timestep=6 * 3600, SETTLS_order=1, subdomain=sub)(ds, verbose=False, traj_interp_order=1)
+    assert e['latitude'].values.min() == -18 and e['latitude'].values.max() == 18   # strict (tools.py:184-185)
+    assert e['longitude'].values.min() == -58 and e['longitude'].values.max() == -22
+    full, xd, yd = LCS(timestep=6 * 3600, SETTLS_order=1, return_dpts=True)(ds, verbose=False, traj_interp_order=1)
+    ilat = (lat > -20) & (lat < 20)
+    ilon = (lon > -60) & (lon < -20)
+    assert np.array_equal(e.values[0], full.values[0][ilat][:, ilon])
+    dt = flowmap_gradient(xd, yd)
+    assert dt.dims == ('derivatives', 'latitude', 'longitude') and dt.shape == (9, 89, 180)
+    ref = O.flowmap_gradient(xd.values, yd.values, lat, lon)
+    np.testing.assert_allclose(dt.values, ref, rtol=1e-9, atol=1e-12)
+    assert list(dt['derivatives'].values[:2]) == ['dxdx', 'dxdy']
+
+
+def test_tools_helpers_vs_scipy_and_oracle():
+    from scipy.ndimage import map_coordinates
+    from LagrangianCoherence.LCS.tools import derivative_spherical_coords, fourth_order_derivative, xr_map_coordinates
+    from oracle import lcs_oracle as O
+    rng = np.random.default_rng(12)
+    lat = np.linspace(-70, 70, 29)
+    lon = -180 + 9.0 * np.arange(40)
+    f = rng.standard_normal((29, 40))
+    da = labelled.DataArray(f, ['latitude', 'longitude'], {'latitude': lat, 'longitude': lon})
+    px = rng.uniform(-400, 400, f.shape)
+    py = rng.uniform(-120, 120, f.shape)
+    for order in (1, 3):
+        got = xr_map_coordinates(da, px, py, order=order)
+        np.testing.assert_allclose(got.values, O.xr_map_coordinates(f, lat, lon, px, py, order=order), atol=5e-13)
+    # KAT-3 straight against scipy on the interior rows (index-space semantics)
+    cy = 29 * (py - lat.min()) / (lat.max() - lat.min())
+    cx = 40 * (px - lon.min()) / (lon.max() - lon.min())
+    ref = map_coordinates(f, np.array([cy[3:-3].ravel(), cx[3:-3].ravel()]), order=3, mode='wrap').reshape(23, 40)
+    np.testing.assert_allclose(xr_map_coordinates(da, px, py, order=3).values[3:-3], ref, atol=5e-13)
+    a32 = (1e6 * rng.standard_normal((29, 40))).astype(np.float32)
+    for dim in (0, 1):
+        assert np.array_equal(fourth_order_derivative(a32, dim=dim), O.fourth_order_derivative(a32, dim=dim))
+        d = derivative_spherical_coords(labelled.DataArray(a32.astype(np.float64), ['latitude', 'longitude'],
+                                                           {'latitude': lat, 'longitude': lon}), dim=dim)
+        np.testing.assert_allclose(d.values, O.derivative_spherical_coords(a32.astype(np.float64), lat, lon, dim=dim),
+                                   rtol=1e-15)
