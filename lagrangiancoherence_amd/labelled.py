@@ -68,9 +68,10 @@ class DataArray:
         data, dims, coords = self.values, list(self.dims), dict(self.coords)
         for d, i in indexers.items():
             ax = dims.index(d)
-            data = np.take(data, i, axis=ax) if np.ndim(i) == 0 else data[(slice(None),) * ax + (i,)]
+            scalar = not isinstance(i, slice) and np.ndim(i) == 0
+            data = data[(slice(None),) * ax + (i,)]
             coords[d] = coords[d][i]
-            if np.ndim(i) == 0:
+            if scalar:
                 dims.pop(ax)
         return DataArray(data, dims, coords, self.name)
 

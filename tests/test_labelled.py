@@ -1,0 +1,38 @@
+"""The xarray stand-in used where xarray is not installed (adapter plumbing only)."""
+import numpy as np
+import pytest
+
+from lagrangiancoherence_amd import labelled
+
+
+def _da():
+    return labelled.DataArray(np.arange(24.0).reshape(2, 3, 4), ['time', 'latitude', 'longitude'],
+                              {'time': np.array([10, 20]), 'latitude': np.array([3.0, 1.0, 2.0]),
+                               'longitude': np.arange(4.0)}, name='u')
+
+
+def test_transpose_sortby_isel_copy():
+    da = _da()
+    t = da.transpose('latitude', 'longitude', 'time')
+    assert t.shape == (3, 4, 2) and t.values[1, 2, 0] == da.values[0, 1, 2]
+    s = da.sortby('latitude')
+    assert list(s['latitude'].values) == [1.0, 2.0, 3.0] and np.array_equal(s.values[:, 0], da.values[:, 1])
+    assert da.isel(time=1).dims == ('latitude', 'longitude') and da.isel(time=1).coords['time'] == 20
+    r = da.isel(latitude=slice(None, None, -1))
+    assert list(r['latitude'].values) == [2.0, 1.0, 3.0] and np.array_equal(r.values[:, 0], da.values[:, 2])
+    c = da.copy()
+    c.values[0, 0, 0] = -1
+    assert da.values[0, 0, 0] == 0 and c.name == 'u'
+    assert da.latitude.values[0] == 3.0 and np.asarray(da).shape == (2, 3, 4)
+
+
+def test_dataset_and_errors():
+    da = _da()
+    ds = labelled.Dataset({'u': da, 'v': da.copy()})
+    assert ds.u is da and ds['v'].shape == (2, 3, 4) and ds.copy().u is not da
+    with pytest.raises(ValueError):
+        labelled.DataArray(np.zeros((2, 2)), ['a'])
+    with pytest.raises(ValueError):
+        labelled.DataArray(np.zeros((2, 2)), ['a', 'b'], {'a': np.zeros(3)})
+    with pytest.raises(AttributeError):
+        ds.w
