@@ -89,6 +89,14 @@ size_t lc_packed_elems(int nt, int ny_f, int nx_f);
 int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype,
                   int nt, int ny_f, int nx_f, int interp_order, void *packed_dev);
 
+/* Optional third image for the SETTLS iterations: ext[t] = 2*packed[t] - packed[t+1],
+ * t = 0..nt-2 (same layout, nt-1 levels).  Interpolation is linear in the field, so
+ * one sample of ext[t] equals 2*interp(F[t]) - interp(F[t+1]) of trajectory.py:110-112
+ * up to rounding, and halves the gathers of every SETTLS iteration.  Build it from
+ * the image that matches interp_order (raw for 1, coefficients for 3). */
+int lc_field_extrapolate(lc_ctx *ctx, const void *packed_dev, int dtype,
+                         int nt, int ny_f, int nx_f, void *ext_dev);
+
 /* ---- K1: parcel advection ------------------------------------------------
  * Replaces trajectory.parcel_propagation (LCS/trajectory.py:8-144) together
  * with every tools.xr_map_coordinates call it makes (LCS/tools.py:11-41):
@@ -98,6 +106,9 @@ int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype,
  *   packed_lin   image from lc_field_pack(order=1)   (always required: the
  *                first/last interp_order seed rows use order 1 + 'constant')
  *   packed_cub   image from lc_field_pack(order=3), or NULL when interp_order==1
+ *   packed_ext   image from lc_field_extrapolate, or NULL.  NULL = two samples per
+ *                SETTLS iteration in the reference's operation order (the float64
+ *                default); non-NULL = one sample of the combined field (float32 path)
  *   lat_min..lon_max   extremes of the FIELD coordinates (index scale, tools.py:21-22,
  *                and the clamp bounds, trajectory.py:63-66)
  *   seed_lat[ny], seed_lon[nx]   seed coordinates (dtype elements, device).  The
@@ -114,7 +125,8 @@ int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype,
  *   traj_x,traj_y  NULL, or [(nsteps+1)*ny*nx]: positions after every step,
  *                entry 0 = seed grid (return_traj=True, trajectory.py:125-139)
  */
-int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype,
+int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub,
+              const void *packed_ext, int dtype,
               int nt, int ny_f, int nx_f,
               double lat_min, double lat_max, double lon_min, double lon_max,
               const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx,

@@ -32,10 +32,12 @@ template <typename T>
 struct AdvectArgs {
     const T *lin;  // order-1 image (raw values)
     const T *img;  // image for the interior rows (== lin for order 1, coefficients for order 3)
+    const T *ext;  // null, or 2*img[t] - img[t+1] (lc_field_extrapolate)
     size_t level_elems;
     int pitch;  // nodes per padded row
     int ny_f, nx_f;
     T lat_min, lat_span, lon_min, lon_span;  // index transform (Q2)
+    T sx, sy;                                // float path: c = (x - min) * (n / span)
     T y_min, y_max, x_min, x_max;            // clamp bounds = field coordinate extremes
     const T *seed_lat, *seed_lon;
     int ny, nx;          // local seed block
@@ -50,6 +52,21 @@ struct AdvectArgs {
 template <typename T>
 struct Pair {
     T u, v;
+};
+
+template <typename T>
+void set_fast_transform(AdvectArgs<T> &A) {
+    const double sx = (double)A.nx_f / (double)A.lon_span, sy = (double)A.ny_f / (double)A.lat_span;
+    A.sx = (T)sx;
+    A.sy = (T)sy;
+}
+
+// The float instantiation cannot be bit-identical to the reference anyway (scipy interpolates
+// float32 fields in double), so it takes the cheap forms: FMA index map, FMA lerps, fmin/fmax
+// clamps.  The double instantiation keeps numpy/scipy's operation order.
+template <typename T>
+struct Fast {
+    static constexpr bool value = sizeof(T) == 4;
 };
 
 // scipy NI_EXTEND_WRAP coordinate map (ni_interpolation.c map_coordinate):
@@ -97,13 +114,21 @@ __device__ __forceinline__ Pair<T> sample1(const T *__restrict__ lvl, int pitch,
     const int y0 = clampi((int)fy, 0, ny_f - 1);  // clamp: memory safety for NaN/inf/rounding
     const int x0 = clampi((int)fx, 0, nx_f - 1);
     const T ty = cy - fy, tx = cx - fx;
-    const T wy0 = T(1) - ty, wy1 = T(1) - wy0;  // scipy: last weight = 1 - sum(others)
-    const T wx0 = T(1) - tx, wx1 = T(1) - wx0;
-    const T *p0 = lvl + ((size_t)(y0 + LC_PAD_LO) * pitch + (x0 + LC_PAD_LO)) * 2;
-    const T *p1 = p0 + (size_t)pitch * 2;
+    const T *p0 = lvl + ((unsigned)(y0 + LC_PAD_LO) * (unsigned)pitch + (unsigned)(x0 + LC_PAD_LO)) * 2u;
+    const T *p1 = p0 + (unsigned)pitch * 2u;
     T a[4], b[4];
     __builtin_memcpy(a, p0, sizeof(a));  // {u00, v00, u01, v01}
     __builtin_memcpy(b, p1, sizeof(b));  // {u10, v10, u11, v11}
+    if (Fast<T>::value) {
+#pragma clang fp contract(fast)
+        const T u0 = fma(tx, a[2] - a[0], a[0]), v0 = fma(tx, a[3] - a[1], a[1]);
+        const T u1 = fma(tx, b[2] - b[0], b[0]), v1 = fma(tx, b[3] - b[1], b[1]);
+        r.u = fma(ty, u1 - u0, u0);
+        r.v = fma(ty, v1 - v0, v0);
+        return r;
+    }
+    const T wy0 = T(1) - ty, wy1 = T(1) - wy0;  // scipy: last weight = 1 - sum(others)
+    const T wx0 = T(1) - tx, wx1 = T(1) - wx0;
     // scipy tap order (last axis fastest); per tap ((value*wy)*wx), summed from 0
     T su = T(0), sv = T(0);
     su += (a[0] * wy0) * wx0;
@@ -143,12 +168,12 @@ __device__ __forceinline__ Pair<T> sample3(const T *__restrict__ lvl, int pitch,
     cubic_weights<T>(cy - fy, wy);
     cubic_weights<T>(cx - fx, wx);
     // window starts at (y0-1, x0-1) -> padded (y0, x0)
-    const T *p = lvl + ((size_t)y0 * pitch + x0) * 2;
+    const T *p = lvl + ((unsigned)y0 * (unsigned)pitch + (unsigned)x0) * 2u;
     T su = T(0), sv = T(0);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         T row[8];
-        __builtin_memcpy(row, p + (size_t)a * pitch * 2, sizeof(row));
+        __builtin_memcpy(row, p + (unsigned)a * (unsigned)pitch * 2u, sizeof(row));
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             su += (row[2 * b] * wy[a]) * wx[b];
@@ -165,17 +190,40 @@ template <typename T, int ORDER, bool WRAP>
 __device__ __forceinline__ Pair<T> sample(const T *__restrict__ lvl, const AdvectArgs<T> &A, T x, T y) {
 #pragma clang fp contract(off)
     // tools.py:21-22: (n * (x - min)) / (max - min)
-    const T cx = (T(A.nx_f) * (x - A.lon_min)) / A.lon_span;
-    const T cy = (T(A.ny_f) * (y - A.lat_min)) / A.lat_span;
+    T cx, cy;
+    if (Fast<T>::value) {
+        // subtract first: exact 0 at the grid origin, where 'constant' mode is discontinuous
+        cx = (x - A.lon_min) * A.sx;
+        cy = (y - A.lat_min) * A.sy;
+    } else {
+        cx = (T(A.nx_f) * (x - A.lon_min)) / A.lon_span;
+        cy = (T(A.ny_f) * (y - A.lat_min)) / A.lat_span;
+    }
     if (ORDER == 3) return sample3<T>(lvl, A.pitch, A.ny_f, A.nx_f, cy, cx);
     return sample1<T, WRAP>(lvl, A.pitch, A.ny_f, A.nx_f, cy, cx);
+}
+
+// y + a*x: fused for float, mul-then-add (numpy's two roundings) for double
+template <typename T>
+__device__ __forceinline__ T axpy(T a, T x, T y) {
+    if (Fast<T>::value) {
+        return fma(a, x, y);
+    } else {
+#pragma clang fp contract(off)
+        const T m = a * x;
+        return y + m;
+    }
 }
 
 template <typename T>
 __device__ __forceinline__ void clamp_position(const AdvectArgs<T> &A, T &x, T &y) {
     // trajectory.py:89-90 -- where(y > y_min, y, y_min): NaN -> y_min (Q8)
-    y = (y > A.y_min) ? y : A.y_min;
-    y = (y < A.y_max) ? y : A.y_max;
+    if (Fast<T>::value) {
+        y = fmin(fmax(y, A.y_min), A.y_max);  // same NaN rule: fmax(NaN, y_min) = y_min
+    } else {
+        y = (y > A.y_min) ? y : A.y_min;
+        y = (y < A.y_max) ? y : A.y_max;
+    }
     if (A.cyclic) {
         // trajectory.py:93-94 (Q7)
         if (!(x > T(-180))) x = pymod180<T>(x);
@@ -206,14 +254,14 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
     for (int s = 0; s < A.nsteps; ++s) {
         const T *nxt = lvl + A.level_elems;
         const Pair<T> e = sample<T, ORDER, WRAP>(lvl, A, x, y);  // trajectory.py:82-84
-        y = y + A.dtcy * e.v;                                    // :86
-        x = x + dtcx * e.u;                                      // :87
+        y = axpy<T>(A.dtcy, e.v, y);                             // :86
+        x = axpy<T>(dtcx, e.u, x);                               // :87
         clamp_position<T>(A, x, y);
         for (int k = 0; k < A.K; ++k) {                          // :100
             const Pair<T> c = sample<T, ORDER, WRAP>(lvl, A, x, y);  // :105,107
             const Pair<T> n = sample<T, ORDER, WRAP>(nxt, A, x, y);  // :106,108
-            y = y + A.hdtcy * ((e.v + T(2) * c.v) - n.v);            // :110
-            x = x + hdtcx * ((e.u + T(2) * c.u) - n.u);              // :112
+            y = axpy<T>(A.hdtcy, (e.v + T(2) * c.v) - n.v, y);       // :110
+            x = axpy<T>(hdtcx, (e.u + T(2) * c.u) - n.u, x);         // :112
             clamp_position<T>(A, x, y);
         }
         if (A.traj_x) {
@@ -225,6 +273,168 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
     A.x_out[idx] = x;
     A.y_out[idx] = y;
 }
+
+// ======================================================================================
+// float fast path (interior rows).  Same algorithm as advect_seed<float,...>; arranged so
+// that one sample position costs the VALU as little as possible, because rocprof shows
+// the fused kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 94 % of SIMD cycles):
+//   * the tap window is located ONCE per position (shared by time levels t and t+1);
+//   * in-range test = one unsigned compare per axis on the float's bits (catches c<0,
+//     c>n-1 and NaN), the exact scipy wrap runs in the rare out-of-range branch;
+//   * index clamp is a float med3, the address is a 24-bit mad off a uniform level base;
+//   * (u,v) pairs are processed as 2-vectors (v_pk_fma_f32).
+// ======================================================================================
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct TapF {
+    unsigned byte_off;  // of the window origin inside one time level
+    float tx, ty;
+};
+
+__device__ __forceinline__ TapF locate_wrap_f(const AdvectArgs<float> &A, float x, float y, unsigned origin_bytes) {
+    float cx = (x - A.lon_min) * A.sx;  // subtract first: exact at the grid origin
+    float cy = (y - A.lat_min) * A.sy;
+    const float szx = (float)(A.nx_f - 1), szy = (float)(A.ny_f - 1);
+    if ((unsigned)(__float_as_uint(cx) > __float_as_uint(szx)) | (unsigned)(__float_as_uint(cy) > __float_as_uint(szy))) {
+        cx = wrap_coord<float>(cx, szx);
+        cy = wrap_coord<float>(cy, szy);
+    }
+    float fx = floorf(cx), fy = floorf(cy);
+    TapF t;
+    t.tx = cx - fx;
+    t.ty = cy - fy;
+    fx = __builtin_amdgcn_fmed3f(fx, 0.0f, szx);  // memory safety (NaN -> 0)
+    fy = __builtin_amdgcn_fmed3f(fy, 0.0f, szy);
+    const unsigned x0 = (unsigned)(int)fx, y0 = (unsigned)(int)fy;
+    t.byte_off = (__umul24(y0, (unsigned)A.pitch) + x0) * 8u + origin_bytes;
+    return t;
+}
+
+__device__ __forceinline__ f2 fetch1_f(const float *__restrict__ lvl, const TapF &t, unsigned row_bytes) {
+    const char *p = (const char *)lvl + t.byte_off;
+    f4 a, b;
+    __builtin_memcpy(&a, p, 16);              // {u00, v00, u01, v01}
+    __builtin_memcpy(&b, p + row_bytes, 16);  // {u10, v10, u11, v11}
+    const f2 r0 = a.xy + t.tx * (a.zw - a.xy);
+    const f2 r1 = b.xy + t.tx * (b.zw - b.xy);
+    return r0 + t.ty * (r1 - r0);
+}
+
+__device__ __forceinline__ void cubic_weights_f(float t, float w[4]) {
+    const float z = 1.0f - t, s = 1.0f / 6.0f;
+    w[0] = z * z * z * s;
+    w[1] = (t * t * (t - 2.0f) * 3.0f + 4.0f) * s;
+    w[2] = (z * z * (z - 2.0f) * 3.0f + 4.0f) * s;
+    w[3] = 1.0f - w[0] - w[1] - w[2];
+}
+
+__device__ __forceinline__ f2 fetch3_f(const float *__restrict__ lvl, const TapF &t, unsigned row_bytes,
+                                       const float wx[4], const float wy[4]) {
+    const char *p = (const char *)lvl + t.byte_off;
+    f2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        f4 lo, hi;
+        __builtin_memcpy(&lo, p + a * row_bytes, 16);
+        __builtin_memcpy(&hi, p + a * row_bytes + 16, 16);
+        const f2 r = wx[0] * lo.xy + wx[1] * lo.zw + wx[2] * hi.xy + wx[3] * hi.zw;
+        acc += wy[a] * r;
+    }
+    return acc;
+}
+
+template <int ORDER>
+__device__ __forceinline__ f2 fetch_f(const float *__restrict__ lvl, const TapF &t, unsigned row_bytes,
+                                      const float wx[4], const float wy[4]) {
+    if (ORDER == 3) return fetch3_f(lvl, t, row_bytes, wx, wy);
+    return fetch1_f(lvl, t, row_bytes);
+}
+
+__device__ __forceinline__ void clamp_position_f(const AdvectArgs<float> &A, float &x, float &y) {
+    y = fminf(fmaxf(y, A.y_min), A.y_max);  // trajectory.py:89-90; fmax(NaN, y_min) = y_min (Q8)
+    if (A.cyclic) {
+        if (!(fabsf(x) < 180.0f)) {  // rare: the exact reference sequence, trajectory.py:93-94 (Q7)
+            if (!(x > -180.0f)) x = pymod180<float>(x);
+            if (!(x < 180.0f)) x = -180.0f + pymod180<float>(x);
+        }
+    } else {
+        x = x < A.x_min ? A.x_min : x;  // NaN stays NaN, as in the reference
+        x = x > A.x_max ? A.x_max : x;
+    }
+}
+
+template <int ORDER>
+__device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
+#pragma clang fp contract(fast)
+    float x = A.seed_lon[ix];
+    float y = A.seed_lat[iy];
+    const float cx_conv =
+        180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((y * (float)3.141592653589793) / 180.0f)));
+    const float dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
+    const size_t idx = (size_t)iy * A.nx + ix;
+    const size_t plane = (size_t)A.ny * A.nx;
+    const unsigned row_bytes = (unsigned)A.pitch * 8u;
+    const unsigned origin = ORDER == 3 ? 0u : row_bytes + 8u;  // order 3 window starts one node up/left
+    if (A.traj_x) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    const float *elv = A.ext ? A.ext + (size_t)A.t0 * A.level_elems : nullptr;
+    float wx[4], wy[4];
+    for (int s = 0; s < A.nsteps; ++s) {
+        const float *nxt = lvl + A.level_elems;
+        TapF t = locate_wrap_f(A, x, y, origin);
+        if (ORDER == 3) {
+            cubic_weights_f(t.tx, wx);
+            cubic_weights_f(t.ty, wy);
+        }
+        const f2 e = fetch_f<ORDER>(lvl, t, row_bytes, wx, wy);
+        y = fmaf(A.dtcy, e.y, y);
+        x = fmaf(dtcx, e.x, x);
+        clamp_position_f(A, x, y);
+        for (int k = 0; k < A.K; ++k) {
+            t = locate_wrap_f(A, x, y, origin);
+            if (ORDER == 3) {
+                cubic_weights_f(t.tx, wx);
+                cubic_weights_f(t.ty, wy);
+            }
+            f2 d;
+            if (elv) {  // uniform branch: one gather of (2 F[t] - F[t+1])
+                d = e + fetch_f<ORDER>(elv, t, row_bytes, wx, wy);
+            } else {
+                const f2 c = fetch_f<ORDER>(lvl, t, row_bytes, wx, wy);
+                const f2 n = fetch_f<ORDER>(nxt, t, row_bytes, wx, wy);
+                d = (e + 2.0f * c) - n;
+            }
+            y = fmaf(A.hdtcy, d.y, y);
+            x = fmaf(hdtcx, d.x, x);
+            clamp_position_f(A, x, y);
+        }
+        if (A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl = nxt;
+        if (elv) elv += A.level_elems;
+    }
+    A.x_out[idx] = x;
+    A.y_out[idx] = y;
+}
+
+template <typename T, int ORDER>
+struct InteriorPath {
+    static __device__ __forceinline__ void run(const AdvectArgs<T> &A, int iy, int ix) {
+        advect_seed<T, ORDER, true>(A, A.img, iy, ix);
+    }
+};
+template <int ORDER>
+struct InteriorPath<float, ORDER> {
+    static __device__ __forceinline__ void run(const AdvectArgs<float> &A, int iy, int ix) {
+        advect_seed_f32<ORDER>(A, iy, ix);
+    }
+};
 
 template <typename T, int ORDER>
 __global__ void __launch_bounds__(BLOCK) advect_kernel(const AdvectArgs<T> A) {
@@ -242,17 +452,19 @@ __global__ void __launch_bounds__(BLOCK) advect_kernel(const AdvectArgs<T> A) {
     if (pole)
         advect_seed<T, 1, false>(A, A.lin, iy, ix);
     else
-        advect_seed<T, ORDER, true>(A, A.img, iy, ix);
+        InteriorPath<T, ORDER>::run(A, iy, ix);
 }
 
 template <typename T>
-int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int nt, int ny_f, int nx_f,
+int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *packed_ext, int nt, int ny_f,
+                int nx_f,
                 double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
                 int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y) {
     AdvectArgs<T> A;
     A.lin = (const T *)packed_lin;
     A.img = (order == 3) ? (const T *)packed_cub : (const T *)packed_lin;
+    A.ext = (const T *)packed_ext;
     A.level_elems = lc_level_elems(ny_f, nx_f);
     A.pitch = nx_f + LC_PAD;
     A.ny_f = ny_f;
@@ -261,6 +473,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int
     A.lon_min = (T)lon_min;
     A.lat_span = (T)lat_max - (T)lat_min;
     A.lon_span = (T)lon_max - (T)lon_min;
+    set_fast_transform(A);
     A.y_min = (T)lat_min;
     A.y_max = (T)lat_max;
     A.x_min = (T)lon_min;
@@ -331,6 +544,7 @@ int sample_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int
     A.lon_min = (T)lon_min;
     A.lat_span = (T)lat_max - (T)lat_min;
     A.lon_span = (T)lon_max - (T)lon_min;
+    set_fast_transform(A);
     A.ny = ny;
     A.nx = nx;
     A.row0 = row0;
@@ -373,8 +587,8 @@ extern "C" int lc_sample(lc_ctx *ctx, const void *packed_lin, const void *packed
                                pos_x_dev, pos_y_dev, ny, nx, row0, ny_global, interp_order, out_u, out_v);
 }
 
-extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype, int nt, int ny_f,
-                         int nx_f, double lat_min, double lat_max, double lon_min, double lon_max,
+extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *packed_ext,
+                         int dtype, int nt, int ny_f, int nx_f, double lat_min, double lat_max, double lon_min, double lon_max,
                          const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx, int row0, int ny_global,
                          double timestep, int settls_order, int interp_order, int cyclic_x, int t0, int nsteps,
                          void *x_out, void *y_out, void *traj_x, void *traj_y) {
@@ -399,10 +613,10 @@ extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed
     LC_REQUIRE(lat_max > lat_min && lon_max > lon_min, "lc_advect: field coordinates must be ascending");
     LC_HIP_CHECK(hipSetDevice(ctx->device));
     if (dtype == LC_F32)
-        return advect_impl<float>(ctx, packed_lin, packed_cub, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
+        return advect_impl<float>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
                                   seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                   interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y);
-    return advect_impl<double>(ctx, packed_lin, packed_cub, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
+    return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
                                seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y);
 }

@@ -128,6 +128,16 @@ extern "C" int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, 
     return lc_launch_pack(ctx, u_dev, v_dev, dtype, nt, ny_f, nx_f, interp_order, packed_dev);
 }
 
+extern "C" int lc_field_extrapolate(lc_ctx *ctx, const void *packed_dev, int dtype, int nt, int ny_f, int nx_f,
+                                    void *ext_dev) {
+    LC_REQUIRE(ctx, "lc_field_extrapolate: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_field_extrapolate: bad dtype %d", dtype);
+    LC_REQUIRE(packed_dev && ext_dev && packed_dev != ext_dev, "lc_field_extrapolate: bad pointers");
+    LC_REQUIRE(nt >= 2 && ny_f >= 4 && nx_f >= 4, "lc_field_extrapolate: field too small");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    return lc_launch_extrapolate(ctx, packed_dev, dtype, nt, ny_f, nx_f, ext_dev);
+}
+
 // ---------------------------------------------------------------------------
 // Gaussian smoothing (LCS/LCS.py:187-190 -> scipy.ndimage.gaussian_filter defaults:
 // truncate=4.0, mode='reflect', axis 0 then axis 1, output dtype = input dtype,
@@ -283,7 +293,7 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     const double dlat = dtype == LC_F32 ? (double)((float)s_lat1 - (float)s_lat0) : s_lat1 - s_lat0;
     const double dlon = dtype == LC_F32 ? (double)((float)s_lon1 - (float)s_lon0) : s_lon1 - s_lon0;
 
-    DevBuf u, v, lin, cub, slat, slon, x, y, tx, ty, sig, gx, gy, gtmp;
+    DevBuf u, v, lin, cub, ext, slat, slon, x, y, tx, ty, sig, gx, gy, gtmp;
     LC_TRY(u.alloc(fbytes));
     LC_TRY(v.alloc(fbytes));
     LC_TRY(lin.alloc(pbytes));
@@ -303,7 +313,11 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     LC_HIP_CHECK(hipMemcpyAsync(slon.p, seed_lon_host, nx * es, hipMemcpyHostToDevice, st));
     LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p));
     if (interp_order == 3) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 3, cub.p));
-    LC_TRY(lc_advect(ctx, lin.p, cub.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p,
+    if (dtype == LC_F32 && settls_order > 0) {  // float path: one combined sample per SETTLS iteration
+        LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
+        LC_TRY(lc_field_extrapolate(ctx, interp_order == 3 ? cub.p : lin.p, dtype, nt, ny_f, nx_f, ext.p));
+    }
+    LC_TRY(lc_advect(ctx, lin.p, cub.p, ext.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p,
                      nx, 0, ny, timestep, settls_order, interp_order, cyclic_x, t0, nsteps, x.p, y.p, tx.p, ty.p));
     if (sigma_out) {
         LC_TRY(sig.alloc(sbytes));

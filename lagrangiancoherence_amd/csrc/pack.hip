@@ -128,6 +128,13 @@ __global__ void prefilter_rows_kernel(T *__restrict__ packed, int nt, int ny, in
     prefilter_line<T>(c, 2, nx);
 }
 
+// ext[t] = 2*img[t] - img[t+1] over whole padded levels (linear, so pads stay mirrored)
+template <typename T>
+__global__ void extrapolate_kernel(const T *__restrict__ img, T *__restrict__ ext, size_t level_elems, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        ext[i] = T(2) * img[i] - img[i + level_elems];
+}
+
 template <typename T>
 int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int order, T *packed) {
     const size_t nodes = (size_t)nt * ny * nx;
@@ -150,6 +157,18 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
 }
 
 }  // namespace
+
+int lc_launch_extrapolate(lc_ctx *ctx, const void *img, int dtype, int nt, int ny_f, int nx_f, void *ext) {
+    const size_t le = lc_level_elems(ny_f, nx_f), total = le * (size_t)(nt - 1);
+    if (dtype == LC_F32)
+        hipLaunchKernelGGL(extrapolate_kernel<float>, dim3(8192), dim3(256), 0, ctx->stream, (const float *)img,
+                           (float *)ext, le, total);
+    else
+        hipLaunchKernelGGL(extrapolate_kernel<double>, dim3(8192), dim3(256), 0, ctx->stream, (const double *)img,
+                           (double *)ext, le, total);
+    LC_HIP_CHECK(hipGetLastError());
+    return LC_OK;
+}
 
 int lc_launch_pack(lc_ctx *ctx, const void *u, const void *v, int dtype, int nt, int ny_f, int nx_f, int order,
                    void *packed) {

@@ -41,6 +41,7 @@ class PackedField:
     """Gather-ready image(s) of a wind time series, resident on the device."""
     lin: "torch.Tensor"            # order-1 image, always present
     cub: "torch.Tensor | None"     # order-3 coefficient image
+    ext: "torch.Tensor | None"     # 2*img[t]-img[t+1] of the image matching interp_order (fused SETTLS sample)
     nt: int
     ny_f: int
     nx_f: int
@@ -99,8 +100,13 @@ class Engine:
         return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
     # ------------------------------------------------------------------ field
-    def prepare_field(self, u, v, lat_f, lon_f, interp_order: int = 1, dtype=None) -> PackedField:
-        """Upload (if needed) and pack a wind series.  u, v: (nt, ny_f, nx_f)."""
+    def prepare_field(self, u, v, lat_f, lon_f, interp_order: int = 1, dtype=None, fuse_levels=None) -> PackedField:
+        """Upload (if needed) and pack a wind series.  u, v: (nt, ny_f, nx_f).
+
+        ``fuse_levels``: also build ext[t] = 2 F[t] - F[t+1] so each SETTLS iteration takes one
+        gather instead of two (linear interpolation => same value up to rounding).  Default: on for
+        float32 (which cannot be bit-identical to scipy's double evaluation anyway), off for float64
+        (keeps the reference's operation order)."""
         if interp_order not in (1, 3):
             raise ValueError(f"interp_order {interp_order} unsupported (1 and 3 are implemented; "
                              "0 fails in the reference too, LCS/tools.py:24-30)")
@@ -126,10 +132,17 @@ class Engine:
             cub = self._empty((n,), dtype)
             _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f,
                                                3, self._ptr(cub)), self.lib)
+        ext = None
+        if fuse_levels is None:
+            fuse_levels = dtype == np.dtype(np.float32)
+        if fuse_levels and nt >= 2:
+            ext = self._empty((self.lib.lc_packed_elems(nt - 1, ny_f, nx_f),), dtype)
+            _capi.check(self.lib.lc_field_extrapolate(self.ctx, self._ptr(cub if interp_order == 3 else lin),
+                                                      _NP2LC[dtype], nt, ny_f, nx_f, self._ptr(ext)), self.lib)
         # coordinate extremes in the arithmetic dtype (what .min()/.max() give numpy)
         la = lat_f.astype(dtype)
         lo = lon_f.astype(dtype)
-        return PackedField(lin, cub, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype)
+        return PackedField(lin, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype)
 
     # ------------------------------------------------------------------ K1
     def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
@@ -151,7 +164,8 @@ class Engine:
             ty = self._empty((nsteps + 1, ny, nx), dtype)
         self._use_current_stream()
         _capi.check(self.lib.lc_advect(
-            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order == 3 else None), _NP2LC[dtype],
+            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order == 3 else None),
+            self._ptr(field.ext if (field.cub is not None) == (interp_order == 3) else None), _NP2LC[dtype],
             field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max,
             self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, float(timestep), int(SETTLS_order),
             int(interp_order), int(bool(cyclic_xboundary)), int(t0), nsteps, self._ptr(x), self._ptr(y),

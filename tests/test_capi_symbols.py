@@ -48,7 +48,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.lc_sync(None) == _capi.LC_EINVAL
     assert b"null context" in lib.lc_last_error()
     with pytest.raises(ValueError):
-        _capi.check(lib.lc_advect(None, None, None, 0, 2, 4, 4, 0., 1., 0., 1., None, 1, None, 1, 0, 1,
+        _capi.check(lib.lc_advect(None, None, None, None, 0, 2, 4, 4, 0., 1., 0., 1., None, 1, None, 1, 0, 1,
                                   1.0, 0, 1, 1, 0, 1, None, None, None, None), lib)
 
 
