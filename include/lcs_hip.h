@@ -87,7 +87,9 @@ int lc_memcpy_d2h(lc_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes
  * lc_packed_elems() = number of dtype elements the image needs.            */
 size_t lc_packed_elems(int nt, int ny_f, int nx_f);
 int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype,
-                  int nt, int ny_f, int nx_f, int interp_order, void *packed_dev);
+                  int nt, int ny_f, int nx_f, int interp_order, void *packed_dev,
+                  void *ext_dev /* NULL, or lc_packed_elems(nt-1,..): also build the
+                                   lc_field_extrapolate image of this order in the same call */);
 
 /* Optional third image for the SETTLS iterations: ext[t] = 2*packed[t] - packed[t+1],
  * t = 0..nt-2 (same layout, nt-1 levels).  Interpolation is linear in the field, so

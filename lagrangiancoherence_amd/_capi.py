@@ -31,7 +31,7 @@ PROTOTYPES = {
     "lc_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "lc_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "lc_packed_elems": (_sz, [_i, _i, _i]),
-    "lc_field_pack": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "lc_field_pack": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lc_field_extrapolate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lc_advect": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i,
                        _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

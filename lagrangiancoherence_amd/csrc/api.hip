@@ -114,7 +114,7 @@ extern "C" size_t lc_packed_elems(int nt, int ny_f, int nx_f) {
 }
 
 extern "C" int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype, int nt, int ny_f, int nx_f,
-                             int interp_order, void *packed_dev) {
+                             int interp_order, void *packed_dev, void *ext_dev) {
     LC_REQUIRE(ctx, "lc_field_pack: null context");
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_field_pack: bad dtype %d", dtype);
     LC_REQUIRE(u_dev && v_dev && packed_dev, "lc_field_pack: null pointer");
@@ -125,7 +125,8 @@ extern "C" int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, 
         return LC_EUNSUPPORTED;
     }
     LC_HIP_CHECK(hipSetDevice(ctx->device));
-    return lc_launch_pack(ctx, u_dev, v_dev, dtype, nt, ny_f, nx_f, interp_order, packed_dev);
+    LC_REQUIRE(ext_dev != packed_dev, "lc_field_pack: ext_dev must not alias packed_dev");
+    return lc_launch_pack(ctx, u_dev, v_dev, dtype, nt, ny_f, nx_f, interp_order, packed_dev, ext_dev);
 }
 
 extern "C" int lc_field_extrapolate(lc_ctx *ctx, const void *packed_dev, int dtype, int nt, int ny_f, int nx_f,
@@ -311,12 +312,10 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     LC_HIP_CHECK(hipMemcpyAsync(v.p, v_host, fbytes, hipMemcpyHostToDevice, st));
     LC_HIP_CHECK(hipMemcpyAsync(slat.p, seed_lat_host, ny * es, hipMemcpyHostToDevice, st));
     LC_HIP_CHECK(hipMemcpyAsync(slon.p, seed_lon_host, nx * es, hipMemcpyHostToDevice, st));
-    LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p));
-    if (interp_order == 3) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 3, cub.p));
-    if (dtype == LC_F32 && settls_order > 0) {  // float path: one combined sample per SETTLS iteration
-        LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
-        LC_TRY(lc_field_extrapolate(ctx, interp_order == 3 ? cub.p : lin.p, dtype, nt, ny_f, nx_f, ext.p));
-    }
+    // float path: one combined sample per SETTLS iteration (ext image of the matching order)
+    if (dtype == LC_F32 && settls_order > 0) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
+    LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
+    if (interp_order == 3) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 3, cub.p, ext.p));
     LC_TRY(lc_advect(ctx, lin.p, cub.p, ext.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p,
                      nx, 0, ny, timestep, settls_order, interp_order, cyclic_x, t0, nsteps, x.p, y.p, tx.p, ty.p));
     if (sigma_out) {

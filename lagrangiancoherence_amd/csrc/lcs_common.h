@@ -44,5 +44,5 @@ static inline size_t lc_level_elems(int ny_f, int nx_f) {
 
 // kernel launchers implemented in the .hip files
 int lc_launch_pack(lc_ctx *ctx, const void *u, const void *v, int dtype, int nt, int ny_f, int nx_f,
-                   int order, void *packed);
+                   int order, void *packed, void *ext);
 int lc_launch_extrapolate(lc_ctx *ctx, const void *img, int dtype, int nt, int ny_f, int nx_f, void *ext);

@@ -128,6 +128,32 @@ __global__ void prefilter_rows_kernel(T *__restrict__ packed, int nt, int ny, in
     prefilter_line<T>(c, 2, nx);
 }
 
+// Order 1 in one pass over the PADDED image: every node (pads included) reads its mirrored
+// source once and writes lin[t] and, when asked, ext[t] = 2 F[t] - F[t+1].
+template <typename T>
+__global__ void pack_fused_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ lin,
+                                  T *__restrict__ ext, int nt, int ny, int nx) {
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch;
+    const size_t plane = (size_t)ny * nx;
+    const size_t total = level * nt;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / level;
+        const size_t r = i - t * level;
+        const int py = (int)(r / pitch);
+        const int px = (int)(r - (size_t)py * pitch);
+        const int sy = mirror_index(py - LC_PAD_LO, ny), sx = mirror_index(px - LC_PAD_LO, nx);
+        const size_t src = t * plane + (size_t)sy * nx + sx;
+        const T a = u[src], b = v[src];
+        lin[2 * i] = a;
+        lin[2 * i + 1] = b;
+        if (ext && t + 1 < (size_t)nt) {
+            ext[2 * i] = T(2) * a - u[src + plane];
+            ext[2 * i + 1] = T(2) * b - v[src + plane];
+        }
+    }
+}
+
 // ext[t] = 2*img[t] - img[t+1] over whole padded levels (linear, so pads stay mirrored)
 template <typename T>
 __global__ void extrapolate_kernel(const T *__restrict__ img, T *__restrict__ ext, size_t level_elems, size_t total) {
@@ -136,9 +162,15 @@ __global__ void extrapolate_kernel(const T *__restrict__ img, T *__restrict__ ex
 }
 
 template <typename T>
-int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int order, T *packed) {
+int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int order, T *packed, T *ext) {
     const size_t nodes = (size_t)nt * ny * nx;
     const int threads = 256;
+    if (order == 1) {
+        hipLaunchKernelGGL(pack_fused_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, u, v, packed, ext, nt, ny,
+                           nx);
+        LC_HIP_CHECK(hipGetLastError());
+        return LC_OK;
+    }
     const int blocks = (int)((nodes + threads - 1) / threads < 8192 ? (nodes + threads - 1) / threads : 8192);
     hipLaunchKernelGGL(pack_interior_kernel<T>, dim3(blocks), dim3(threads), 0, ctx->stream, u, v, packed, ny, nx,
                        nodes);
@@ -152,6 +184,11 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
                            packed, nt, ny, nx);
     }
     hipLaunchKernelGGL(fill_pads_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
+    if (ext && nt >= 2) {
+        const size_t le = lc_level_elems(ny, nx), total = le * (size_t)(nt - 1);
+        hipLaunchKernelGGL(extrapolate_kernel<T>, dim3(8192), dim3(256), 0, ctx->stream, (const T *)packed, ext, le,
+                           total);
+    }
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }
@@ -171,8 +208,10 @@ int lc_launch_extrapolate(lc_ctx *ctx, const void *img, int dtype, int nt, int n
 }
 
 int lc_launch_pack(lc_ctx *ctx, const void *u, const void *v, int dtype, int nt, int ny_f, int nx_f, int order,
-                   void *packed) {
+                   void *packed, void *ext) {
     if (dtype == LC_F32)
-        return pack_impl<float>(ctx, (const float *)u, (const float *)v, nt, ny_f, nx_f, order, (float *)packed);
-    return pack_impl<double>(ctx, (const double *)u, (const double *)v, nt, ny_f, nx_f, order, (double *)packed);
+        return pack_impl<float>(ctx, (const float *)u, (const float *)v, nt, ny_f, nx_f, order, (float *)packed,
+                                (float *)ext);
+    return pack_impl<double>(ctx, (const double *)u, (const double *)v, nt, ny_f, nx_f, order, (double *)packed,
+                             (double *)ext);
 }

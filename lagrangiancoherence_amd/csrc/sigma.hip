@@ -136,6 +136,125 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel(const SigmaArgs<T> A) {
     }
 }
 
+// ======================================================================================
+// float fast path of K3.  The float result cannot be bit-identical to the reference
+// (numpy float32 sin/cos, LAPACK sgesdd) anyway, so this instantiation spends as few VALU
+// cycles per cell as it can: bounded-argument sincos (Cody-Waite by pi/2 + cephes
+// minimax polynomials, ~1 ulp), float stencil with the 4th-order weights folded
+// (2/3, -1/12), reciprocal metrics per row, float closed form.  Tile 64 x 32 outputs per
+// 256 threads: halo redundancy (68*36)/(64*32) = 1.195.
+// ======================================================================================
+constexpr int FW = 64, FH = 32;
+constexpr int FLW = FW + 2 * HALO, FLH = FH + 2 * HALO;
+
+__device__ __forceinline__ void fast_sincosf(float a, float *sn, float *cs) {
+    if (!(fabsf(a) < 64.0f)) {  // out of the bounded range (or NaN): library path
+        sincosf(a, sn, cs);
+        return;
+    }
+    const float n = rintf(a * 0.636619772367581343f);  // 2/pi
+    float r = fmaf(n, -1.5703125f, a);
+    r = fmaf(n, -4.837512969970703125e-4f, r);
+    r = fmaf(n, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                          z * z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)n;
+    const float s1 = (q & 1) ? cp : sp, c1 = (q & 1) ? sp : cp;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+__global__ void __launch_bounds__(SBLOCK) sigma_kernel_f32(const SigmaArgs<float> A) {
+    __shared__ float sX[FLH][FLW + 1];
+    __shared__ float sY[FLH][FLW + 1];
+    __shared__ float sZ[FLH][FLW + 1];
+    __shared__ float s_inv_dx[FH];
+    const int ntx = (A.nx + FW - 1) / FW;
+    const int tyi = blockIdx.x / ntx, txi = blockIdx.x - tyi * ntx;
+    const int gy0 = A.out_row0 + tyi * FH;
+    const int gx0 = txi * FW;
+    const float D2R = 3.141592653589793f / 180.0f;
+    const float R = 6371000.0f;
+
+    if (threadIdx.x < FH) {
+        const int gy = gy0 + (int)threadIdx.x;
+        float v = 0.0f;
+        if (gy < A.out_row0 + A.n_out_rows) {
+            const float latr = (A.seed_lat[gy - A.in_row0] * 3.141592653589793f) / 180.0f;  // tools.py:254
+            v = 1.0f / ((((3.141592653589793f / 180.0f) * A.dlon) * R) * cosf(latr));      // tools.py:255
+        }
+        s_inv_dx[threadIdx.x] = v;
+    }
+    for (int i = threadIdx.x; i < FLW * FLH; i += SBLOCK) {
+        const int ly = i / FLW, lx = i - ly * FLW;
+        const int gy = gy0 - HALO + ly;
+        int gx = gx0 - HALO + lx;
+        gx = gx < 0 ? gx + A.nx : (gx >= A.nx ? gx - A.nx : gx);
+        if (gx < 0 || gx >= A.nx) {  // grids narrower than the tile: general modulo
+            gx %= A.nx;
+            if (gx < 0) gx += A.nx;
+        }
+        const int ry = gy - A.in_row0;
+        float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+        if (gy >= 0 && gy < A.ny_global && ry >= 0 && ry < A.n_in_rows) {
+            const size_t o = (size_t)ry * A.nx + gx;
+            const float lon = A.x_dep[o] * D2R;             // LCS.py:195
+            const float lat = (A.y_dep[o] - 90.0f) * D2R;   // LCS.py:196
+            float sl, cl, so, co;
+            fast_sincosf(lat, &sl, &cl);
+            fast_sincosf(lon, &so, &co);
+            const float rs = R * sl;
+            vx = rs * co;  // LCS.py:197
+            vy = rs * so;  // LCS.py:198
+            vz = R * cl;   // LCS.py:199
+        }
+        sX[ly][lx] = vx;
+        sY[ly][lx] = vy;
+        sZ[ly][lx] = vz;
+    }
+    __syncthreads();
+
+    const float inv_dy = 1.0f / (((3.141592653589793f / 180.0f) * A.dlat) * R);  // tools.py:256
+    const float W1 = 2.0f / 3.0f, W2 = -1.0f / 12.0f;  // (4/3)/2 and -(1/3)/4 of tools.py:204-207
+    for (int i = threadIdx.x; i < FW * FH; i += SBLOCK) {
+        const int oy = i / FW, ox = i - oy * FW;
+        const int gy = gy0 + oy, gx = gx0 + ox;
+        if (gy >= A.out_row0 + A.n_out_rows || gx >= A.nx) continue;
+        const int ly = oy + HALO, lx = ox + HALO;
+        const float inv_dx = s_inv_dx[oy];
+        auto ddx = [&](float(*a)[FLW + 1]) -> float {
+            return fmaf(W1, a[ly][lx + 1] - a[ly][lx - 1], W2 * (a[ly][lx + 2] - a[ly][lx - 2])) * inv_dx;
+        };
+        auto ddy = [&](float(*a)[FLW + 1]) -> float {
+            float d;
+            if (gy < 2)
+                d = 0.5f * (a[ly + 1][lx] - a[ly][lx]);  // tools.py:210-213
+            else if (gy >= A.ny_global - 2)
+                d = 0.5f * (a[ly][lx] - a[ly - 1][lx]);  // tools.py:214-217
+            else
+                d = fmaf(W1, a[ly + 1][lx] - a[ly - 1][lx], W2 * (a[ly + 2][lx] - a[ly - 2][lx]));
+            return d * inv_dy;
+        };
+        const float a_ = ddx(sX), b_ = ddy(sX), c_ = ddx(sY), d_ = ddy(sY), e_ = ddx(sZ), f_ = ddy(sZ);
+        const size_t oidx = (size_t)(gy - A.out_row0) * A.nx + gx;
+        float p, q, r;
+        if (A.layout == LC_LAYOUT_REFERENCE) {  // LCS.py:153 (Q13)
+            p = a_ * a_ + b_ * b_ + c_ * c_;
+            q = d_ * d_ + e_ * e_ + f_ * f_;
+            r = a_ * d_ + b_ * e_ + c_ * f_;
+        } else {
+            p = a_ * a_ + c_ * c_ + e_ * e_;
+            q = b_ * b_ + d_ * d_ + f_ * f_;
+            r = a_ * b_ + c_ * d_ + e_ * f_;
+        }
+        const float dpq = p - q;
+        const float disc = sqrtf(fmaf(dpq, dpq, 4.0f * r * r));
+        A.sigma[oidx] = sqrtf(0.5f * ((p + q) + disc));
+    }
+}
+
 template <typename T>
 int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, int n_in_rows, int nx, int ny_global,
                const void *seed_lat, double dlat, double dlon, int fd_fp32_cast, int layout, int out_row0,
@@ -155,6 +274,14 @@ int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, i
     A.n_out_rows = n_out_rows;
     A.sigma = (T *)sigma_out;
     A.tensor = (T *)tensor_out;
+    if constexpr (sizeof(T) == 4) {
+        if (!tensor_out) {  // float, sigma only: the fast kernel
+            const int fx = (nx + FW - 1) / FW, fy = (n_out_rows + FH - 1) / FH;
+            hipLaunchKernelGGL(sigma_kernel_f32, dim3(fx * fy), dim3(SBLOCK), 0, ctx->stream, A);
+            LC_HIP_CHECK(hipGetLastError());
+            return LC_OK;
+        }
+    }
     const int ntx = (nx + SW - 1) / SW, nty = (n_out_rows + SH - 1) / SH;
     if (fd_fp32_cast || sizeof(T) == 4)
         hipLaunchKernelGGL((sigma_kernel<T, float>), dim3(ntx * nty), dim3(SBLOCK), 0, ctx->stream, A);

@@ -124,21 +124,19 @@ class Engine:
         vd = self.to_device(v, dtype)
         n = self.lib.lc_packed_elems(nt, ny_f, nx_f)
         self._use_current_stream()
+        if fuse_levels is None:
+            fuse_levels = dtype == np.dtype(np.float32)
+        ext = None
+        if fuse_levels and nt >= 2:
+            ext = self._empty((self.lib.lc_packed_elems(nt - 1, ny_f, nx_f),), dtype)
         lin = self._empty((n,), dtype)
         _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f, 1,
-                                           self._ptr(lin)), self.lib)
+                                           self._ptr(lin), self._ptr(ext if interp_order == 1 else None)), self.lib)
         cub = None
         if interp_order == 3:
             cub = self._empty((n,), dtype)
             _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f,
-                                               3, self._ptr(cub)), self.lib)
-        ext = None
-        if fuse_levels is None:
-            fuse_levels = dtype == np.dtype(np.float32)
-        if fuse_levels and nt >= 2:
-            ext = self._empty((self.lib.lc_packed_elems(nt - 1, ny_f, nx_f),), dtype)
-            _capi.check(self.lib.lc_field_extrapolate(self.ctx, self._ptr(cub if interp_order == 3 else lin),
-                                                      _NP2LC[dtype], nt, ny_f, nx_f, self._ptr(ext)), self.lib)
+                                               3, self._ptr(cub), self._ptr(ext)), self.lib)
         # coordinate extremes in the arithmetic dtype (what .min()/.max() give numpy)
         la = lat_f.astype(dtype)
         lo = lon_f.astype(dtype)
