@@ -20,6 +20,8 @@
 // the 2x2 (order 1) or 4x4 (order 3) tap window of a wrapped coordinate is
 // always in range and its (u,v) pairs are contiguous along x, so one sample
 // position costs 2 (order 1, float) wide loads per level instead of 8 scalars.
+#include <cstdlib>
+
 #include "lcs_common.h"
 
 namespace {
@@ -423,6 +425,247 @@ __device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
     A.y_out[idx] = y;
 }
 
+// ======================================================================================
+// LDS-staged variant of the float path (used when the fused-level image ext is given).
+//
+// rocprof on the direct-gather kernel: TCP_TOTAL_CACHE_ACCESSES ~ 1 per CU-cycle, ~27 tag
+// lookups per 16-byte gather instruction -- the vector L1's lookup rate, not HBM, not the
+// VALU, bounds it.  A wave's 64 seeds (16 x 4 patch) sit within a few field cells of each
+// other and a SETTLS sub-step moves them a fraction of a cell, so the K iterations of one
+// time level read from a window of ext[t] a few nodes wide.  Per time level each WAVE:
+//   1. takes the Euler sample from global memory (positions known only now) and locates
+//      iteration 0's tap;
+//   2. predicts the node range the K iterations will touch from the Euler displacement,
+//      reduces it across the wave (packed 16-bit min/max through shuffles);
+//   3. copies that range of ext[t] (<= 16 rows x 32 nodes) into its own LDS tile with
+//      coalesced row loads;
+//   4. runs the K iterations reading windows with ds_read2_b64; a lane whose window falls
+//      outside the tile (jets, polar rows, the +-180 seam) falls back to the global gather.
+// Tiles are per wave, so there is no workgroup barrier anywhere (LDS operations of one wave
+// execute in order) and waves of a block drift freely.  Same arithmetic as the direct-gather
+// float path; only the memory the window is read from differs.
+// ======================================================================================
+constexpr int LT_COLS = 32;             // tile width in nodes
+constexpr int LT_ROWS = 16;             // tile height
+constexpr int LT_PITCH = LT_COLS + 1;   // +1 node: rows start on different banks
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+struct TapL {
+    int wx0, wy0;  // window origin, padded node coordinates
+    float tx, ty;
+};
+
+template <int ORDER>
+__device__ __forceinline__ TapL locate_wrap_l(const AdvectArgs<float> &A, float x, float y, float &cx_out,
+                                              float &cy_out) {
+    float cx = (x - A.lon_min) * A.sx;
+    float cy = (y - A.lat_min) * A.sy;
+    const float szx = (float)(A.nx_f - 1), szy = (float)(A.ny_f - 1);
+    if ((unsigned)(__float_as_uint(cx) > __float_as_uint(szx)) | (unsigned)(__float_as_uint(cy) > __float_as_uint(szy))) {
+        cx = wrap_coord<float>(cx, szx);
+        cy = wrap_coord<float>(cy, szy);
+    }
+    cx_out = cx;
+    cy_out = cy;
+    float fx = floorf(cx), fy = floorf(cy);
+    TapL t;
+    t.tx = cx - fx;
+    t.ty = cy - fy;
+    fx = __builtin_amdgcn_fmed3f(fx, 0.0f, szx);
+    fy = __builtin_amdgcn_fmed3f(fy, 0.0f, szy);
+    // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that
+    t.wx0 = (int)fx + (ORDER == 3 ? 0 : LC_PAD_LO);
+    t.wy0 = (int)fy + (ORDER == 3 ? 0 : LC_PAD_LO);
+    return t;
+}
+
+__device__ __forceinline__ s2 wave_min_s2(s2 v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int o = __shfl_xor(__builtin_bit_cast(int, v), m, 64);
+        v = __builtin_elementwise_min(v, __builtin_bit_cast(s2, o));
+    }
+    return v;
+}
+__device__ __forceinline__ s2 wave_max_s2(s2 v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int o = __shfl_xor(__builtin_bit_cast(int, v), m, 64);
+        v = __builtin_elementwise_max(v, __builtin_bit_cast(s2, o));
+    }
+    return v;
+}
+
+template <int ORDER>
+__device__ __forceinline__ f2 window_global(const float *__restrict__ lvl, const AdvectArgs<float> &A, const TapL &t,
+                                            const float wx[4], const float wy[4]) {
+    TapF g;
+    g.byte_off = (__umul24((unsigned)t.wy0, (unsigned)A.pitch) + (unsigned)t.wx0) * 8u;
+    g.tx = t.tx;
+    g.ty = t.ty;
+    return fetch_f<ORDER>(lvl, g, (unsigned)A.pitch * 8u, wx, wy);
+}
+
+template <int ORDER>
+__device__ __forceinline__ f2 window_lds(const f2 *__restrict__ tile, int rx, int ry, const TapL &t, const float wx[4],
+                                         const float wy[4]) {
+    const f2 *p = tile + ry * LT_PITCH + rx;
+    if (ORDER == 1) {
+        const f2 n00 = p[0], n01 = p[1], n10 = p[LT_PITCH], n11 = p[LT_PITCH + 1];
+        const f2 r0 = n00 + t.tx * (n01 - n00);
+        const f2 r1 = n10 + t.tx * (n11 - n10);
+        return r0 + t.ty * (r1 - r0);
+    }
+    f2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const f2 *q = p + a * LT_PITCH;
+        const f2 r = wx[0] * q[0] + wx[1] * q[1] + wx[2] * q[2] + wx[3] * q[3];
+        acc += wy[a] * r;
+    }
+    return acc;
+}
+
+template <int ORDER>
+__global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<float> A) {
+#pragma clang fp contract(fast)
+    __shared__ f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
+    const int per_xcd = (A.ntiles + 7) / 8;
+    const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile_id >= A.ntiles) return;  // whole block
+    const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
+    const int ix = txi * TILE_W + (threadIdx.x % TILE_W);
+    const int iy = tyi * TILE_H + (threadIdx.x / TILE_W);
+    const int lane = threadIdx.x & 63;
+    f2 *tile = s_tiles[threadIdx.x >> 6];
+    constexpr int WIN = ORDER + 1;  // window edge in nodes
+
+    bool live = ix < A.nx && iy < A.ny;
+    if (live) {
+        const int grow = A.row0 + iy;
+        if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path, whole integration (Q3)
+            advect_seed<float, 1, false>(A, A.lin, iy, ix);
+            live = false;
+        }
+    }
+    // From here on every lane of the wave runs the loop (dead lanes predicated off), because the
+    // wave-wide reductions below must see all 64 lanes.
+    float x = 0.0f, y = 0.0f, dtcx = 0.0f, hdtcx = 0.0f;
+    const size_t idx = live ? (size_t)iy * A.nx + ix : 0;
+    const size_t plane = (size_t)A.ny * A.nx;
+    if (live) {
+        x = A.seed_lon[ix];
+        y = A.seed_lat[iy];
+        const float cx_conv =
+            180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((y * (float)3.141592653589793) / 180.0f)));
+        dtcx = A.dt * cx_conv;
+        hdtcx = A.half_dt * cx_conv;
+        if (A.traj_x) {
+            A.traj_x[idx] = x;
+            A.traj_y[idx] = y;
+        }
+    }
+    const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    float wx[4], wy[4];
+    for (int s = 0; s < A.nsteps; ++s) {
+        // ---- 1. Euler sample (global) and iteration 0's tap ---------------------------------
+        float cx0 = 0.0f, cy0 = 0.0f, cx1 = 0.0f, cy1 = 0.0f;
+        f2 e = {0.0f, 0.0f};
+        TapL t = {0, 0, 0.0f, 0.0f};
+        if (live) {
+            t = locate_wrap_l<ORDER>(A, x, y, cx0, cy0);
+            if (ORDER == 3) {
+                cubic_weights_f(t.tx, wx);
+                cubic_weights_f(t.ty, wy);
+            }
+            e = window_global<ORDER>(lvl, A, t, wx, wy);
+            y = fmaf(A.dtcy, e.y, y);
+            x = fmaf(dtcx, e.x, x);
+            clamp_position_f(A, x, y);
+            t = locate_wrap_l<ORDER>(A, x, y, cx1, cy1);
+        }
+        // ---- 2. node range of the K iterations, predicted from the Euler displacement ---------
+        // every iteration moves a parcel by about the Euler displacement (Q4); 25 % slack + 1 node
+        const float kx = (float)(A.K > 0 ? A.K - 1 : 0) * 1.25f;
+        const float ddx = (cx1 - cx0) * kx, ddy = (cy1 - cy0) * kx;
+        const bool predictable = live && fabsf(ddx) < (float)(LT_COLS - WIN - 2) && fabsf(ddy) < (float)(LT_ROWS - WIN - 2);
+        int lo_x = 32767, lo_y = 32767, hi_x = -32768, hi_y = -32768;
+        if (predictable) {
+            const int ex = t.wx0 + (int)floorf(ddx + (ddx < 0.0f ? -1.0f : 1.0f));
+            const int ey = t.wy0 + (int)floorf(ddy + (ddy < 0.0f ? -1.0f : 1.0f));
+            lo_x = max(min(t.wx0, ex), 0);
+            lo_y = max(min(t.wy0, ey), 0);
+            hi_x = min(max(t.wx0, ex) + WIN - 1, pad_cols - 1);
+            hi_y = min(max(t.wy0, ey) + WIN - 1, pad_rows - 1);
+        }
+        s2 lo = {(short)lo_x, (short)lo_y}, hi = {(short)hi_x, (short)hi_y};
+        lo = wave_min_s2(lo);
+        hi = wave_max_s2(hi);
+        const int ox = lo.x, oy = lo.y;
+        const int tw = min((int)hi.x - ox + 1, LT_COLS), th = min((int)hi.y - oy + 1, LT_ROWS);  // <= 0: no tile
+        // ---- 3. stage ext[t][oy .. oy+th) x [ox .. ox+32) into this wave's tile ------------------
+        if (tw > 0 && th > 0 && A.K > 0) {
+            const int c = lane & (LT_COLS - 1), r0 = lane >> 5;  // 2 rows of 32 nodes per pass
+            const unsigned src_c = (unsigned)min(ox + c, pad_cols - 1);
+            for (int r = r0; r < th; r += 2) {
+                const f2 v = *(const f2 *)(elv + ((size_t)__umul24((unsigned)(oy + r), (unsigned)pad_cols) + src_c) * 2);
+                tile[r * LT_PITCH + c] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- 4. K iterations out of LDS -----------------------------------------------------------
+        for (int k = 0; k < A.K; ++k) {
+            if (live) {
+                if (k > 0) {
+                    float ucx, ucy;
+                    t = locate_wrap_l<ORDER>(A, x, y, ucx, ucy);
+                }
+                if (ORDER == 3) {
+                    cubic_weights_f(t.tx, wx);
+                    cubic_weights_f(t.ty, wy);
+                }
+                const int rx = t.wx0 - ox, ry = t.wy0 - oy;
+                f2 w;
+                if (rx >= 0 && ry >= 0 && rx <= tw - WIN && ry <= th - WIN)
+                    w = window_lds<ORDER>(tile, rx, ry, t, wx, wy);
+                else
+                    w = window_global<ORDER>(elv, A, t, wx, wy);
+                const f2 d = e + w;
+                y = fmaf(A.hdtcy, d.y, y);
+                x = fmaf(hdtcx, d.x, x);
+                clamp_position_f(A, x, y);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // tile reads done before the next level overwrites it
+        if (live && A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl += A.level_elems;
+        elv += A.level_elems;
+    }
+    if (live) {
+        A.x_out[idx] = x;
+        A.y_out[idx] = y;
+    }
+}
+
+template <typename T, int ORDER>
+struct LdsLaunch {
+    static bool launch(const AdvectArgs<T> &, int, hipStream_t) { return false; }
+};
+template <int ORDER>
+struct LdsLaunch<float, ORDER> {
+    static bool launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
+        // 16-bit packed min/max in the wave reduction: padded node coordinates must fit a short
+        if (!A.ext || A.nx_f + LC_PAD > 32000 || A.ny_f + LC_PAD > 32000) return false;
+        hipLaunchKernelGGL((advect_lds_kernel<ORDER>), dim3(grid), dim3(BLOCK), 0, st, A);
+        return true;
+    }
+};
+
 template <typename T, int ORDER>
 struct InteriorPath {
     static __device__ __forceinline__ void run(const AdvectArgs<T> &A, int iy, int ix) {
@@ -502,10 +745,20 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     const int nty = (ny + TILE_H - 1) / TILE_H;
     A.ntiles = A.ntx * nty;
     const int grid = ((A.ntiles + 7) / 8) * 8;
-    if (order == 3)
-        hipLaunchKernelGGL((advect_kernel<T, 3>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-    else
-        hipLaunchKernelGGL((advect_kernel<T, 1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+    // Kernel choice (float + fused levels only; measured on MI355X, 4096^2 seeds, 96 steps, K=4):
+    //   order 1: direct gather 11.3 ms, LDS tiles 15.6 ms -- the tile bookkeeping costs more VALU
+    //            issue slots (262 vs 160 instructions per wave-step) than the 8 gathers it removes;
+    //   order 3: direct gather 38.5 ms, LDS tiles 32.4 ms -- 32 gathers per step become LDS reads.
+    // LCS_LDS_TILES=0/1 overrides (profiling).
+    bool use_lds = order == 3;
+    if (const char *ev = getenv("LCS_LDS_TILES")) use_lds = ev[0] == '1';
+    if (order == 3) {
+        if (!(use_lds && LdsLaunch<T, 3>::launch(A, grid, ctx->stream)))
+            hipLaunchKernelGGL((advect_kernel<T, 3>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+    } else {
+        if (!(use_lds && LdsLaunch<T, 1>::launch(A, grid, ctx->stream)))
+            hipLaunchKernelGGL((advect_kernel<T, 1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+    }
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }

@@ -319,3 +319,24 @@ def test_errors(eng):
         eng.advect(f, lat, lon, 3600.0, interp_order=3)    # no coefficient image
     with pytest.raises(ValueError):
         eng.advect(f, lat, lon, 3600.0, interp_order=1, t0=2, nsteps=5)   # runs past the last level
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_lds_tile_and_direct_gather_kernels_agree(eng, order, monkeypatch):
+    """Both float kernels (per-wave LDS tiles / direct gather) on a flow with jets, a seam crossing and
+    polar rows, so the tile fallback paths run; they share the arithmetic, so they must agree to rounding."""
+    u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
+    u = (u * 2.5).astype(np.float32)                  # up to ~170 m/s: windows leave the tiles
+    slat, slon = flows.seed_grid(150, 200, lat, lon)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LCS_LDS_TILES", flag)
+        x, y = eng.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=order)
+        out[flag] = (_np(x).astype(np.float64), _np(y).astype(np.float64))
+    dx = np.abs(out["0"][0] - out["1"][0])
+    dx = np.minimum(dx, np.abs(dx - 360))
+    dy = np.abs(out["0"][1] - out["1"][1])
+    print(f"order {order}: LDS vs direct max |dx| {dx.max():.2e} |dy| {dy.max():.2e}, identical {np.mean(dx == 0):.3f}")
+    assert np.percentile(dx, 99) < 1e-4 and np.percentile(dy, 99) < 1e-4
+    assert dx.max() < 5e-2 and dy.max() < 5e-2
