@@ -340,3 +340,15 @@ def test_lds_tile_and_direct_gather_kernels_agree(eng, order, monkeypatch):
     print(f"order {order}: LDS vs direct max |dx| {dx.max():.2e} |dy| {dy.max():.2e}, identical {np.mean(dx == 0):.3f}")
     assert np.percentile(dx, 99) < 1e-4 and np.percentile(dy, 99) < 1e-4
     assert dx.max() < 5e-2 and dy.max() < 5e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 5e-13), (np.float32, 4e-5)])
+def test_prefilter_wide_rows_lds_kernel(eng, O, dtype, tol):
+    # nx >= 64 takes the LDS-chunked longitude sweep (3 chunks here, ragged last chunk, ragged row block)
+    u, v, lat, lon = _rand_field(61, nt=2, ny=37, nx=150, dtype=dtype, scale=1.0)
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    nt, ny, nx = u.shape
+    img = _np(f.cub).reshape(nt, ny + 3, nx + 3, 2).astype(np.float64)
+    for t in range(nt):
+        np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 0], O.spline_prefilter_mirror(u[t]), atol=tol)
+        np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 1], O.spline_prefilter_mirror(v[t]), atol=tol)
