@@ -37,6 +37,25 @@ def b_adv(K: int, order: int, s_p: int, s_f: int) -> int:
     return 4 * s_p + taps * (2 + 4 * K) * s_f
 
 
+def pmc_traffic(kernel_prefix: str, workload: dict):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summaries (profiles/*/
+    *_pmc_traffic.json, written by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE passes of
+    this same command).  Counters cannot be read from inside the timed run; None if no summary matches."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != workload:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
+                best = (v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +155,9 @@ def main():
     sig_s = ms["sigma"] / 1e3
     sigma_gbps = (ny_local * nx) * 3 * s_p / sig_s / 1e9
 
+    wl = {"seeds": args.seeds, "nt": nt, "order": order, "K": K, "dtype": "f32"}
+    tr_adv = pmc_traffic("advect_", wl) if world == 1 else None
+    tr_sig = pmc_traffic("sigma_kernel", wl) if world == 1 else None
     out = {
         "metric": "particle-timesteps/sec (+ FTLE Mcells/sec) at 4096^2 seeds per GPU",
         "value": value,
@@ -159,9 +181,11 @@ def main():
         "ftle_mcells_per_s": ny_global * nx / sig_s / 1e6,
         "kernel_ms": ms,
         "roofline": {
-            "bound": "hbm", "kernel": "advect_kernel<float,%d>" % order,
+            "bound": "hbm", "kernel": ("advect_lds_kernel<%d>" if order == 3 else "advect_kernel<float,%d>") % order,
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": tr_adv[0] if tr_adv else None,
+            "traffic_source": tr_adv[1] if tr_adv else None,
+            "algorithmic_bytes_per_launch": (ny_local * nx * nsteps) * bytes_pts,
             "algorithmic_bytes_per_particle_timestep": bytes_pts,
             "note": "achieved = B_adv(K,order) x seeds x steps / HIP-event duration of the fused advect launch "
                     "(per GPU); the taps are served from L2/Infinity Cache, so this is an algorithmic, not an "
@@ -169,7 +193,7 @@ def main():
         },
         "roofline_sigma": {
             "bound": "hbm", "kernel": "sigma_kernel<float,float>", "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "traffic": None,
+            "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "traffic": tr_sig[0] if tr_sig else None,
             "algorithmic_bytes_per_cell": 3 * s_p,
         },
     }
