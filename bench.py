@@ -80,9 +80,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # LCS_BENCH_BACKEND=gloo + LCS_BENCH_ONE_GPU=1: rehearsal of the N>1 path with every rank on GPU 0
+    # (RCCL refuses two ranks on one device); the driver's multi-GPU runs use nccl = RCCL over xGMI.
+    backend = os.environ.get("LCS_BENCH_BACKEND", "nccl")
+    if os.environ.get("LCS_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     K, order, nt = args.settls, args.order, args.nt
     nsteps = nt - 1
@@ -97,6 +105,7 @@ def main():
     ud = eng.to_device(u, np.float32)
     vd = eng.to_device(v, np.float32)
     lo, hi = sharded.row_partition(ny_global, world, rank)
+    n_lo, n_hi = sharded.halo_rows(ny_global, lo, hi)
     slat_d = eng.to_device(slat, np.float32)      # seeds resident too: the event brackets hold kernels only
     slon_d = eng.to_device(slon, np.float32)
     dlat, dlon = float(slat[1] - slat[0]), float(slon[1] - slon[0])
@@ -109,9 +118,11 @@ def main():
         marks[0].record()
         field = eng.prepare_field(ud, vd, lat, lon, order)
         marks[1].record()
-        x, y = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo, ny_global=ny_global)
+        x_ext, y_ext = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo,
+                                  ny_global=ny_global, halo=(n_lo, n_hi))
         marks[2].record()
-        x_ext, y_ext, in_row0 = sharded.halo_exchange(x, y, rank, world, ny_global, lo, hi)
+        sharded.halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world)
+        in_row0 = lo - n_lo
         marks[3].record()
         sig = eng.sigma(x_ext, y_ext, slat_d[in_row0:in_row0 + x_ext.shape[0]], dlat, dlon, ny_global=ny_global,
                         in_row0=in_row0, out_row0=lo, n_out_rows=hi - lo)
@@ -137,7 +148,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     for marks in ev_marks:

@@ -144,8 +144,11 @@ class Engine:
 
     # ------------------------------------------------------------------ K1
     def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
-               cyclic_xboundary=True, t0=0, nsteps=None, return_traj=False, row0=0, ny_global=None):
-        """Departure points of the seed rows given.  Returns (x, y[, traj_x, traj_y]) device tensors."""
+               cyclic_xboundary=True, t0=0, nsteps=None, return_traj=False, row0=0, ny_global=None, halo=None):
+        """Departure points of the seed rows given.  Returns (x, y[, traj_x, traj_y]) device tensors.
+
+        ``halo=(n_lo, n_hi)``: return ``(n_lo + ny + n_hi, nx)`` buffers with the results in the middle
+        rows, so a row-sharded caller can receive its neighbours' rows in place (sharded.py)."""
         if interp_order == 3 and field.cub is None:
             raise ValueError("field was prepared for interp_order=1")
         dtype = field.dtype
@@ -154,8 +157,10 @@ class Engine:
         ny, nx = int(slat.numel()), int(slon.numel())
         ny_global = ny if ny_global is None else int(ny_global)
         nsteps = field.nt - 1 - t0 if nsteps is None else int(nsteps)
-        x = self._empty((ny, nx), dtype)
-        y = self._empty((ny, nx), dtype)
+        n_lo, n_hi = halo if halo else (0, 0)
+        x_buf = self._empty((n_lo + ny + n_hi, nx), dtype)
+        y_buf = self._empty((n_lo + ny + n_hi, nx), dtype)
+        x, y = x_buf[n_lo:n_lo + ny], y_buf[n_lo:n_lo + ny]
         tx = ty = None
         if return_traj:
             tx = self._empty((nsteps + 1, ny, nx), dtype)
@@ -168,6 +173,8 @@ class Engine:
             self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, float(timestep), int(SETTLS_order),
             int(interp_order), int(bool(cyclic_xboundary)), int(t0), nsteps, self._ptr(x), self._ptr(y),
             self._ptr(tx), self._ptr(ty)), self.lib)
+        if halo:
+            x, y = x_buf, y_buf
         return (x, y, tx, ty) if return_traj else (x, y)
 
     def sample(self, field: PackedField, pos_x, pos_y, level=0, interp_order=1, row0=0, ny_global=None):

@@ -18,7 +18,8 @@ from __future__ import annotations
 
 HALO = 2  # rows; LCS/tools.py:202-207 (4th-order, +-2 points), SURVEY Q12
 
-__all__ = ["HALO", "row_partition", "halo_rows", "halo_exchange", "ensemble_partition", "sharded_lcs"]
+__all__ = ["HALO", "row_partition", "halo_rows", "halo_exchange", "halo_exchange_into", "ensemble_partition",
+           "sharded_lcs"]
 
 
 def row_partition(ny_global: int, world: int, rank: int):
@@ -44,43 +45,61 @@ def ensemble_partition(n_members: int, world: int, rank: int):
     return list(range(lo, lo + base + (1 if rank < rem else 0)))
 
 
-def halo_exchange(x, y, rank: int, world: int, ny_global: int, lo: int, hi: int, group=None):
-    """Exchange the 2 boundary rows of the local (x_dep, y_dep) block with both neighbours.
-
-    ``x``, ``y``: ``(hi-lo, nx)`` tensors on the backend's device.  Returns
-    ``(x_ext, y_ext, in_row0)``: the block extended by the halo rows received,
-    and the global index of its first row -- the input window ``lc_sigma`` wants.
-    One message per neighbour per direction holds both arrays
-    (2 rows x nx x 2 arrays; 128 KiB at nx=8192 fp32 -- latency-bound on xGMI).
-    """
+def halo_exchange_into(x_ext, y_ext, n_lo: int, n_hi: int, rank: int, world: int, group=None):
+    """In-place halo exchange.  ``x_ext``, ``y_ext``: ``(n_lo + n + n_hi, nx)`` buffers whose middle ``n``
+    rows hold this rank's departure points; the first ``n_lo`` / last ``n_hi`` rows are filled with the
+    neighbours' boundary rows.  One message per neighbour per direction carries both arrays
+    (2 rows x nx x 2 arrays: 64 KiB at nx=4096 fp32 -- latency-bound on xGMI; no collective)."""
     import torch
     import torch.distributed as dist
-    n_lo, n_hi = halo_rows(ny_global, lo, hi)
     if world == 1:
-        return x, y, lo
-    if x.shape[0] < HALO:
+        return
+    n = x_ext.shape[0] - n_lo - n_hi
+    if n < HALO:
         raise ValueError("local block thinner than the halo")
+    # gloo cannot move device tensors: stage the (tiny) messages through the host.  Only used when
+    # rehearsing the N>1 path without RCCL (several ranks on one GPU); nccl sends device memory.
+    via_host = x_ext.is_cuda and dist.get_backend(group) == "gloo"
+
+    def msg(rows):
+        m = torch.stack([x_ext[rows], y_ext[rows]]).contiguous()
+        return m.cpu() if via_host else m
+
     ops, recv_lo, recv_hi = [], None, None
-    if rank > 0:           # previous rank owns the rows just below lo
-        send = torch.stack([x[:HALO], y[:HALO]]).contiguous()
+    if rank > 0:           # previous rank owns the rows just below ours
+        assert n_lo == HALO
+        send = msg(slice(n_lo, n_lo + HALO))
         recv_lo = torch.empty_like(send)
         ops += [dist.P2POp(dist.isend, send, rank - 1, group), dist.P2POp(dist.irecv, recv_lo, rank - 1, group)]
-    if rank < world - 1:   # next rank owns the rows from hi on
-        send2 = torch.stack([x[-HALO:], y[-HALO:]]).contiguous()
+    if rank < world - 1:   # next rank owns the rows above ours
+        assert n_hi == HALO
+        send2 = msg(slice(n_lo + n - HALO, n_lo + n))
         recv_hi = torch.empty_like(send2)
         ops += [dist.P2POp(dist.isend, send2, rank + 1, group), dist.P2POp(dist.irecv, recv_hi, rank + 1, group)]
     for req in dist.batch_isend_irecv(ops):
         req.wait()
-    xs, ys = [x], [y]
     if recv_lo is not None:
-        assert n_lo == HALO
-        xs.insert(0, recv_lo[0])
-        ys.insert(0, recv_lo[1])
+        x_ext[:n_lo].copy_(recv_lo[0])
+        y_ext[:n_lo].copy_(recv_lo[1])
     if recv_hi is not None:
-        assert n_hi == HALO
-        xs.append(recv_hi[0])
-        ys.append(recv_hi[1])
-    return torch.cat(xs), torch.cat(ys), lo - (HALO if recv_lo is not None else 0)
+        x_ext[n_lo + n:].copy_(recv_hi[0])
+        y_ext[n_lo + n:].copy_(recv_hi[1])
+
+
+def halo_exchange(x, y, rank: int, world: int, ny_global: int, lo: int, hi: int, group=None):
+    """Copying form: ``x``, ``y`` are this rank's ``(hi-lo, nx)`` blocks; returns ``(x_ext, y_ext, in_row0)``,
+    the blocks extended by the halo rows received and the global index of their first row -- the
+    input window ``lc_sigma`` wants.  (`sharded_lcs` uses the in-place form and never copies the block.)"""
+    import torch
+    n_lo, n_hi = halo_rows(ny_global, lo, hi)
+    if world == 1:
+        return x, y, lo
+    x_ext = torch.empty((n_lo + x.shape[0] + n_hi, x.shape[1]), dtype=x.dtype, device=x.device)
+    y_ext = torch.empty_like(x_ext)
+    x_ext[n_lo:n_lo + x.shape[0]].copy_(x)
+    y_ext[n_lo:n_lo + y.shape[0]].copy_(y)
+    halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world, group)
+    return x_ext, y_ext, lo - n_lo
 
 
 def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, world: int, SETTLS_order=0,
@@ -105,9 +124,11 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
         in_row0 = a
         x, y = x_ext[n_lo:n_lo + hi - lo], y_ext[n_lo:n_lo + hi - lo]
     else:
-        x, y = engine.advect(field, seed_lat_global[lo:hi], seed_lon, timestep, SETTLS_order, interp_order,
-                             cyclic_xboundary, t0, nsteps, row0=lo, ny_global=nyg)
-        x_ext, y_ext, in_row0 = halo_exchange(x, y, rank, world, nyg, lo, hi, group)
+        x_ext, y_ext = engine.advect(field, seed_lat_global[lo:hi], seed_lon, timestep, SETTLS_order, interp_order,
+                                     cyclic_xboundary, t0, nsteps, row0=lo, ny_global=nyg, halo=(n_lo, n_hi))
+        halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world, group)
+        in_row0 = lo - n_lo
+        x, y = x_ext[n_lo:n_lo + hi - lo], y_ext[n_lo:n_lo + hi - lo]
     dlat = float(seed_lat_global[1] - seed_lat_global[0])
     dlon = float(seed_lon[1] - seed_lon[0])
     sig = engine.sigma(x_ext, y_ext, seed_lat_global[in_row0:in_row0 + x_ext.shape[0]], dlat, dlon, ny_global=nyg,

@@ -32,7 +32,7 @@ class OracleEngine:
         self.slat, self.slon = seed_lat_global, seed_lon
 
     def advect(self, field, seed_lat, seed_lon, timestep, SETTLS_order, interp_order, cyclic, t0, nsteps, row0=0,
-               ny_global=None):
+               ny_global=None, halo=None):
         from oracle import lcs_oracle as O
         u, v, lat, lon = self.args
         assert ny_global == self.slat.size and np.array_equal(seed_lat, self.slat[row0:row0 + len(seed_lat)])
@@ -40,7 +40,12 @@ class OracleEngine:
                                     interp_order=interp_order, cyclic_xboundary=cyclic, seed_lat=self.slat,
                                     seed_lon=self.slon, t0=t0, nsteps=nsteps)
         n = len(seed_lat)
-        return torch.from_numpy(x[row0:row0 + n].copy()), torch.from_numpy(y[row0:row0 + n].copy())
+        n_lo, n_hi = halo if halo else (0, 0)
+        xe = torch.full((n_lo + n + n_hi, x.shape[1]), float("nan"), dtype=torch.float64)
+        ye = torch.full((n_lo + n + n_hi, x.shape[1]), float("nan"), dtype=torch.float64)
+        xe[n_lo:n_lo + n] = torch.from_numpy(x[row0:row0 + n].copy())
+        ye[n_lo:n_lo + n] = torch.from_numpy(y[row0:row0 + n].copy())
+        return xe, ye
 
     def sigma(self, x_ext, y_ext, lat_rows, dlat, dlon, ny_global, in_row0, out_row0, n_out_rows, fd_fp32_cast,
               tensor_layout):
