@@ -56,6 +56,54 @@ def pmc_traffic(kernel_prefix: str, workload: dict):
     return best
 
 
+def run_c2(args, torch, flows, Engine, local_rank):
+    """BASELINE configs[1] on one GPU (a parity config; reported for the float64 path's rate)."""
+    K, order = args.settls, args.order
+    u, v, lat, lon = flows.config2()
+    nt, ny, nx = u.shape
+    eng = Engine(local_rank)
+    ud, vd = eng.to_device(u, np.float64), eng.to_device(v, np.float64)
+    lat_d, lon_d = eng.to_device(lat, np.float64), eng.to_device(lon, np.float64)
+    dlat, dlon = float(lat[1] - lat[0]), float(lon[1] - lon[0])
+
+    def one():
+        m = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        m[0].record()
+        f = eng.prepare_field(ud, vd, lat, lon, order)
+        m[1].record()
+        x, y = eng.advect(f, lat_d, lon_d, -900.0, K, order, True)
+        m[2].record()
+        s = eng.sigma(x, y, lat_d, dlat, dlon)
+        m[3].record()
+        return s, m
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks = []
+    for _ in range(args.steps):
+        s, m = one()
+        marks.append(m)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = {k: float(np.mean([m[i].elapsed_time(m[i + 1]) for m in marks])) for i, k in enumerate(("pack", "advect", "sigma"))}
+    pts = ny * nx * (nt - 1)
+    bytes_pts = b_adv(K, order, 8, 8)
+    ach = pts * bytes_pts / (ms["advect"] / 1e3) / 1e9
+    print(json.dumps({
+        "metric": "particle-timesteps/sec, BASELINE configs[1] (float64)", "value": pts * args.steps / el,
+        "unit": "particle-timesteps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {ny}x{nx} seeds = field nodes, moving ideal vortex, {nt} levels, "
+                               f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order},
+        "kernel_ms": ms,
+        "roofline": {"bound": "hbm", "kernel": "advect_kernel<double,%d>" % order, "achieved": ach,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_particle_timestep": bytes_pts},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +114,9 @@ def main():
     ap.add_argument("--settls", type=int, default=4)
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2"],
+                    help="c3 (default, the headline): 4096^2 seeds on the 720x1440 fp32 flow; "
+                         "c2: BASELINE configs[1], 1024^2 nodes, moving ideal vortex, 200 steps, fp64, N=1 only")
     args = ap.parse_args()
 
     import torch
@@ -92,6 +143,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.workload == "c2":
+        return run_c2(args, torch, flows, Engine, local_rank)
     K, order, nt = args.settls, args.order, args.nt
     nsteps = nt - 1
     ny_local = nx = args.seeds

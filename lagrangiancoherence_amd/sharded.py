@@ -19,7 +19,7 @@ from __future__ import annotations
 HALO = 2  # rows; LCS/tools.py:202-207 (4th-order, +-2 points), SURVEY Q12
 
 __all__ = ["HALO", "row_partition", "halo_rows", "halo_exchange", "halo_exchange_into", "ensemble_partition",
-           "sharded_lcs"]
+           "sharded_lcs", "ensemble_lcs"]
 
 
 def row_partition(ny_global: int, world: int, rank: int):
@@ -135,3 +135,22 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
                        in_row0=in_row0, out_row0=lo, n_out_rows=hi - lo, fd_fp32_cast=fd_fp32_cast,
                        tensor_layout=tensor_layout)
     return {"sigma": sig, "x_dep": x, "y_dep": y, "rows": (lo, hi)}
+
+
+def ensemble_lcs(engine, field, seed_lat, seed_lon, timestep, n_members: int, nsteps: int, rank: int = 0,
+                 world: int = 1, SETTLS_order=0, interp_order=1, cyclic_xboundary=True, fd_fp32_cast=True,
+                 tensor_layout="reference"):
+    """BASELINE config 5: member ``e`` starts at time level ``t0 = e`` and runs ``nsteps`` steps over the
+    same seed grid.  Members are sharded over ranks in contiguous blocks; nothing is exchanged (gathering
+    the sigma fields is the caller's business).  Returns ``(member_indices, sigma[len(members), ny, nx])``."""
+    import torch
+    if n_members - 1 + nsteps > field.nt - 1:
+        raise ValueError(f"{n_members} members x {nsteps} steps need {n_members + nsteps} time levels, have {field.nt}")
+    mine = ensemble_partition(n_members, world, rank)
+    out = []
+    for e in mine:
+        r = engine.lcs(field, seed_lat, seed_lon, timestep, SETTLS_order=SETTLS_order, interp_order=interp_order,
+                       cyclic_xboundary=cyclic_xboundary, t0=e, nsteps=nsteps, fd_fp32_cast=fd_fp32_cast,
+                       tensor_layout=tensor_layout)
+        out.append(r["sigma"])
+    return mine, (torch.stack(out) if out else None)

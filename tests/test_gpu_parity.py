@@ -352,3 +352,25 @@ def test_prefilter_wide_rows_lds_kernel(eng, O, dtype, tol):
     for t in range(nt):
         np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 0], O.spline_prefilter_mirror(u[t]), atol=tol)
         np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 1], O.spline_prefilter_mirror(v[t]), atol=tol)
+
+
+def test_ensemble_members_are_t0_windows(eng, O):
+    # BASELINE config 5 in miniature: member e = the same seeds started at time level e
+    from lagrangiancoherence_amd import sharded
+    u, v, lat, lon = _rand_field(71, nt=9, ny=25, nx=40)
+    slat = np.linspace(lat[0], lat[-1], 30)
+    slon = np.linspace(lon[0], lon[-1], 44)
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    got = {}
+    for rank in range(2):          # two "ranks" in one process: the partition is what is under test
+        mine, sig = sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=5, nsteps=4, rank=rank, world=2,
+                                         SETTLS_order=2, interp_order=1)
+        for e, s in zip(mine, sig):
+            got[e] = _np(s)
+    assert sorted(got) == [0, 1, 2, 3, 4]
+    for e in (0, 3, 4):
+        ref, _, _ = O.lcs(u, v, lat, lon, timestep=-1800.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=True,
+                          seed_lat=slat, seed_lon=slon, t0=e, nsteps=4)
+        np.testing.assert_allclose(got[e], ref, rtol=SIG_RTOL64)
+    with pytest.raises(ValueError):
+        sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=6, nsteps=4)
