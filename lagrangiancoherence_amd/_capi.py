@@ -57,6 +57,13 @@ def load(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # One HIP runtime per process: torch wheels bundle their own ROCm libraries, and loading ours
+    # (linked against /opt/rocm) first leaves the process with two HSA runtimes and "no ROCm-capable
+    # device".  Importing torch first makes our DT_NEEDED entries resolve to the copies torch loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # torch-free hosts use lc_lcs_host only
+        pass
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} is missing: the HIP extension is the only compute path of this package "
