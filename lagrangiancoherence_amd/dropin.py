@@ -14,10 +14,9 @@ HIP library; this file is argument handling only.
 Deliberate differences from the reference (all outside the arithmetic):
   * the unconditional ``print('!'*100)`` and ``print('using s = ...')`` (LCS.py:74,126)
     are not reproduced; ``verbose`` prints the same progress lines;
-  * ``isglobal=True`` with ``interp_to_common_grid=True`` or ``truncation`` set needs the
-    0.5 degree regrid / T20 spectral truncation (windspharm), which are out of scope
-    this round: a clear NotImplementedError is raised instead of
-    silently skipping them;
+  * ``isglobal=True`` runs the 0.5 degree regrid and the T20 spectral truncation on the
+    device (``preprocess.py``); the truncation restates windspharm/SPHEREPACK's published
+    algorithm in float64 and is NOT pinned against pyspharm (not installable here);
   * non-cyclic longitude clamp is per point (the reference's outer-product indexing
     is a defect, SURVEY Q9);
   * mixed float32/float64 inputs are computed in float64 (engine.common_dtype).
@@ -201,22 +200,25 @@ class LCS:
         assert set(u.dims) == {'latitude', 'longitude', timedim}, \
             'array dims should be latitude and longitude only'                             # LCS.py:96
 
+        uu, time, lat, lon = _sorted_tll(u, timedim)                       # LCS.py:101-104
+        vv, _, _, _ = _sorted_tll(v, timedim)
+        eng = get_engine()
         if isglobal:
-            if interp_to_common_grid or truncation is not None:            # LCS.py:106-118
-                raise NotImplementedError(
-                    "isglobal=True with interp_to_common_grid=True or truncation set needs the 0.5-degree "
-                    "regrid and the spherical-harmonic truncation of the reference (LCS/LCS.py:106-118); "
-                    "they are not part of this engine yet. Call with interp_to_common_grid=False, "
-                    "truncation=None to run the advection/FTLE path on the grid as given.")
+            from . import preprocess
+            if interp_to_common_grid:                                      # LCS.py:106-114
+                uu, lat_new, lon_new = preprocess.regrid_common_grid(eng, uu, lat, lon)
+                vv, _, _ = preprocess.regrid_common_grid(eng, vv, lat, lon)
+                lat, lon = lat_new, lon_new
+            if truncation is not None:                                     # LCS.py:115-118
+                preprocess.check_regular_global_lat(lat)
+                uu = preprocess.spectral_truncate(eng, uu, truncation)
+                vv = preprocess.spectral_truncate(eng, vv, truncation)
             cyclic_xboundary = True                                        # LCS.py:119-120
             self.subdomain = None
         else:
             cyclic_xboundary = False
 
         verboseprint("*---- Parcel propagation ----*")
-        uu, time, lat, lon = _sorted_tll(u, timedim)                       # LCS.py:101-104
-        vv, _, _, _ = _sorted_tll(v, timedim)
-        eng = get_engine()
         field = eng.prepare_field(uu, vv, lat, lon, traj_interp_order)
         dtype = field.dtype
         lat_t, lon_t = lat.astype(dtype), lon.astype(dtype)

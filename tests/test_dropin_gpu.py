@@ -95,8 +95,8 @@ def test_dims_assertions_and_unsupported_paths():
         LCS()(u=bad, v=ds.v, verbose=False)
     with pytest.raises(AssertionError, match="array dims should be latitude and longitude only"):
         LCS()(u=bad, v=bad, verbose=False)
-    with pytest.raises(NotImplementedError, match="truncation"):
-        LCS()(ds, isglobal=True, verbose=False)            # default regrid + T20 truncation: not in this engine
+    with pytest.raises(ValueError, match="non-global"):    # windspharm refuses the example's 89-row grid as is
+        LCS()(ds, isglobal=True, interp_to_common_grid=False, verbose=False)
     with pytest.raises(ValueError):
         LCS()(ds, verbose=False, traj_interp_order=0)      # fails in the reference too (tools.py:24-30)
 
@@ -146,3 +146,28 @@ def test_tools_helpers_vs_scipy_and_oracle():
                                                            {'latitude': lat, 'longitude': lon}), dim=dim)
         np.testing.assert_allclose(d.values, O.derivative_spherical_coords(a32.astype(np.float64), lat, lon, dim=dim),
                                    rtol=1e-15)
+
+
+def test_example_default_global_call_with_regrid_and_truncation():
+    """examples/ideal_vortex.py:286-287 exactly as written: ``LCS(...)(ds, isglobal=True)`` -- 0.5 degree regrid,
+    T20 truncation (LCS.py:105-118), cubic interpolation, cyclic; against the oracle's composition of the same."""
+    from LagrangianCoherence.LCS.LCS import LCS
+    from oracle import lcs_oracle as O
+    from oracle import preprocess_oracle as PO
+    ds, times, lat, lon = _dataset()
+    acs = LCS(timestep=-6 * 3600, timedim='time', SETTLS_order=4, return_dpts=True)
+    eig, xd, yd = acs(ds.copy(), isglobal=True, verbose=False)
+    assert eig.shape == (1, 360, 721) and eig['latitude'].values[0] == -89.75 and eig['longitude'].values[-1] == 179.5
+    u, v, _, _ = flows.config1()
+    ur, lats, lons = PO.regrid_common_grid(u, lat, lon)
+    vr, _, _ = PO.regrid_common_grid(v, lat, lon)
+    ut, vt = PO.spectral_truncate(ur, 20), PO.spectral_truncate(vr, 20)
+    s, x, y = O.lcs(ut, vt, lats, lons, timestep=-6 * 3600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
+    np.testing.assert_allclose(xd.values, x, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(yd.values, y, rtol=0, atol=1e-8)
+    # rows at +-89.75 have dx = 240 m, so one float32 rounding flip of X (ulp 0.5 m, Q11) moves a derivative
+    # by 1e-3 of its value: sigma agrees to 1e-5 there, 1e-7 elsewhere
+    np.testing.assert_allclose(eig.values[0], s, rtol=1e-5)
+    np.testing.assert_allclose(eig.values[0][20:-20], s[20:-20], rtol=1e-7)
+    # T20 is a strong low-pass: the 2-degree vortex is smeared out, sigma stays close to the identity map's
+    assert np.isfinite(eig.values).all()
