@@ -187,6 +187,17 @@ int lc_fourth_order_derivative(lc_ctx *ctx, const void *in_dev, int dtype, int n
 int lc_gaussian_filter(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int nx,
                        double sigma, void *tmp_dev, void *out_dev);
 
+/* ---- ridge classification (consumer of the sigma / FTLE field) ---------------------
+ * Replaces the per-point Python loop of tools.find_ridges_spherical_hessian
+ * (LCS/tools.py:99-138): numpy.linalg.eig of the symmetric 2x2 Hessian
+ * [[hxx,hxy],[hxy,hyy]] (inf/NaN entries zeroed), the reference's row-indexed
+ * eigenvector dotted with the gradient, the eigenvalue of largest magnitude, and the
+ * mask (|dot| <= tolerance and that eigenvalue negative).  All arrays [n] doubles on the
+ * device; dt_out (the raw dot product) may be NULL. */
+int lc_ridge_classify(lc_ctx *ctx, const void *hxx, const void *hxy, const void *hyy,
+                      const void *gx, const void *gy, size_t n, double tolerance,
+                      void *mask_out, void *eigmin_out, void *dt_out);
+
 /* ---- one-call host entry point ----------------------------------------------
  * What a reference-side binding would call from LCS.__call__ (LCS/LCS.py:129-157):
  * host arrays in, host arrays out; upload, pack, advect, sigma, download, sync.

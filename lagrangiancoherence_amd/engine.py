@@ -250,6 +250,18 @@ class Engine:
                                                         self._ptr(out)), self.lib)
         return out
 
+    def ridge_classify(self, hxx, hxy, hyy, gx, gy, tolerance):
+        """Per-point step of tools.find_ridges_spherical_hessian (LCS/tools.py:99-138).
+        Returns (mask, eigmin, dt) float64 device tensors shaped like the inputs."""
+        t = [self.to_device(a, np.float64) for a in (hxx, hxy, hyy, gx, gy)]
+        shape = tuple(t[0].shape)
+        n = int(t[0].numel())
+        mask, eigmin, dt = (self._empty(shape, np.float64) for _ in range(3))
+        self._use_current_stream()
+        _capi.check(self.lib.lc_ridge_classify(self.ctx, *(self._ptr(a) for a in t), n, float(tolerance),
+                                               self._ptr(mask), self._ptr(eigmin), self._ptr(dt)), self.lib)
+        return mask, eigmin, dt
+
     def gaussian_filter(self, a, sigma):
         """scipy.ndimage.gaussian_filter(a, sigma) on the device (LCS/LCS.py:187-190)."""
         torch = self.torch

@@ -4,8 +4,10 @@
 * ``derivative_spherical_coords``  LCS/tools.py:248-267
 * ``fourth_order_derivative``      LCS/tools.py:190-245 (plain arrays in the reference)
 
-The other functions of that module (ridge extraction, IDW regridding, latlonsel) are
-not on the advect -> gradient -> sigma path.
+* ``find_ridges_spherical_hessian`` LCS/tools.py:52-155 (the consumer of the FTLE field)
+
+The remaining functions of that module (IDW regridding, harvesine, latlonsel) have no caller on the
+path.
 """
 from __future__ import annotations
 
@@ -14,7 +16,8 @@ import numpy as np
 from .dropin import _coord, _make, _to_np, get_engine
 from .engine import common_dtype
 
-__all__ = ["xr_map_coordinates", "fourth_order_derivative", "derivative_spherical_coords"]
+__all__ = ["xr_map_coordinates", "fourth_order_derivative", "derivative_spherical_coords",
+           "find_ridges_spherical_hessian"]
 
 
 def xr_map_coordinates(da, new_x, new_y, isglobal=True, order=1):
@@ -63,3 +66,46 @@ def derivative_spherical_coords(da, dim=0, isglobal=True):
     deriv = fourth_order_derivative(vals.astype('float32'), dim=dim, isglobal=isglobal)
     deriv = deriv / dy if dim == 0 else deriv / dx[:, None]
     return _make(da, deriv, ("latitude", "longitude"), {"latitude": lat, "longitude": lon}, getattr(da, "name", None))
+
+
+def find_ridges_spherical_hessian(da, sigma=.5, scheme='first_order', tolerance_threshold=0.0005e-3,
+                                  return_eigvectors=False, isglobal=True):
+    """Hessian ridge filter in spherical coordinates.  Signature of LCS/tools.py:52-54.
+
+    Returns ``(ridges, eigmin)`` with the input's dimension order: ``ridges`` is 1 where the reference's
+    gradient/eigenvector product is within ``tolerance_threshold`` and the Hessian eigenvalue of largest
+    magnitude is negative, else 0.  Gaussian smoothing, the five float32-cast 4th-order derivatives and
+    the per-point ``numpy.linalg.eig`` (a Python loop in the reference) all run on the device.
+    ``return_eigvectors=True`` (extra eigenvector / angle arrays) is not provided.
+    """
+    if return_eigvectors:
+        raise NotImplementedError("return_eigvectors=True is not provided (only the ridge mask and eigmin are)")
+    if not isglobal:
+        raise NotImplementedError("only the isglobal=True (cyclic longitude) branch is provided")
+    dims = tuple(da.dims)
+    lat, lon = _coord(da, "latitude"), _coord(da, "longitude")
+    ilat, ilon = np.argsort(lat, kind="stable"), np.argsort(lon, kind="stable")       # tools.py:70-71
+    vals = np.asarray(da.transpose("latitude", "longitude").values, dtype=np.float64)[ilat][:, ilon]
+    lat, lon = lat[ilat], lon[ilon]
+    eng = get_engine()
+    torch = eng.torch
+    a = eng.to_device(vals, np.float64)
+    if isinstance(sigma, (float, int)) and sigma > 1e-15:                              # tools.py:74-75
+        a = eng.gaussian_filter(a, sigma)
+    y = lat * np.pi / 180
+    dx = eng.to_device((np.pi / 180) * (lon[1] - lon[0]) * 6371000 * np.cos(y), np.float64)[:, None]   # tools.py:255
+    dy = (np.pi / 180) * (lat[1] - lat[0]) * 6371000                                   # tools.py:256
+
+    def D(f, dim):   # derivative_spherical_coords: float32 cast, index stencil, metric (tools.py:258-264)
+        d = eng.index_derivative(f.to(torch.float32), dim).to(torch.float64)
+        return d / dy if dim == 0 else d / dx
+    ddadx, ddady = D(a, 1), D(a, 0)                                                    # tools.py:77-78
+    d2x2, d2y2, dxdy = D(ddadx, 1), D(ddady, 0), D(ddadx, 0)                           # tools.py:79-81
+    mask, eigmin, _ = eng.ridge_classify(d2x2, dxdy, d2y2, ddadx, ddady, tolerance_threshold)
+    inv_lat, inv_lon = np.argsort(ilat), np.argsort(ilon)
+
+    def out(t):
+        arr = _to_np(t)
+        o = _make(da, arr, ("latitude", "longitude"), {"latitude": lat, "longitude": lon}, getattr(da, "name", None))
+        return o.transpose(*dims)                                                      # tools.py:150
+    return out(mask), out(eigmin)
