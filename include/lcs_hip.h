@@ -38,7 +38,14 @@ extern "C" {
 
 typedef struct lc_ctx lc_ctx;
 
-enum lc_dtype { LC_F32 = 0, LC_F64 = 1 };
+enum lc_dtype {
+    LC_F32 = 0,
+    LC_F64 = 1,
+    /* lc_advect only: float64 positions and images whose wind values are float32-valued; the
+     * arithmetic follows numpy's promotion for that mix in the reference (samples rounded to float,
+     * latitude increments formed in float; LCS/trajectory.py:86-87,110-112 with SURVEY Q10). */
+    LC_F64_WIND_F32 = 2
+};
 
 enum lc_status {
     LC_OK = 0,

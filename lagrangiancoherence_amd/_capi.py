@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblcs_hip.so")
 
-LC_F32, LC_F64 = 0, 1
+LC_F32, LC_F64, LC_F64_WIND_F32 = 0, 1, 2
 LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM = 0, -1, -2, -3, -4
 LC_LAYOUT_REFERENCE, LC_LAYOUT_PHYSICAL = 0, 1
 

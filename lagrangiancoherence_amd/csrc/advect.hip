@@ -47,6 +47,7 @@ struct AdvectArgs {
     T dt, half_dt;       // T(timestep), T(0.5*timestep)
     T dtcy, hdtcy;       // T(timestep*conversion_y), T((0.5*timestep)*conversion_y)
     int K, order, cyclic, t0, nsteps;
+    int wind_f32;  // double instantiation only: the wind is float32-valued -> numpy's promotion rules (Q10)
     T *x_out, *y_out, *traj_x, *traj_y;
     int ntx, ntiles;
 };
@@ -237,6 +238,28 @@ __device__ __forceinline__ void clamp_position(const AdvectArgs<T> &A, T &x, T &
     }
 }
 
+// float32 wind on float64 coordinates (the reference's behaviour for e.g. float32 reanalysis winds on
+// float64 lat/lon): map_coordinates returns the FIELD's dtype, so samples are float32; python-float *
+// float32-array stays float32, so the latitude increments are formed in float32 and only then added to
+// the float64 position, while conversion_x (a float64 array) promotes the longitude increments to
+// float64 (numpy promotion through trajectory.py:86-87,110-112).  No-ops unless A.wind_f32.
+template <typename T>
+__device__ __forceinline__ T round_sample(const AdvectArgs<T> &A, T v) {
+    return (sizeof(T) == 8 && A.wind_f32) ? (T)(float)v : v;
+}
+template <typename T>
+__device__ __forceinline__ T lat_increment(const AdvectArgs<T> &A, T scale, T vel_or_bracket) {
+#pragma clang fp contract(off)
+    if (sizeof(T) == 8 && A.wind_f32) return (T)((float)scale * (float)vel_or_bracket);
+    return scale * vel_or_bracket;
+}
+template <typename T>
+__device__ __forceinline__ T settls_bracket(const AdvectArgs<T> &A, T e, T c, T n) {
+#pragma clang fp contract(off)
+    if (sizeof(T) == 8 && A.wind_f32) return (T)(((float)e + 2.0f * (float)c) - (float)n);
+    return (e + T(2) * c) - n;
+}
+
 template <typename T, int ORDER, bool WRAP>
 __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image, int iy, int ix) {
 #pragma clang fp contract(off)
@@ -255,15 +278,21 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
     const T *lvl = image + (size_t)A.t0 * A.level_elems;
     for (int s = 0; s < A.nsteps; ++s) {
         const T *nxt = lvl + A.level_elems;
-        const Pair<T> e = sample<T, ORDER, WRAP>(lvl, A, x, y);  // trajectory.py:82-84
-        y = axpy<T>(A.dtcy, e.v, y);                             // :86
+        Pair<T> e = sample<T, ORDER, WRAP>(lvl, A, x, y);        // trajectory.py:82-84
+        e.u = round_sample<T>(A, e.u);
+        e.v = round_sample<T>(A, e.v);
+        y = y + lat_increment<T>(A, A.dtcy, e.v);                // :86
         x = axpy<T>(dtcx, e.u, x);                               // :87
         clamp_position<T>(A, x, y);
         for (int k = 0; k < A.K; ++k) {                          // :100
-            const Pair<T> c = sample<T, ORDER, WRAP>(lvl, A, x, y);  // :105,107
-            const Pair<T> n = sample<T, ORDER, WRAP>(nxt, A, x, y);  // :106,108
-            y = axpy<T>(A.hdtcy, (e.v + T(2) * c.v) - n.v, y);       // :110
-            x = axpy<T>(hdtcx, (e.u + T(2) * c.u) - n.u, x);         // :112
+            Pair<T> c = sample<T, ORDER, WRAP>(lvl, A, x, y);    // :105,107
+            Pair<T> n = sample<T, ORDER, WRAP>(nxt, A, x, y);    // :106,108
+            c.u = round_sample<T>(A, c.u);
+            c.v = round_sample<T>(A, c.v);
+            n.u = round_sample<T>(A, n.u);
+            n.v = round_sample<T>(A, n.v);
+            y = y + lat_increment<T>(A, A.hdtcy, settls_bracket<T>(A, e.v, c.v, n.v));  // :110
+            x = axpy<T>(hdtcx, settls_bracket<T>(A, e.u, c.u, n.u), x);                 // :112
             clamp_position<T>(A, x, y);
         }
         if (A.traj_x) {
@@ -703,8 +732,9 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 int nx_f,
                 double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
-                int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y) {
+                int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, int wind_f32 = 0) {
     AdvectArgs<T> A;
+    A.wind_f32 = wind_f32;
     A.lin = (const T *)packed_lin;
     A.img = (order == 3) ? (const T *)packed_cub : (const T *)packed_lin;
     A.ext = (const T *)packed_ext;
@@ -846,7 +876,8 @@ extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed
                          double timestep, int settls_order, int interp_order, int cyclic_x, int t0, int nsteps,
                          void *x_out, void *y_out, void *traj_x, void *traj_y) {
     LC_REQUIRE(ctx, "lc_advect: null context");
-    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_advect: bad dtype %d", dtype);
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64 || dtype == LC_F64_WIND_F32, "lc_advect: bad dtype %d", dtype);
+    LC_REQUIRE(dtype != LC_F64_WIND_F32 || !packed_ext, "lc_advect: LC_F64_WIND_F32 keeps the two-sample form (no ext)");
     if (interp_order != 1 && interp_order != 3) {
         lc_set_error("lc_advect: interp_order %d unsupported (1 and 3 are implemented; 0 fails in the reference too)",
                      interp_order);
@@ -871,5 +902,6 @@ extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed
                                   interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y);
     return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
                                seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
-                               interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y);
+                               interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y,
+                               dtype == LC_F64_WIND_F32);
 }

@@ -50,6 +50,7 @@ class PackedField:
     lon_min: float
     lon_max: float
     dtype: np.dtype
+    wind_f32: bool = False          # float32 wind on float64 coordinates: numpy's promotion rules in lc_advect
 
 
 class Engine:
@@ -113,6 +114,8 @@ class Engine:
         lat_f = np.asarray(lat_f)
         lon_f = np.asarray(lon_f)
         dtype = np.dtype(dtype or common_dtype(u, v, lat_f, lon_f))
+        f32 = np.dtype(np.float32)
+        wind_f32 = dtype == np.dtype(np.float64) and common_dtype(u, v) == f32 and common_dtype(lat_f, lon_f) != f32
         if tuple(u.shape) != tuple(v.shape) or len(u.shape) != 3:
             raise ValueError("u and v must both be (time, latitude, longitude)")
         nt, ny_f, nx_f = (int(s) for s in u.shape)
@@ -126,6 +129,8 @@ class Engine:
         self._use_current_stream()
         if fuse_levels is None:
             fuse_levels = dtype == np.dtype(np.float32)
+        if wind_f32:
+            fuse_levels = False
         ext = None
         if fuse_levels and nt >= 2:
             ext = self._empty((self.lib.lc_packed_elems(nt - 1, ny_f, nx_f),), dtype)
@@ -140,7 +145,8 @@ class Engine:
         # coordinate extremes in the arithmetic dtype (what .min()/.max() give numpy)
         la = lat_f.astype(dtype)
         lo = lon_f.astype(dtype)
-        return PackedField(lin, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype)
+        return PackedField(lin, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
+                           wind_f32)
 
     # ------------------------------------------------------------------ K1
     def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
@@ -168,8 +174,8 @@ class Engine:
         self._use_current_stream()
         _capi.check(self.lib.lc_advect(
             self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order == 3 else None),
-            self._ptr(field.ext if (field.cub is not None) == (interp_order == 3) else None), _NP2LC[dtype],
-            field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max,
+            self._ptr(field.ext if (field.cub is not None) == (interp_order == 3) else None),
+            _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[dtype], field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max,
             self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, float(timestep), int(SETTLS_order),
             int(interp_order), int(bool(cyclic_xboundary)), int(t0), nsteps, self._ptr(x), self._ptr(y),
             self._ptr(tx), self._ptr(ty)), self.lib)

@@ -374,3 +374,24 @@ def test_ensemble_members_are_t0_windows(eng, O):
         np.testing.assert_allclose(got[e], ref, rtol=SIG_RTOL64)
     with pytest.raises(ValueError):
         sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=6, nsteps=4)
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_float32_wind_on_float64_coordinates_follows_numpy_promotion(eng, O, order):
+    """The reference with float32 winds and float64 lat/lon: samples come back float32 (Q10), latitude
+    increments are formed in float32, longitude increments in float64.  lc_advect's LC_F64_WIND_F32 mode
+    must reproduce that to float64 rounding -- plain float64 arithmetic on the same values does not."""
+    u, v, lat, lon = _rand_field(81, nt=6, ny=27, nx=40)
+    u32, v32 = u.astype(np.float32), v.astype(np.float32)
+    f = eng.prepare_field(u32, v32, lat, lon, order)
+    assert f.dtype == np.float64 and f.wind_f32 and f.ext is None
+    x, y = eng.advect(f, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
+    xr_, yr_ = O.parcel_propagation(u32, v32, lat, lon, timestep=-3600.0, SETTLS_order=3, interp_order=order,
+                                    cyclic_xboundary=True)
+    assert xr_.dtype == np.float64
+    np.testing.assert_allclose(_np(x), xr_, rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(y), yr_, rtol=0, atol=POS_ATOL64)
+    # the same float32-valued wind pushed through pure float64 arithmetic is a different (1e-7-ish) answer
+    f64 = eng.prepare_field(u32.astype(np.float64), v32.astype(np.float64), lat, lon, order)
+    x64, y64 = eng.advect(f64, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
+    assert np.abs(_np(y64) - yr_).max() > 100 * POS_ATOL64
