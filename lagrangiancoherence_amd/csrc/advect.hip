@@ -895,6 +895,12 @@ extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed
     LC_REQUIRE(x_out && y_out, "lc_advect: null output");
     LC_REQUIRE((traj_x == nullptr) == (traj_y == nullptr), "lc_advect: traj_x and traj_y must both be set or both NULL");
     LC_REQUIRE(lat_max > lat_min && lon_max > lon_min, "lc_advect: field coordinates must be ascending");
+    // the kernels address a tap inside one time level with 32-bit offsets (24-bit row multiply)
+    if (lc_level_elems(ny_f, nx_f) * (dtype == LC_F32 ? 4 : 1) >= (size_t)1 << 32 || nx_f + LC_PAD >= (1 << 24) ||
+        ny_f + LC_PAD >= (1 << 24)) {
+        lc_set_error("lc_advect: a %dx%d time level is too large for 32-bit tap offsets", ny_f, nx_f);
+        return LC_EUNSUPPORTED;
+    }
     LC_HIP_CHECK(hipSetDevice(ctx->device));
     if (dtype == LC_F32)
         return advect_impl<float>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
