@@ -458,26 +458,29 @@ __device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
 // LDS-staged variant of the float path (used when the fused-level image ext is given).
 //
 // rocprof on the direct-gather kernel: TCP_TOTAL_CACHE_ACCESSES ~ 1 per CU-cycle, ~27 tag
-// lookups per 16-byte gather instruction -- the vector L1's lookup rate, not HBM, not the
-// VALU, bounds it.  A wave's 64 seeds (16 x 4 patch) sit within a few field cells of each
-// other and a SETTLS sub-step moves them a fraction of a cell, so the K iterations of one
-// time level read from a window of ext[t] a few nodes wide.  Per time level each WAVE:
-//   1. takes the Euler sample from global memory (positions known only now) and locates
-//      iteration 0's tap;
-//   2. predicts the node range the K iterations will touch from the Euler displacement,
-//      reduces it across the wave (packed 16-bit min/max through shuffles);
-//   3. copies that range of ext[t] (<= 16 rows x 32 nodes) into its own LDS tile with
-//      coalesced row loads;
+// lookups per 16-byte gather instruction -- the vector L1's lookup rate, not HBM, bounds it.
+// A wave's 64 seeds (16 x 4 patch) sit within a few field cells of each other and a SETTLS
+// sub-step moves them a fraction of a cell, so the K iterations of one time level read a
+// window of ext[t] a few nodes wide.  Per time level each WAVE:
+//   1. takes the Euler sample from global memory and locates iteration 0's tap;
+//   2. anchors a fixed-size tile (LT_COLS x rows nodes) on the patch's centre lane, shifted half
+//      way along that lane's predicted travel (Euler displacement x (K-1)) -- two v_readlane,
+//      no reduction;
+//   3. copies the tile of ext[t] into its own LDS region with coalesced 16-byte row loads;
 //   4. runs the K iterations reading windows with ds_read2_b64; a lane whose window falls
-//      outside the tile (jets, polar rows, the +-180 seam) falls back to the global gather.
+//      outside the tile (jets, polar rows, the +-180 seam, stretched patches) gathers from
+//      global memory instead.
 // Tiles are per wave, so there is no workgroup barrier anywhere (LDS operations of one wave
 // execute in order) and waves of a block drift freely.  Same arithmetic as the direct-gather
 // float path; only the memory the window is read from differs.
 // ======================================================================================
-constexpr int LT_COLS = 32;             // tile width in nodes
-constexpr int LT_ROWS = 16;             // tile height
-constexpr int LT_PITCH = LT_COLS + 1;   // +1 node: rows start on different banks
-typedef short s2 __attribute__((ext_vector_type(2)));
+constexpr int LT_COLS = 32;            // tile width in nodes (one 256-byte row segment = 16 lanes x 16 B)
+constexpr int LT_PITCH = LT_COLS + 2;  // nodes; 272 B: rows stay 16-byte aligned and shift 4 banks
+
+template <int ORDER>
+struct TileRows {
+    static constexpr int value = ORDER == 3 ? 16 : 8;
+};
 
 struct TapL {
     int wx0, wy0;  // window origin, padded node coordinates
@@ -506,23 +509,6 @@ __device__ __forceinline__ TapL locate_wrap_l(const AdvectArgs<float> &A, float 
     t.wx0 = (int)fx + (ORDER == 3 ? 0 : LC_PAD_LO);
     t.wy0 = (int)fy + (ORDER == 3 ? 0 : LC_PAD_LO);
     return t;
-}
-
-__device__ __forceinline__ s2 wave_min_s2(s2 v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int o = __shfl_xor(__builtin_bit_cast(int, v), m, 64);
-        v = __builtin_elementwise_min(v, __builtin_bit_cast(s2, o));
-    }
-    return v;
-}
-__device__ __forceinline__ s2 wave_max_s2(s2 v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int o = __shfl_xor(__builtin_bit_cast(int, v), m, 64);
-        v = __builtin_elementwise_max(v, __builtin_bit_cast(s2, o));
-    }
-    return v;
 }
 
 template <int ORDER>
@@ -558,7 +544,9 @@ __device__ __forceinline__ f2 window_lds(const f2 *__restrict__ tile, int rx, in
 template <int ORDER>
 __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<float> A) {
 #pragma clang fp contract(fast)
-    __shared__ f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
+    constexpr int LT_ROWS = TileRows<ORDER>::value;
+    constexpr int WIN = ORDER + 1;  // window edge in nodes
+    __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
     const int per_xcd = (A.ntiles + 7) / 8;
     const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile_id >= A.ntiles) return;  // whole block
@@ -567,7 +555,6 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     const int iy = tyi * TILE_H + (threadIdx.x / TILE_W);
     const int lane = threadIdx.x & 63;
     f2 *tile = s_tiles[threadIdx.x >> 6];
-    constexpr int WIN = ORDER + 1;  // window edge in nodes
 
     bool live = ix < A.nx && iy < A.ny;
     if (live) {
@@ -577,8 +564,8 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             live = false;
         }
     }
-    // From here on every lane of the wave runs the loop (dead lanes predicated off), because the
-    // wave-wide reductions below must see all 64 lanes.
+    // From here on every lane of the wave runs the loop (dead lanes predicated off): the staging
+    // below is a whole-wave operation.
     float x = 0.0f, y = 0.0f, dtcx = 0.0f, hdtcx = 0.0f;
     const size_t idx = live ? (size_t)iy * A.nx + ix : 0;
     const size_t plane = (size_t)A.ny * A.nx;
@@ -596,7 +583,10 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     }
     const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
     const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
-    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;  // >= LT_COLS, LT_ROWS (checked by the launcher)
+    const float kpred = 0.5f * (float)(A.K > 0 ? A.K - 1 : 0);  // half of the predicted travel, in Euler displacements
+    // staging geometry of this lane: 4 tile rows per pass, 16 lanes x 16 B per row
+    const int st_row = lane >> 4, st_col = (lane & 15) * 2;
     float wx[4], wy[4];
     for (int s = 0; s < A.nsteps; ++s) {
         // ---- 1. Euler sample (global) and iteration 0's tap ---------------------------------
@@ -615,36 +605,32 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             clamp_position_f(A, x, y);
             t = locate_wrap_l<ORDER>(A, x, y, cx1, cy1);
         }
-        // ---- 2. node range of the K iterations, predicted from the Euler displacement ---------
-        // every iteration moves a parcel by about the Euler displacement (Q4); 25 % slack + 1 node
-        const float kx = (float)(A.K > 0 ? A.K - 1 : 0) * 1.25f;
-        const float ddx = (cx1 - cx0) * kx, ddy = (cy1 - cy0) * kx;
-        const bool predictable = live && fabsf(ddx) < (float)(LT_COLS - WIN - 2) && fabsf(ddy) < (float)(LT_ROWS - WIN - 2);
-        int lo_x = 32767, lo_y = 32767, hi_x = -32768, hi_y = -32768;
-        if (predictable) {
-            const int ex = t.wx0 + (int)floorf(ddx + (ddx < 0.0f ? -1.0f : 1.0f));
-            const int ey = t.wy0 + (int)floorf(ddy + (ddy < 0.0f ? -1.0f : 1.0f));
-            lo_x = max(min(t.wx0, ex), 0);
-            lo_y = max(min(t.wy0, ey), 0);
-            hi_x = min(max(t.wx0, ex) + WIN - 1, pad_cols - 1);
-            hi_y = min(max(t.wy0, ey) + WIN - 1, pad_rows - 1);
+        // ---- 2. anchor the tile on the patch's centre lane (first live lane if that one is dead) ----
+        const unsigned long long alive = __ballot(live);
+        int ox = 0, oy = 0;
+        bool have_tile = alive != 0ull && A.K > 0;
+        if (have_tile) {
+            const int ref = (alive >> 40) & 1ull ? 40 : (int)__ffsll((long long)alive) - 1;
+            // centre of the window's predicted travel: every iteration moves a parcel by about the
+            // Euler displacement (Q4)
+            const int mx = t.wx0 + (int)((cx1 - cx0) * kpred), my = t.wy0 + (int)((cy1 - cy0) * kpred);
+            const int rxm = __builtin_amdgcn_readlane(mx, ref), rym = __builtin_amdgcn_readlane(my, ref);
+            ox = min(max(rxm - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
+            oy = min(max(rym - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
         }
-        s2 lo = {(short)lo_x, (short)lo_y}, hi = {(short)hi_x, (short)hi_y};
-        lo = wave_min_s2(lo);
-        hi = wave_max_s2(hi);
-        const int ox = lo.x, oy = lo.y;
-        const int tw = min((int)hi.x - ox + 1, LT_COLS), th = min((int)hi.y - oy + 1, LT_ROWS);  // <= 0: no tile
-        // ---- 3. stage ext[t][oy .. oy+th) x [ox .. ox+32) into this wave's tile ------------------
-        if (tw > 0 && th > 0 && A.K > 0) {
-            const int c = lane & (LT_COLS - 1), r0 = lane >> 5;  // 2 rows of 32 nodes per pass
-            const unsigned src_c = (unsigned)min(ox + c, pad_cols - 1);
-            for (int r = r0; r < th; r += 2) {
-                const f2 v = *(const f2 *)(elv + ((size_t)__umul24((unsigned)(oy + r), (unsigned)pad_cols) + src_c) * 2);
-                tile[r * LT_PITCH + c] = v;
+        // ---- 3. stage ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) ---------------------------
+        __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
+        if (have_tile) {
+            const float *src = elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)(ox + st_col)) * 2;
+#pragma unroll
+            for (int r = 0; r < LT_ROWS; r += 4) {
+                f4 v;
+                __builtin_memcpy(&v, src + (size_t)(r + st_row) * pad_cols * 2, 16);
+                *(f4 *)(tile + (r + st_row) * LT_PITCH + st_col) = v;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- 4. K iterations out of LDS -----------------------------------------------------------
+        // ---- 4. K iterations out of LDS (global gather for lanes whose window left the tile) ------
         for (int k = 0; k < A.K; ++k) {
             if (live) {
                 if (k > 0) {
@@ -657,7 +643,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
                 }
                 const int rx = t.wx0 - ox, ry = t.wy0 - oy;
                 f2 w;
-                if (rx >= 0 && ry >= 0 && rx <= tw - WIN && ry <= th - WIN)
+                if (have_tile && (unsigned)rx <= (unsigned)(LT_COLS - WIN) && (unsigned)ry <= (unsigned)(LT_ROWS - WIN))
                     w = window_lds<ORDER>(tile, rx, ry, t, wx, wy);
                 else
                     w = window_global<ORDER>(elv, A, t, wx, wy);
@@ -667,7 +653,6 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
                 clamp_position_f(A, x, y);
             }
         }
-        __builtin_amdgcn_wave_barrier();  // tile reads done before the next level overwrites it
         if (live && A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = x;
             A.traj_y[(size_t)(s + 1) * plane + idx] = y;
@@ -688,8 +673,8 @@ struct LdsLaunch {
 template <int ORDER>
 struct LdsLaunch<float, ORDER> {
     static bool launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
-        // 16-bit packed min/max in the wave reduction: padded node coordinates must fit a short
-        if (!A.ext || A.nx_f + LC_PAD > 32000 || A.ny_f + LC_PAD > 32000) return false;
+        // the fixed-size tile must fit inside one padded time level
+        if (!A.ext || A.nx_f + LC_PAD < LT_COLS || A.ny_f + LC_PAD < TileRows<ORDER>::value) return false;
         hipLaunchKernelGGL((advect_lds_kernel<ORDER>), dim3(grid), dim3(BLOCK), 0, st, A);
         return true;
     }
@@ -776,9 +761,9 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.ntiles = A.ntx * nty;
     const int grid = ((A.ntiles + 7) / 8) * 8;
     // Kernel choice (float + fused levels only; measured on MI355X, 4096^2 seeds, 96 steps, K=4):
-    //   order 1: direct gather 11.3 ms, LDS tiles 15.6 ms -- the tile bookkeeping costs more VALU
-    //            issue slots (262 vs 160 instructions per wave-step) than the 8 gathers it removes;
-    //   order 3: direct gather 38.5 ms, LDS tiles 32.4 ms -- 32 gathers per step become LDS reads.
+    //   order 1: direct gather 11.3 ms (vector-L1 lookup bound, 160 VALU instr per wave-timestep),
+    //            LDS tiles 11.45 ms (VALU-issue bound at 213) -- a wash, the simpler kernel stays default;
+    //   order 3: direct gather 38.5 ms, LDS tiles 25.0 ms -- 32 gathers per timestep become LDS reads.
     // LCS_LDS_TILES=0/1 overrides (profiling).
     bool use_lds = order == 3;
     if (const char *ev = getenv("LCS_LDS_TILES")) use_lds = ev[0] == '1';
