@@ -331,13 +331,13 @@ __device__ __forceinline__ TapF locate_wrap_f(const AdvectArgs<float> &A, float 
         cx = wrap_coord<float>(cx, szx);
         cy = wrap_coord<float>(cy, szy);
     }
-    float fx = floorf(cx), fy = floorf(cy);
+    // floor-convert + fract: one instruction each (v_cvt_flr_i32_f32, v_fract_f32).  The coordinate is
+    // non-negative here; the unsigned min is memory safety (NaN converts to 0, garbage saturates).
     TapF t;
-    t.tx = cx - fx;
-    t.ty = cy - fy;
-    fx = __builtin_amdgcn_fmed3f(fx, 0.0f, szx);  // memory safety (NaN -> 0)
-    fy = __builtin_amdgcn_fmed3f(fy, 0.0f, szy);
-    const unsigned x0 = (unsigned)(int)fx, y0 = (unsigned)(int)fy;
+    t.tx = __builtin_amdgcn_fractf(cx);
+    t.ty = __builtin_amdgcn_fractf(cy);
+    const unsigned x0 = min((unsigned)__float2int_rd(cx), (unsigned)(A.nx_f - 1));
+    const unsigned y0 = min((unsigned)__float2int_rd(cy), (unsigned)(A.ny_f - 1));
     t.byte_off = (__umul24(y0, (unsigned)A.pitch) + x0) * 8u + origin_bytes;
     return t;
 }
@@ -499,15 +499,14 @@ __device__ __forceinline__ TapL locate_wrap_l(const AdvectArgs<float> &A, float 
     }
     cx_out = cx;
     cy_out = cy;
-    float fx = floorf(cx), fy = floorf(cy);
     TapL t;
-    t.tx = cx - fx;
-    t.ty = cy - fy;
-    fx = __builtin_amdgcn_fmed3f(fx, 0.0f, szx);
-    fy = __builtin_amdgcn_fmed3f(fy, 0.0f, szy);
+    t.tx = __builtin_amdgcn_fractf(cx);
+    t.ty = __builtin_amdgcn_fractf(cy);
+    const unsigned x0 = min((unsigned)__float2int_rd(cx), (unsigned)(A.nx_f - 1));
+    const unsigned y0 = min((unsigned)__float2int_rd(cy), (unsigned)(A.ny_f - 1));
     // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that
-    t.wx0 = (int)fx + (ORDER == 3 ? 0 : LC_PAD_LO);
-    t.wy0 = (int)fy + (ORDER == 3 ? 0 : LC_PAD_LO);
+    t.wx0 = (int)x0 + (ORDER == 3 ? 0 : LC_PAD_LO);
+    t.wy0 = (int)y0 + (ORDER == 3 ? 0 : LC_PAD_LO);
     return t;
 }
 
