@@ -26,8 +26,11 @@
 
 namespace {
 
-constexpr int TILE_W = 16;
-constexpr int TILE_H = 16;
+// 8 x 32 seeds per workgroup: each wave owns an 8 x 8 patch.  Measured on C3 (ms, direct kernel):
+// 64x4 17.9, 32x8 12.6, 16x16 11.2, 8x32 10.9, 4x64 10.85, 2x128 11.1, 1x256 13.5 -- compact patches
+// touch the fewest distinct cache lines per gather.
+constexpr int TILE_W = 8;
+constexpr int TILE_H = 32;
 constexpr int BLOCK = TILE_W * TILE_H;
 
 template <typename T>
@@ -459,11 +462,11 @@ __device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
 //
 // rocprof on the direct-gather kernel: TCP_TOTAL_CACHE_ACCESSES ~ 1 per CU-cycle, ~27 tag
 // lookups per 16-byte gather instruction -- the vector L1's lookup rate, not HBM, bounds it.
-// A wave's 64 seeds (16 x 4 patch) sit within a few field cells of each other and a SETTLS
+// A wave's 64 seeds (8 x 8 patch) sit within a few field cells of each other and a SETTLS
 // sub-step moves them a fraction of a cell, so the K iterations of one time level read a
 // window of ext[t] a few nodes wide.  Per time level each WAVE:
 //   1. takes the Euler sample from global memory and locates iteration 0's tap;
-//   2. anchors a fixed-size tile (LT_COLS x rows nodes) on the patch's centre lane, shifted half
+//   2. anchors a fixed-size tile (TileGeom<ORDER> nodes) on the patch's centre lane, shifted half
 //      way along that lane's predicted travel (Euler displacement x (K-1)) -- two v_readlane,
 //      no reduction;
 //   3. copies the tile of ext[t] into its own LDS region with coalesced 16-byte row loads;
@@ -474,12 +477,15 @@ __device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
 // execute in order) and waves of a block drift freely.  Same arithmetic as the direct-gather
 // float path; only the memory the window is read from differs.
 // ======================================================================================
-constexpr int LT_COLS = 32;            // tile width in nodes (one 256-byte row segment = 16 lanes x 16 B)
-constexpr int LT_PITCH = LT_COLS + 2;  // nodes; 272 B: rows stay 16-byte aligned and shift 4 banks
-
+// Tile geometry per interpolation order (nodes).  Measured on C3 with 8x8-seed waves (ms):
+//   order 1: 16x4 11.9, 16x8 10.2, 16x16 10.2, 32x8 10.6     order 3: 16x8 22.7, 16x16 21.2, 32x8 24.3, 32x16 20.4
 template <int ORDER>
-struct TileRows {
-    static constexpr int value = ORDER == 3 ? 16 : 8;
+struct TileGeom {
+    static constexpr int COLS = ORDER == 3 ? 32 : 16;   // one row = COLS/2 lanes x 16 B
+    static constexpr int ROWS = ORDER == 3 ? 16 : 8;
+    static constexpr int PITCH = COLS + 2;              // rows stay 16-byte aligned and shift 4 banks
+    static constexpr int LANES_PER_ROW = COLS / 2;
+    static constexpr int ROWS_PER_PASS = 64 / LANES_PER_ROW;
 };
 
 struct TapL {
@@ -523,6 +529,7 @@ __device__ __forceinline__ f2 window_global(const float *__restrict__ lvl, const
 template <int ORDER>
 __device__ __forceinline__ f2 window_lds(const f2 *__restrict__ tile, int rx, int ry, const TapL &t, const float wx[4],
                                          const float wy[4]) {
+    constexpr int LT_PITCH = TileGeom<ORDER>::PITCH;
     const f2 *p = tile + ry * LT_PITCH + rx;
     if (ORDER == 1) {
         const f2 n00 = p[0], n01 = p[1], n10 = p[LT_PITCH], n11 = p[LT_PITCH + 1];
@@ -543,7 +550,8 @@ __device__ __forceinline__ f2 window_lds(const f2 *__restrict__ tile, int rx, in
 template <int ORDER>
 __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<float> A) {
 #pragma clang fp contract(fast)
-    constexpr int LT_ROWS = TileRows<ORDER>::value;
+    typedef TileGeom<ORDER> G;
+    constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
     constexpr int WIN = ORDER + 1;  // window edge in nodes
     __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
     const int per_xcd = (A.ntiles + 7) / 8;
@@ -584,8 +592,8 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;  // >= LT_COLS, LT_ROWS (checked by the launcher)
     const float kpred = 0.5f * (float)(A.K > 0 ? A.K - 1 : 0);  // half of the predicted travel, in Euler displacements
-    // staging geometry of this lane: 4 tile rows per pass, 16 lanes x 16 B per row
-    const int st_row = lane >> 4, st_col = (lane & 15) * 2;
+    // staging geometry of this lane: ROWS_PER_PASS tile rows per pass, 16 B (2 nodes) per lane
+    const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
     float wx[4], wy[4];
     for (int s = 0; s < A.nsteps; ++s) {
         // ---- 1. Euler sample (global) and iteration 0's tap ---------------------------------
@@ -607,9 +615,10 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
         // ---- 2. anchor the tile on the patch's centre lane (first live lane if that one is dead) ----
         const unsigned long long alive = __ballot(live);
         int ox = 0, oy = 0;
-        bool have_tile = alive != 0ull && A.K > 0;
+        const bool have_tile = alive != 0ull && A.K > 0;
         if (have_tile) {
-            const int ref = (alive >> 40) & 1ull ? 40 : (int)__ffsll((long long)alive) - 1;
+            constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
+            const int ref = (alive >> CENTRE) & 1ull ? CENTRE : (int)__ffsll((long long)alive) - 1;
             // centre of the window's predicted travel: every iteration moves a parcel by about the
             // Euler displacement (Q4)
             const int mx = t.wx0 + (int)((cx1 - cx0) * kpred), my = t.wy0 + (int)((cy1 - cy0) * kpred);
@@ -622,7 +631,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
         if (have_tile) {
             const float *src = elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)(ox + st_col)) * 2;
 #pragma unroll
-            for (int r = 0; r < LT_ROWS; r += 4) {
+            for (int r = 0; r < LT_ROWS; r += G::ROWS_PER_PASS) {
                 f4 v;
                 __builtin_memcpy(&v, src + (size_t)(r + st_row) * pad_cols * 2, 16);
                 *(f4 *)(tile + (r + st_row) * LT_PITCH + st_col) = v;
@@ -641,8 +650,10 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
                     cubic_weights_f(t.ty, wy);
                 }
                 const int rx = t.wx0 - ox, ry = t.wy0 - oy;
+                const bool inside =
+                    have_tile && (unsigned)rx <= (unsigned)(LT_COLS - WIN) && (unsigned)ry <= (unsigned)(LT_ROWS - WIN);
                 f2 w;
-                if (have_tile && (unsigned)rx <= (unsigned)(LT_COLS - WIN) && (unsigned)ry <= (unsigned)(LT_ROWS - WIN))
+                if (inside)
                     w = window_lds<ORDER>(tile, rx, ry, t, wx, wy);
                 else
                     w = window_global<ORDER>(elv, A, t, wx, wy);
@@ -673,7 +684,7 @@ template <int ORDER>
 struct LdsLaunch<float, ORDER> {
     static bool launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
         // the fixed-size tile must fit inside one padded time level
-        if (!A.ext || A.nx_f + LC_PAD < LT_COLS || A.ny_f + LC_PAD < TileRows<ORDER>::value) return false;
+        if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return false;
         hipLaunchKernelGGL((advect_lds_kernel<ORDER>), dim3(grid), dim3(BLOCK), 0, st, A);
         return true;
     }
@@ -759,12 +770,15 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     const int nty = (ny + TILE_H - 1) / TILE_H;
     A.ntiles = A.ntx * nty;
     const int grid = ((A.ntiles + 7) / 8) * 8;
-    // Kernel choice (float + fused levels only; measured on MI355X, 4096^2 seeds, 96 steps, K=4):
-    //   order 1: direct gather 11.3 ms (vector-L1 lookup bound, 160 VALU instr per wave-timestep),
-    //            LDS tiles 11.45 ms (VALU-issue bound at 213) -- a wash, the simpler kernel stays default;
-    //   order 3: direct gather 38.5 ms, LDS tiles 25.0 ms -- 32 gathers per timestep become LDS reads.
+    // Kernel choice (float + fused levels only; measured on MI355X, 4096^2 seeds, 96 steps, K=4, 8x8-seed waves):
+    //   order 1: direct gather 10.9 ms (vector-L1 lookup bound), LDS tiles 10.2 ms (VALU-issue bound);
+    //   order 3: direct gather 37.8 ms, LDS tiles 20.4 ms.
+    // With the wind scaled x4 / x10 (patches stretched far beyond a tile) the LDS kernel degrades to
+    // 10.7-11.9 ms against 11.0 for direct gathers: its global-gather fallback is per lane, so the worst
+    // case costs the tile bookkeeping only.  An adaptive "skip the tile when most lanes miss" vote was
+    // measured and dropped (it costs 5 % everywhere to save 8 % in that extreme).
     // LCS_LDS_TILES=0/1 overrides (profiling).
-    bool use_lds = order == 3;
+    bool use_lds = true;
     if (const char *ev = getenv("LCS_LDS_TILES")) use_lds = ev[0] == '1';
     if (order == 3) {
         if (!(use_lds && LdsLaunch<T, 3>::launch(A, grid, ctx->stream)))
