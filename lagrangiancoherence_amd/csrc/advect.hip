@@ -326,6 +326,13 @@ struct TapF {
     float tx, ty;
 };
 
+// floor(x) as an integer in ONE instruction (the compiler expands __float2int_rd to v_floor + v_cvt)
+__device__ __forceinline__ unsigned floor_to_uint(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return (unsigned)r;
+}
+
 __device__ __forceinline__ TapF locate_wrap_f(const AdvectArgs<float> &A, float x, float y, unsigned origin_bytes) {
     float cx = (x - A.lon_min) * A.sx;  // subtract first: exact at the grid origin
     float cy = (y - A.lat_min) * A.sy;
@@ -339,8 +346,8 @@ __device__ __forceinline__ TapF locate_wrap_f(const AdvectArgs<float> &A, float 
     TapF t;
     t.tx = __builtin_amdgcn_fractf(cx);
     t.ty = __builtin_amdgcn_fractf(cy);
-    const unsigned x0 = min((unsigned)__float2int_rd(cx), (unsigned)(A.nx_f - 1));
-    const unsigned y0 = min((unsigned)__float2int_rd(cy), (unsigned)(A.ny_f - 1));
+    const unsigned x0 = min(floor_to_uint(cx), (unsigned)(A.nx_f - 1));
+    const unsigned y0 = min(floor_to_uint(cy), (unsigned)(A.ny_f - 1));
     t.byte_off = (__umul24(y0, (unsigned)A.pitch) + x0) * 8u + origin_bytes;
     return t;
 }
@@ -386,7 +393,8 @@ __device__ __forceinline__ f2 fetch_f(const float *__restrict__ lvl, const TapF 
 }
 
 __device__ __forceinline__ void clamp_position_f(const AdvectArgs<float> &A, float &x, float &y) {
-    y = fminf(fmaxf(y, A.y_min), A.y_max);  // trajectory.py:89-90; fmax(NaN, y_min) = y_min (Q8)
+    // trajectory.py:89-90 in one v_med3_f32; a NaN input makes med3 return min3 = y_min, which is Q8's rule
+    y = __builtin_amdgcn_fmed3f(y, A.y_min, A.y_max);
     if (A.cyclic) {
         if (!(fabsf(x) < 180.0f)) {  // rare: the exact reference sequence, trajectory.py:93-94 (Q7)
             if (!(x > -180.0f)) x = pymod180<float>(x);
@@ -508,8 +516,8 @@ __device__ __forceinline__ TapL locate_wrap_l(const AdvectArgs<float> &A, float 
     TapL t;
     t.tx = __builtin_amdgcn_fractf(cx);
     t.ty = __builtin_amdgcn_fractf(cy);
-    const unsigned x0 = min((unsigned)__float2int_rd(cx), (unsigned)(A.nx_f - 1));
-    const unsigned y0 = min((unsigned)__float2int_rd(cy), (unsigned)(A.ny_f - 1));
+    const unsigned x0 = min(floor_to_uint(cx), (unsigned)(A.nx_f - 1));
+    const unsigned y0 = min(floor_to_uint(cy), (unsigned)(A.ny_f - 1));
     // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that
     t.wx0 = (int)x0 + (ORDER == 3 ? 0 : LC_PAD_LO);
     t.wy0 = (int)y0 + (ORDER == 3 ? 0 : LC_PAD_LO);
