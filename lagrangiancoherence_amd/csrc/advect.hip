@@ -497,7 +497,7 @@ struct TileGeom {
 };
 
 struct TapL {
-    int wx0, wy0;  // window origin, padded node coordinates
+    int x0, y0;  // floor of the index-space coordinate (the window origin follows from ORDER)
     float tx, ty;
 };
 
@@ -518,17 +518,18 @@ __device__ __forceinline__ TapL locate_wrap_l(const AdvectArgs<float> &A, float 
     t.ty = __builtin_amdgcn_fractf(cy);
     const unsigned x0 = min(floor_to_uint(cx), (unsigned)(A.nx_f - 1));
     const unsigned y0 = min(floor_to_uint(cy), (unsigned)(A.ny_f - 1));
-    // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that
-    t.wx0 = (int)x0 + (ORDER == 3 ? 0 : LC_PAD_LO);
-    t.wy0 = (int)y0 + (ORDER == 3 ? 0 : LC_PAD_LO);
+    t.x0 = (int)x0;
+    t.y0 = (int)y0;
     return t;
 }
 
 template <int ORDER>
 __device__ __forceinline__ f2 window_global(const float *__restrict__ lvl, const AdvectArgs<float> &A, const TapL &t,
                                             const float wx[4], const float wy[4]) {
+    // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that, i.e. padded (y0, x0)
     TapF g;
-    g.byte_off = (__umul24((unsigned)t.wy0, (unsigned)A.pitch) + (unsigned)t.wx0) * 8u;
+    g.byte_off = (__umul24((unsigned)t.y0, (unsigned)A.pitch) + (unsigned)t.x0) * 8u +
+                 (ORDER == 3 ? 0u : ((unsigned)A.pitch + 1u) * 8u);
     g.tx = t.tx;
     g.ty = t.ty;
     return fetch_f<ORDER>(lvl, g, (unsigned)A.pitch * 8u, wx, wy);
@@ -538,7 +539,7 @@ template <int ORDER>
 __device__ __forceinline__ f2 window_lds(const f2 *__restrict__ tile, int rx, int ry, const TapL &t, const float wx[4],
                                          const float wy[4]) {
     constexpr int LT_PITCH = TileGeom<ORDER>::PITCH;
-    const f2 *p = tile + ry * LT_PITCH + rx;
+    const f2 *p = tile + (__umul24((unsigned)ry, (unsigned)LT_PITCH) + (unsigned)rx);
     if (ORDER == 1) {
         const f2 n00 = p[0], n01 = p[1], n10 = p[LT_PITCH], n11 = p[LT_PITCH + 1];
         const f2 r0 = n00 + t.tx * (n01 - n00);
@@ -607,6 +608,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
         // ---- 1. Euler sample (global) and iteration 0's tap ---------------------------------
         float cx0 = 0.0f, cy0 = 0.0f, cx1 = 0.0f, cy1 = 0.0f;
         f2 e = {0.0f, 0.0f};
+        constexpr int WOFF = ORDER == 3 ? 0 : LC_PAD_LO;  // padded window origin = (y0 + WOFF, x0 + WOFF)
         TapL t = {0, 0, 0.0f, 0.0f};
         if (live) {
             t = locate_wrap_l<ORDER>(A, x, y, cx0, cy0);
@@ -629,10 +631,10 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             const int ref = (alive >> CENTRE) & 1ull ? CENTRE : (int)__ffsll((long long)alive) - 1;
             // centre of the window's predicted travel: every iteration moves a parcel by about the
             // Euler displacement (Q4)
-            const int mx = t.wx0 + (int)((cx1 - cx0) * kpred), my = t.wy0 + (int)((cy1 - cy0) * kpred);
+            const int mx = t.x0 + (int)((cx1 - cx0) * kpred), my = t.y0 + (int)((cy1 - cy0) * kpred);
             const int rxm = __builtin_amdgcn_readlane(mx, ref), rym = __builtin_amdgcn_readlane(my, ref);
-            ox = min(max(rxm - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
-            oy = min(max(rym - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
+            ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);  // padded coordinates
+            oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
         }
         // ---- 3. stage ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) ---------------------------
         __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
@@ -657,7 +659,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
                     cubic_weights_f(t.tx, wx);
                     cubic_weights_f(t.ty, wy);
                 }
-                const int rx = t.wx0 - ox, ry = t.wy0 - oy;
+                const int rx = t.x0 - (ox - WOFF), ry = t.y0 - (oy - WOFF);  // the subtrahends are wave-uniform
                 const bool inside =
                     have_tile && (unsigned)rx <= (unsigned)(LT_COLS - WIN) && (unsigned)ry <= (unsigned)(LT_ROWS - WIN);
                 f2 w;
