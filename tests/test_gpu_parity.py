@@ -395,3 +395,33 @@ def test_float32_wind_on_float64_coordinates_follows_numpy_promotion(eng, O, ord
     f64 = eng.prepare_field(u32.astype(np.float64), v32.astype(np.float64), lat, lon, order)
     x64, y64 = eng.advect(f64, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
     assert np.abs(_np(y64) - yr_).max() > 100 * POS_ATOL64
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_float_path_options_and_tiny_field(eng, O, order):
+    """float32 kernels beyond the headline settings: a field smaller than an LDS tile (direct-gather kernel is
+    launched instead), non-cyclic clamp, trajectories, K=0 and K=1, forward time."""
+    # (a) tiny field: 9 x 11 nodes < 16 x 8 / 32 x 16 tile
+    u, v, lat, lon = _rand_field(91, nt=5, ny=9, nx=11, dtype=np.float32, scale=8.0)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    for K in (0, 1, 3):
+        x, y = eng.advect(f, lat, lon, 1800.0, SETTLS_order=K, interp_order=order)
+        x64, y64 = O.parcel_propagation(u.astype(np.float64), v.astype(np.float64), lat.astype(np.float64),
+                                        lon.astype(np.float64), timestep=1800.0, SETTLS_order=K, interp_order=order,
+                                        cyclic_xboundary=True)
+        dx = np.abs(_np(x) - x64)
+        assert np.minimum(dx, np.abs(dx - 360)).max() < 2e-4 and np.abs(_np(y) - y64).max() < 2e-4
+    # (b) larger field through the LDS kernel: non-cyclic clamp + trajectories
+    u, v, lat, lon = _rand_field(92, nt=6, ny=40, nx=64, dtype=np.float32, scale=30.0)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    x, y, tx, ty = eng.advect(f, lat, lon, -3600.0, SETTLS_order=2, interp_order=order, cyclic_xboundary=False,
+                              return_traj=True)
+    tx64, ty64 = O.parcel_propagation(u.astype(np.float64), v.astype(np.float64), lat.astype(np.float64),
+                                      lon.astype(np.float64), timestep=-3600.0, SETTLS_order=2, interp_order=order,
+                                      cyclic_xboundary=False, return_traj=True)
+    ex, ey = np.abs(_np(tx) - tx64), np.abs(_np(ty) - ty64)
+    # random (spatially uncorrelated) wind: neighbouring nodes differ by tens of m/s, so float32 position
+    # rounding is amplified quickly; the bulk must still agree closely and nothing may run away
+    assert np.percentile(ex, 99) < 5e-3 and np.percentile(ey, 99) < 5e-3 and ex.max() < 5.0 and ey.max() < 5.0
+    assert np.array_equal(_np(tx[-1]), _np(x)) and _np(x).min() >= lon.min() and _np(x).max() <= lon.max()
+    assert np.array_equal(_np(tx[0]), np.meshgrid(lon, lat)[0])
