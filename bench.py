@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--settls", type=int, default=4)
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traj", action="store_true",
+                    help="return_traj=True: also store the positions after every step (not the headline)")
     ap.add_argument("--wind-scale", type=float, default=1.0,
                     help="multiply the synthetic wind (stress case: stronger stretching; not the headline)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c2"],
@@ -175,8 +177,9 @@ def main():
         marks[0].record()
         field = eng.prepare_field(ud, vd, lat, lon, order)
         marks[1].record()
-        x_ext, y_ext = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo,
-                                  ny_global=ny_global, halo=(n_lo, n_hi))
+        res = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo,
+                         ny_global=ny_global, halo=(n_lo, n_hi), return_traj=args.traj)
+        x_ext, y_ext = res[0], res[1]
         marks[2].record()
         sharded.halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world)
         in_row0 = lo - n_lo
@@ -244,6 +247,7 @@ def main():
                         f"720x1440 synthetic ERA5-like wind series, {nt} levels ({nsteps} steps, dt=-900 s), fp32",
             "SETTLS_order": K, "interp_order": order, "cyclic_xboundary": True,
             **({"wind_scale": args.wind_scale} if args.wind_scale != 1.0 else {}),
+            **({"return_traj": True} if args.traj else {}),
             "step": "pack + fused advect + halo exchange + sigma; u/v/seeds resident in HBM",
         },
         "advect_particle_timesteps_per_s": ny_global * nx * nsteps / adv_s,
