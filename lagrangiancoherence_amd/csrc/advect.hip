@@ -100,57 +100,18 @@ __device__ __forceinline__ T pymod180(T x) {
     return m;
 }
 
-// ---- order 1 ---------------------------------------------------------------
-template <typename T, bool WRAP>
-__device__ __forceinline__ Pair<T> sample1(const T *__restrict__ lvl, int pitch, int ny_f, int nx_f, T cy, T cx) {
-#pragma clang fp contract(off)
-    Pair<T> r;
-    if (WRAP) {
-        cy = wrap_coord<T>(cy, T(ny_f - 1));
-        cx = wrap_coord<T>(cx, T(nx_f - 1));
-    } else {
-        // 'constant': exactly cval=0 outside [0, n-1] (no interpolation towards cval)
-        if (cy < T(0) || cy > T(ny_f - 1) || cx < T(0) || cx > T(nx_f - 1)) {
-            r.u = T(0);
-            r.v = T(0);
-            return r;
-        }
-    }
-    const T fy = floor(cy), fx = floor(cx);
-    const int y0 = clampi((int)fy, 0, ny_f - 1);  // clamp: memory safety for NaN/inf/rounding
-    const int x0 = clampi((int)fx, 0, nx_f - 1);
-    const T ty = cy - fy, tx = cx - fx;
-    const T *p0 = lvl + ((unsigned)(y0 + LC_PAD_LO) * (unsigned)pitch + (unsigned)(x0 + LC_PAD_LO)) * 2u;
-    const T *p1 = p0 + (unsigned)pitch * 2u;
-    T a[4], b[4];
-    __builtin_memcpy(a, p0, sizeof(a));  // {u00, v00, u01, v01}
-    __builtin_memcpy(b, p1, sizeof(b));  // {u10, v10, u11, v11}
-    if (Fast<T>::value) {
-#pragma clang fp contract(fast)
-        const T u0 = fma(tx, a[2] - a[0], a[0]), v0 = fma(tx, a[3] - a[1], a[1]);
-        const T u1 = fma(tx, b[2] - b[0], b[0]), v1 = fma(tx, b[3] - b[1], b[1]);
-        r.u = fma(ty, u1 - u0, u0);
-        r.v = fma(ty, v1 - v0, v0);
-        return r;
-    }
-    const T wy0 = T(1) - ty, wy1 = T(1) - wy0;  // scipy: last weight = 1 - sum(others)
-    const T wx0 = T(1) - tx, wx1 = T(1) - wx0;
-    // scipy tap order (last axis fastest); per tap ((value*wy)*wx), summed from 0
-    T su = T(0), sv = T(0);
-    su += (a[0] * wy0) * wx0;
-    sv += (a[1] * wy0) * wx0;
-    su += (a[2] * wy0) * wx1;
-    sv += (a[3] * wy0) * wx1;
-    su += (b[0] * wy1) * wx0;
-    sv += (b[1] * wy1) * wx0;
-    su += (b[2] * wy1) * wx1;
-    sv += (b[3] * wy1) * wx1;
-    r.u = su;
-    r.v = sv;
-    return r;
-}
+// ---- generic sampling: locate once per position, fetch per time level ------------------------
+// One sample position is used for time levels t and t+1 (trajectory.py:105-108), so the index map,
+// the coordinate wrap, the floor and the spline weights are computed ONCE (locate) and each level only
+// pays its loads and its tap sum (fetch).  The arithmetic is exactly what scipy does per call.
+template <typename T>
+struct Tap {
+    unsigned off;     // element offset of the window origin inside one time level
+    T wy[4], wx[4];   // scipy's per-axis weights (order 1 uses [0], [1])
+    T ty, tx;         // fractional parts (float order-1 lerp form)
+    bool zero;        // 'constant' mode, coordinate outside [0, n-1]: the sample is exactly 0
+};
 
-// ---- order 3 ('wrap' only: pole rows always use order 1) -------------------
 template <typename T>
 __device__ __forceinline__ void cubic_weights(T t, T w[4]) {
 #pragma clang fp contract(off)
@@ -162,38 +123,8 @@ __device__ __forceinline__ void cubic_weights(T t, T w[4]) {
     w[3] = T(1) - w[0] - w[1] - w[2];
 }
 
-template <typename T>
-__device__ __forceinline__ Pair<T> sample3(const T *__restrict__ lvl, int pitch, int ny_f, int nx_f, T cy, T cx) {
-#pragma clang fp contract(off)
-    cy = wrap_coord<T>(cy, T(ny_f - 1));
-    cx = wrap_coord<T>(cx, T(nx_f - 1));
-    const T fy = floor(cy), fx = floor(cx);
-    const int y0 = clampi((int)fy, 0, ny_f - 1);
-    const int x0 = clampi((int)fx, 0, nx_f - 1);
-    T wy[4], wx[4];
-    cubic_weights<T>(cy - fy, wy);
-    cubic_weights<T>(cx - fx, wx);
-    // window starts at (y0-1, x0-1) -> padded (y0, x0)
-    const T *p = lvl + ((unsigned)y0 * (unsigned)pitch + (unsigned)x0) * 2u;
-    T su = T(0), sv = T(0);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        T row[8];
-        __builtin_memcpy(row, p + (unsigned)a * (unsigned)pitch * 2u, sizeof(row));
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            su += (row[2 * b] * wy[a]) * wx[b];
-            sv += (row[2 * b + 1] * wy[a]) * wx[b];
-        }
-    }
-    Pair<T> r;
-    r.u = su;
-    r.v = sv;
-    return r;
-}
-
 template <typename T, int ORDER, bool WRAP>
-__device__ __forceinline__ Pair<T> sample(const T *__restrict__ lvl, const AdvectArgs<T> &A, T x, T y) {
+__device__ __forceinline__ Tap<T> locate(const AdvectArgs<T> &A, T x, T y) {
 #pragma clang fp contract(off)
     // tools.py:21-22: (n * (x - min)) / (max - min)
     T cx, cy;
@@ -205,8 +136,88 @@ __device__ __forceinline__ Pair<T> sample(const T *__restrict__ lvl, const Advec
         cx = (T(A.nx_f) * (x - A.lon_min)) / A.lon_span;
         cy = (T(A.ny_f) * (y - A.lat_min)) / A.lat_span;
     }
-    if (ORDER == 3) return sample3<T>(lvl, A.pitch, A.ny_f, A.nx_f, cy, cx);
-    return sample1<T, WRAP>(lvl, A.pitch, A.ny_f, A.nx_f, cy, cx);
+    Tap<T> t;
+    t.zero = false;
+    if (WRAP) {
+        cy = wrap_coord<T>(cy, T(A.ny_f - 1));
+        cx = wrap_coord<T>(cx, T(A.nx_f - 1));
+    } else if (cy < T(0) || cy > T(A.ny_f - 1) || cx < T(0) || cx > T(A.nx_f - 1)) {
+        t.zero = true;  // 'constant': exactly cval=0 outside [0, n-1] (no interpolation towards cval)
+    }
+    const T fy = floor(cy), fx = floor(cx);
+    const int y0 = clampi((int)fy, 0, A.ny_f - 1);  // clamp: memory safety for NaN/inf/rounding
+    const int x0 = clampi((int)fx, 0, A.nx_f - 1);
+    t.ty = cy - fy;
+    t.tx = cx - fx;
+    if (ORDER == 3) {
+        cubic_weights<T>(t.ty, t.wy);
+        cubic_weights<T>(t.tx, t.wx);
+        t.off = ((unsigned)y0 * (unsigned)A.pitch + (unsigned)x0) * 2u;  // window starts at padded (y0, x0)
+    } else {
+        t.wy[0] = T(1) - t.ty;
+        t.wy[1] = T(1) - t.wy[0];  // scipy: last weight = 1 - sum(others)
+        t.wx[0] = T(1) - t.tx;
+        t.wx[1] = T(1) - t.wx[0];
+        t.off = ((unsigned)(y0 + LC_PAD_LO) * (unsigned)A.pitch + (unsigned)(x0 + LC_PAD_LO)) * 2u;
+    }
+    return t;
+}
+
+template <typename T, int ORDER>
+__device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const AdvectArgs<T> &A, const Tap<T> &t) {
+#pragma clang fp contract(off)
+    Pair<T> r;
+    if (t.zero) {
+        r.u = T(0);
+        r.v = T(0);
+        return r;
+    }
+    const T *p = lvl + t.off;
+    if (ORDER == 3) {
+        T su = T(0), sv = T(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            T row[8];
+            __builtin_memcpy(row, p + (unsigned)a * (unsigned)A.pitch * 2u, sizeof(row));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {  // scipy tap order; per tap ((value*wy)*wx), summed from 0
+                su += (row[2 * b] * t.wy[a]) * t.wx[b];
+                sv += (row[2 * b + 1] * t.wy[a]) * t.wx[b];
+            }
+        }
+        r.u = su;
+        r.v = sv;
+        return r;
+    }
+    T a[4], b[4];
+    __builtin_memcpy(a, p, sizeof(a));                            // {u00, v00, u01, v01}
+    __builtin_memcpy(b, p + (unsigned)A.pitch * 2u, sizeof(b));   // {u10, v10, u11, v11}
+    if (Fast<T>::value) {
+#pragma clang fp contract(fast)
+        const T u0 = fma(t.tx, a[2] - a[0], a[0]), v0 = fma(t.tx, a[3] - a[1], a[1]);
+        const T u1 = fma(t.tx, b[2] - b[0], b[0]), v1 = fma(t.tx, b[3] - b[1], b[1]);
+        r.u = fma(t.ty, u1 - u0, u0);
+        r.v = fma(t.ty, v1 - v0, v0);
+        return r;
+    }
+    // scipy tap order (last axis fastest); per tap ((value*wy)*wx), summed from 0
+    T su = T(0), sv = T(0);
+    su += (a[0] * t.wy[0]) * t.wx[0];
+    sv += (a[1] * t.wy[0]) * t.wx[0];
+    su += (a[2] * t.wy[0]) * t.wx[1];
+    sv += (a[3] * t.wy[0]) * t.wx[1];
+    su += (b[0] * t.wy[1]) * t.wx[0];
+    sv += (b[1] * t.wy[1]) * t.wx[0];
+    su += (b[2] * t.wy[1]) * t.wx[1];
+    sv += (b[3] * t.wy[1]) * t.wx[1];
+    r.u = su;
+    r.v = sv;
+    return r;
+}
+
+template <typename T, int ORDER, bool WRAP>
+__device__ __forceinline__ Pair<T> sample(const T *__restrict__ lvl, const AdvectArgs<T> &A, T x, T y) {
+    return fetch<T, ORDER>(lvl, A, locate<T, ORDER, WRAP>(A, x, y));
 }
 
 // y + a*x: fused for float, mul-then-add (numpy's two roundings) for double
@@ -288,8 +299,9 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
         x = axpy<T>(dtcx, e.u, x);                               // :87
         clamp_position<T>(A, x, y);
         for (int k = 0; k < A.K; ++k) {                          // :100
-            Pair<T> c = sample<T, ORDER, WRAP>(lvl, A, x, y);    // :105,107
-            Pair<T> n = sample<T, ORDER, WRAP>(nxt, A, x, y);    // :106,108
+            const Tap<T> tap = locate<T, ORDER, WRAP>(A, x, y);  // one position, two time levels
+            Pair<T> c = fetch<T, ORDER>(lvl, A, tap);             // :105,107
+            Pair<T> n = fetch<T, ORDER>(nxt, A, tap);             // :106,108
             c.u = round_sample<T>(A, c.u);
             c.v = round_sample<T>(A, c.v);
             n.u = round_sample<T>(A, n.u);
