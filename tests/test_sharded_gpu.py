@@ -4,7 +4,6 @@ be bit-identical to the unsharded one, with the halo exchanged and with the halo
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
