@@ -141,10 +141,12 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel(const SigmaArgs<T> A) {
 // (numpy float32 sin/cos, LAPACK sgesdd) anyway, so this instantiation spends as few VALU
 // cycles per cell as it can: bounded-argument sincos (Cody-Waite by pi/2 + cephes
 // minimax polynomials, ~1 ulp), float stencil with the 4th-order weights folded
-// (2/3, -1/12), reciprocal metrics per row, float closed form.  Tile 64 x 32 outputs per
-// 256 threads: halo redundancy (68*36)/(64*32) = 1.195.
+// (2/3, -1/12), reciprocal metrics per row, float closed form.  Tile 64 x 16 outputs per
+// 256 threads (halo redundancy (68*20)/(64*16) = 1.33).  Measured on 4096^2 cells (ms): 64x64 0.201,
+// 64x32 0.105, 128x16 0.112, 64x16 0.0905, 64x12 0.096, 32x32 0.094, 32x16 0.101, 128x8 0.099, 64x8 0.108 --
+// occupancy (LDS per workgroup) matters more than halo redundancy.
 // ======================================================================================
-constexpr int FW = 64, FH = 32;
+constexpr int FW = 64, FH = 16;
 constexpr int FLW = FW + 2 * HALO, FLH = FH + 2 * HALO;
 
 __device__ __forceinline__ void fast_sincosf(float a, float *sn, float *cs) {
