@@ -425,3 +425,19 @@ def test_float_path_options_and_tiny_field(eng, O, order):
     assert np.percentile(ex, 99) < 5e-3 and np.percentile(ey, 99) < 5e-3 and ex.max() < 5.0 and ey.max() < 5.0
     assert np.array_equal(_np(tx[-1]), _np(x)) and _np(x).min() >= lon.min() and _np(x).max() <= lon.max()
     assert np.array_equal(_np(tx[0]), np.meshgrid(lon, lat)[0])
+
+
+def test_lcs_host_float32_route(eng):
+    """The torch-free host entry point with float32 arrays takes the same kernels (fused levels, LDS tiles)
+    as the engine route: identical results."""
+    from lagrangiancoherence_amd.engine import lcs_host
+    u, v, lat, lon = flows.era5_like(nt=7, ny=72, nx=144)
+    slat, slon = flows.seed_grid(90, 130, lat, lon)
+    for order in (1, 3):
+        out = lcs_host(u, v, lat, lon, -900.0, SETTLS_order=4, interp_order=order, cyclic_xboundary=True,
+                       seed_lat=slat, seed_lon=slon)
+        f = eng.prepare_field(u, v, lat, lon, order)
+        r = eng.lcs(f, slat, slon, -900.0, SETTLS_order=4, interp_order=order)
+        assert out["x_dep"].dtype == np.float32
+        assert np.array_equal(out["x_dep"], _np(r["x_dep"])) and np.array_equal(out["y_dep"], _np(r["y_dep"]))
+        assert np.array_equal(out["sigma"], _np(r["sigma"]))
