@@ -104,6 +104,22 @@ def run_c2(args, torch, flows, Engine, local_rank):
     }), flush=True)
 
 
+def issue_counters(kernel_prefix: str, workload: dict):
+    """SQ/TCP-derived occupancy of the units that actually bound the kernel (committed --pmc summary)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_sq_tcp.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != workload:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.startswith(kernel_prefix) and "derived" in v:
+                return {**{kk: round(vv, 4) for kk, vv in v["derived"].items()}, "source": os.path.relpath(f, ROOT)}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,6 +275,7 @@ def main():
             "traffic": tr_adv[0] if tr_adv else None,
             "traffic_source": tr_adv[1] if tr_adv else None,
             "algorithmic_bytes_per_launch": (ny_local * nx * nsteps) * bytes_pts,
+            "limiting_unit": issue_counters("advect_lds_kernel<%d>" % order, wl) if world == 1 else None,
             "algorithmic_bytes_per_particle_timestep": bytes_pts,
             "note": "achieved = B_adv(K,order) x seeds x steps / HIP-event duration of the fused advect launch "
                     "(per GPU); the taps are served from L2/Infinity Cache, so this is an algorithmic, not an "
