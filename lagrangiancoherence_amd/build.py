@@ -39,7 +39,7 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> 
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", *extra_flags,
+           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", *extra_flags,
            "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -568,9 +568,10 @@ __device__ __forceinline__ f2 window_lds(const f2 *__restrict__ tile, int rx, in
     return acc;
 }
 
-template <int ORDER>
+template <int ORDER, int KFIX>
 __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<float> A) {
 #pragma clang fp contract(fast)
+    const int K = KFIX >= 0 ? KFIX : A.K;  // KFIX: SETTLS_order known at compile time (the iteration loop unrolls)
     typedef TileGeom<ORDER> G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
     constexpr int WIN = ORDER + 1;  // window edge in nodes
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
     const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;  // >= LT_COLS, LT_ROWS (checked by the launcher)
-    const float kpred = 0.5f * (float)(A.K > 0 ? A.K - 1 : 0);  // half of the predicted travel, in Euler displacements
+    const float kpred = 0.5f * (float)(K > 0 ? K - 1 : 0);  // half of the predicted travel, in Euler displacements
     // staging geometry of this lane: ROWS_PER_PASS tile rows per pass, 16 B (2 nodes) per lane
     const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
     float wx[4], wy[4];
@@ -637,7 +638,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
         // ---- 2. anchor the tile on the patch's centre lane (first live lane if that one is dead) ----
         const unsigned long long alive = __ballot(live);
         int ox = 0, oy = 0;
-        const bool have_tile = alive != 0ull && A.K > 0;
+        const bool have_tile = alive != 0ull && K > 0;
         if (have_tile) {
             constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
             const int ref = (alive >> CENTRE) & 1ull ? CENTRE : (int)__ffsll((long long)alive) - 1;
@@ -661,7 +662,8 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
         }
         __builtin_amdgcn_wave_barrier();
         // ---- 4. K iterations out of LDS (global gather for lanes whose window left the tile) ------
-        for (int k = 0; k < A.K; ++k) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
             if (live) {
                 if (k > 0) {
                     float ucx, ucy;
@@ -707,7 +709,10 @@ struct LdsLaunch<float, ORDER> {
     static bool launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
         // the fixed-size tile must fit inside one padded time level
         if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return false;
-        hipLaunchKernelGGL((advect_lds_kernel<ORDER>), dim3(grid), dim3(BLOCK), 0, st, A);
+        if (A.K == 4)  // the setting the reference's example and drivers use
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4>), dim3(grid), dim3(BLOCK), 0, st, A);
+        else
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1>), dim3(grid), dim3(BLOCK), 0, st, A);
         return true;
     }
 };
