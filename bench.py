@@ -270,7 +270,7 @@ def main():
         "ftle_mcells_per_s": ny_global * nx / sig_s / 1e6,
         "kernel_ms": ms,
         "roofline": {
-            "bound": "hbm", "kernel": "advect_lds_kernel<%d>" % order,
+            "bound": "hbm", "kernel": "advect_lds_kernel<%d,%d>" % (order, 4 if K == 4 else -1),
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": tr_adv[0] if tr_adv else None,
             "traffic_source": tr_adv[1] if tr_adv else None,
