@@ -275,7 +275,7 @@ def main():
             "traffic": tr_adv[0] if tr_adv else None,
             "traffic_source": tr_adv[1] if tr_adv else None,
             "algorithmic_bytes_per_launch": (ny_local * nx * nsteps) * bytes_pts,
-            "limiting_unit": issue_counters("advect_lds_kernel<%d>" % order, wl) if world == 1 else None,
+            "limiting_unit": issue_counters("advect_lds_kernel<%d," % order, wl) if world == 1 else None,
             "algorithmic_bytes_per_particle_timestep": bytes_pts,
             "note": "achieved = B_adv(K,order) x seeds x steps / HIP-event duration of the fused advect launch "
                     "(per GPU); the taps are served from L2/Infinity Cache, so this is an algorithmic, not an "
