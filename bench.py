@@ -37,6 +37,20 @@ def b_adv(K: int, order: int, s_p: int, s_f: int) -> int:
     return 4 * s_p + taps * (2 + 4 * K) * s_f
 
 
+def measured_copy_peak(torch, nbytes: int = 1 << 30, reps: int = 10) -> float:
+    """Device copy bandwidth of this box in GB/s (read + write bytes), the second HBM figure SURVEY 8d asks for."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+
 def pmc_traffic(kernel_prefix: str, workload: dict):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summaries (profiles/*/
     *_pmc_traffic.json, written by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE passes of
@@ -235,6 +249,7 @@ def main():
 
     pts_per_step = ny_global * nx * nsteps
     value = pts_per_step * args.steps / elapsed
+    copy_gbps = measured_copy_peak(torch)                                       # after the timed region
     s_f = s_p = 4
     bytes_pts = b_adv(K, order, s_p, s_f)
     adv_s = ms["advect"] / 1e3
@@ -272,6 +287,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "advect_lds_kernel<%d,%d>" % (order, 4 if K == 4 else -1),
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "measured_copy_peak": copy_gbps, "frac_of_measured_copy_peak": achieved / copy_gbps,
             "traffic": tr_adv[0] if tr_adv else None,
             "traffic_source": tr_adv[1] if tr_adv else None,
             "algorithmic_bytes_per_launch": (ny_local * nx * nsteps) * bytes_pts,
@@ -283,7 +299,8 @@ def main():
         },
         "roofline_sigma": {
             "bound": "hbm", "kernel": "sigma_kernel<float,float>", "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "traffic": tr_sig[0] if tr_sig else None,
+            "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": sigma_gbps / copy_gbps,
+            "traffic": tr_sig[0] if tr_sig else None,
             "algorithmic_bytes_per_cell": 3 * s_p,
         },
     }

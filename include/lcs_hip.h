@@ -200,10 +200,12 @@ int lc_gaussian_filter(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int n
  * [[hxx,hxy],[hxy,hyy]] (inf/NaN entries zeroed), the reference's row-indexed
  * eigenvector dotted with the gradient, the eigenvalue of largest magnitude, and the
  * mask (|dot| <= tolerance and that eigenvalue negative).  All arrays [n] doubles on the
- * device; dt_out (the raw dot product) may be NULL. */
+ * device; dt_out (the raw dot product, tools.py:115) and eigvec_out ([2][n]: the two
+ * components of that row-indexed eigenvector, tools.py:107, unmasked -- the
+ * return_eigvectors=True outputs of tools.py:123-150 are built from it) may be NULL. */
 int lc_ridge_classify(lc_ctx *ctx, const void *hxx, const void *hxy, const void *hyy,
                       const void *gx, const void *gy, size_t n, double tolerance,
-                      void *mask_out, void *eigmin_out, void *dt_out);
+                      void *mask_out, void *eigmin_out, void *dt_out, void *eigvec_out);
 
 /* ---- one-call host entry point ----------------------------------------------
  * What a reference-side binding would call from LCS.__call__ (LCS/LCS.py:129-157):

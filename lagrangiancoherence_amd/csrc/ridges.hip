@@ -126,7 +126,8 @@ __device__ Eig2 dgeev_sym2(double a, double b, double d) {
 __global__ void ridge_kernel(const double *__restrict__ hxx, const double *__restrict__ hxy,
                              const double *__restrict__ hyy, const double *__restrict__ gx,
                              const double *__restrict__ gy, size_t n, double tol, double *__restrict__ mask,
-                             double *__restrict__ eigmin, double *__restrict__ dt_out) {
+                             double *__restrict__ eigmin, double *__restrict__ dt_out,
+                             double *__restrict__ eigvec_out) {
 #pragma clang fp contract(off)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         auto clean = [](double h) { return (fabs(h) != INFINITY && h == h) ? h : 0.0; };  // tools.py:92-93
@@ -141,6 +142,10 @@ __global__ void ridge_kernel(const double *__restrict__ hxx, const double *__res
         mask[i] = m;
         eigmin[i] = em;
         if (dt_out) dt_out[i] = dt;
+        if (eigvec_out) {
+            eigvec_out[i] = r0;
+            eigvec_out[n + i] = r1;
+        }
     }
 }
 
@@ -148,7 +153,7 @@ __global__ void ridge_kernel(const double *__restrict__ hxx, const double *__res
 
 extern "C" int lc_ridge_classify(lc_ctx *ctx, const void *hxx, const void *hxy, const void *hyy, const void *gx,
                                  const void *gy, size_t n, double tolerance, void *mask_out, void *eigmin_out,
-                                 void *dt_out) {
+                                 void *dt_out, void *eigvec_out) {
     LC_REQUIRE(ctx, "lc_ridge_classify: null context");
     LC_REQUIRE(hxx && hxy && hyy && gx && gy && mask_out && eigmin_out, "lc_ridge_classify: null pointer");
     LC_HIP_CHECK(hipSetDevice(ctx->device));
@@ -156,7 +161,7 @@ extern "C" int lc_ridge_classify(lc_ctx *ctx, const void *hxx, const void *hxy, 
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(ridge_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double *)hxx, (const double *)hxy,
                        (const double *)hyy, (const double *)gx, (const double *)gy, n, tolerance, (double *)mask_out,
-                       (double *)eigmin_out, (double *)dt_out);
+                       (double *)eigmin_out, (double *)dt_out, (double *)eigvec_out);
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }

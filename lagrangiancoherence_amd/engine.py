@@ -256,17 +256,20 @@ class Engine:
                                                         self._ptr(out)), self.lib)
         return out
 
-    def ridge_classify(self, hxx, hxy, hyy, gx, gy, tolerance):
+    def ridge_classify(self, hxx, hxy, hyy, gx, gy, tolerance, return_eigvec=False):
         """Per-point step of tools.find_ridges_spherical_hessian (LCS/tools.py:99-138).
-        Returns (mask, eigmin, dt) float64 device tensors shaped like the inputs."""
+        Returns (mask, eigmin, dt) float64 device tensors shaped like the inputs, plus -- with
+        ``return_eigvec`` -- the reference's row-indexed eigenvector as a ``(2, *shape)`` tensor."""
         t = [self.to_device(a, np.float64) for a in (hxx, hxy, hyy, gx, gy)]
         shape = tuple(t[0].shape)
         n = int(t[0].numel())
         mask, eigmin, dt = (self._empty(shape, np.float64) for _ in range(3))
+        vec = self._empty((2,) + shape, np.float64) if return_eigvec else None
         self._use_current_stream()
         _capi.check(self.lib.lc_ridge_classify(self.ctx, *(self._ptr(a) for a in t), n, float(tolerance),
-                                               self._ptr(mask), self._ptr(eigmin), self._ptr(dt)), self.lib)
-        return mask, eigmin, dt
+                                               self._ptr(mask), self._ptr(eigmin), self._ptr(dt),
+                                               self._ptr(vec) if return_eigvec else None), self.lib)
+        return (mask, eigmin, dt, vec) if return_eigvec else (mask, eigmin, dt)
 
     def gaussian_filter(self, a, sigma):
         """scipy.ndimage.gaussian_filter(a, sigma) on the device (LCS/LCS.py:187-190)."""

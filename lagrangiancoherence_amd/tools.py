@@ -76,10 +76,14 @@ def find_ridges_spherical_hessian(da, sigma=.5, scheme='first_order', tolerance_
     gradient/eigenvector product is within ``tolerance_threshold`` and the Hessian eigenvalue of largest
     magnitude is negative, else 0.  Gaussian smoothing, the five float32-cast 4th-order derivatives and
     the per-point ``numpy.linalg.eig`` (a Python loop in the reference) all run on the device.
-    ``return_eigvectors=True`` (extra eigenvector / angle arrays) is not provided.
+
+    ``return_eigvectors=True`` returns the reference's six-tuple (tools.py:140-147):
+    ``(ridges, eigmin, raw product, eigvectors, gradient, angle)`` -- ``eigvectors`` has a leading
+    ``eigvectors`` dimension labelled ``['d2dadxdy', 'd2dadydx']`` (the reference builds it from those two
+    Hessian planes, tools.py:123-124) and is zeroed where ``eigmin >= 0`` (tools.py:133); ``gradient`` has a
+    leading ``elements`` dimension ``['ddadx', 'ddady']``; ``angle`` is ``180/pi * arctan(e0/e1)`` of the
+    unmasked vector (tools.py:125).
     """
-    if return_eigvectors:
-        raise NotImplementedError("return_eigvectors=True is not provided (only the ridge mask and eigmin are)")
     if not isglobal:
         raise NotImplementedError("only the isglobal=True (cyclic longitude) branch is provided")
     dims = tuple(da.dims)
@@ -101,11 +105,21 @@ def find_ridges_spherical_hessian(da, sigma=.5, scheme='first_order', tolerance_
         return d / dy if dim == 0 else d / dx
     ddadx, ddady = D(a, 1), D(a, 0)                                                    # tools.py:77-78
     d2x2, d2y2, dxdy = D(ddadx, 1), D(ddady, 0), D(ddadx, 0)                           # tools.py:79-81
-    mask, eigmin, _ = eng.ridge_classify(d2x2, dxdy, d2y2, ddadx, ddady, tolerance_threshold)
-    inv_lat, inv_lon = np.argsort(ilat), np.argsort(ilon)
+    mask, eigmin, dt, vec = eng.ridge_classify(d2x2, dxdy, d2y2, ddadx, ddady, tolerance_threshold,
+                                               return_eigvec=True)
 
-    def out(t):
+    def out(t, lead=None, labels=None):
         arr = _to_np(t)
-        o = _make(da, arr, ("latitude", "longitude"), {"latitude": lat, "longitude": lon}, getattr(da, "name", None))
-        return o.transpose(*dims)                                                      # tools.py:150
-    return out(mask), out(eigmin)
+        coords = {"latitude": lat, "longitude": lon}
+        if lead is None:
+            o = _make(da, arr, ("latitude", "longitude"), coords, getattr(da, "name", None))
+            return o.transpose(*dims)                                                  # tools.py:150
+        coords[lead] = np.asarray(labels)
+        o = _make(da, arr, (lead, "latitude", "longitude"), coords, getattr(da, "name", None))
+        return o.transpose(lead, *dims)                                                # tools.py:141-147
+    if not return_eigvectors:
+        return out(mask), out(eigmin)
+    angle = (180 / np.pi) * torch.atan(vec[0] / vec[1])                                # tools.py:125
+    vec_masked = torch.where((eigmin < 0)[None], vec, torch.zeros_like(vec))           # tools.py:133
+    return (out(mask), out(eigmin), out(dt), out(vec_masked, "eigvectors", ["d2dadxdy", "d2dadydx"]),
+            out(torch.stack([ddadx, ddady]), "elements", ["ddadx", "ddady"]), out(angle))

@@ -26,9 +26,11 @@ from .lcs_oracle import derivative_spherical_coords
 __all__ = ["find_ridges_spherical_hessian", "dlanv2_sym"]
 
 
-def find_ridges_spherical_hessian(values, lat, lon, sigma=.5, tolerance_threshold=0.0005e-3):
-    """values: (nlat, nlon), lat/lon ascending.  Returns (ridge mask, eigmin, dt_prod_raw), each (nlat, nlon).
-    tools.py:67-155 with isglobal=True, return_eigvectors=False."""
+def find_ridges_spherical_hessian(values, lat, lon, sigma=.5, tolerance_threshold=0.0005e-3, return_eigvectors=False):
+    """values: (nlat, nlon), lat/lon ascending.  Returns (ridge mask, eigmin, dt_prod_raw), each (nlat, nlon);
+    with ``return_eigvectors`` also (eigvectors (2, nlat, nlon) zeroed where eigmin >= 0, gradient (2, nlat, nlon),
+    angle (nlat, nlon)) -- the extra members of the reference's six-tuple (tools.py:123-133,140-147).
+    tools.py:67-155 with isglobal=True."""
     da = np.asarray(values, dtype=np.float64)
     if isinstance(sigma, (float, int)):
         da = gaussian_filter(da, sigma=sigma)                                     # tools.py:74-75
@@ -52,6 +54,13 @@ def find_ridges_spherical_hessian(values, lat, lon, sigma=.5, tolerance_threshol
     mask = np.where(np.abs(dt) > tolerance_threshold, mask, 1)                    # tools.py:137 (R3)
     mask = np.where(np.sign(eigmin) == -1, mask, 0)                               # tools.py:138
     shp = da.shape
+    if return_eigvectors:
+        ev = eigvector.T                                                          # (2, N), tools.py:123
+        with np.errstate(divide="ignore", invalid="ignore"):
+            angle = 180 / np.pi * np.arctan(ev[0] / ev[1])                        # tools.py:125 (before the masking)
+        ev_masked = np.where(eigmin[None] < 0, ev, 0)                             # tools.py:133
+        return (mask.reshape(shp), eigmin.reshape(shp), dt.reshape(shp), ev_masked.reshape((2,) + shp),
+                grad.reshape((2,) + shp), angle.reshape(shp))
     return mask.reshape(shp), eigmin.reshape(shp), dt.reshape(shp)
 
 

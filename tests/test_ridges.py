@@ -72,7 +72,7 @@ def test_ridge_classify_kernel_vs_numpy_eig():
     a[10], b[11], d[12] = np.inf, np.nan, -np.inf                              # cleaned to 0 (tools.py:92-93)
     gx[13] = np.nan                                                             # R3
     tol = 0.3
-    mask, eigmin, dt = (t.cpu().numpy() for t in eng.ridge_classify(a, b, d, gx, gy, tol))
+    mask, eigmin, dt, vec = (t.cpu().numpy() for t in eng.ridge_classify(a, b, d, gx, gy, tol, return_eigvec=True))
     ac, bc, dc = (np.where(np.isfinite(v), v, 0.0) for v in (a, b, d))
     w, V = np.linalg.eig(np.stack([np.stack([ac, bc], -1), np.stack([bc, dc], -1)], -2))
     n = np.arange(a.size)
@@ -81,6 +81,7 @@ def test_ridge_classify_kernel_vs_numpy_eig():
     em_ref = w[n, np.argmax(np.abs(w), axis=1)]
     # the device's double sqrt/divide can differ from the host's in the last bit
     np.testing.assert_allclose(eigmin, em_ref, rtol=2e-15, atol=0)
+    np.testing.assert_allclose(vec, row.T, rtol=0, atol=5e-15)                  # tools.py:107, the ROW of V
     np.testing.assert_allclose(dt, dt_ref, rtol=0, atol=5e-15 * max(1.0, np.nanmax(np.abs(dt_ref))), equal_nan=True)
     m = np.where(np.abs(dt_ref) <= tol, dt_ref, 0)
     m = np.where(np.abs(dt_ref) > tol, m, 1)
@@ -110,3 +111,22 @@ def test_find_ridges_drop_in_vs_oracle():
         borderline = np.abs(np.abs(dt_ref) - tol) < 1e-9 * tol
         assert np.array_equal(ridges.values.T[~borderline], m_ref[~borderline])
         assert 0 < ridges.values.sum() < ridges.values.size
+        # return_eigvectors=True: the reference's six-tuple (tools.py:140-147)
+        six = find_ridges_spherical_hessian(da, sigma=sigma, tolerance_threshold=tol, return_eigvectors=True)
+        ref6 = RO.find_ridges_spherical_hessian(ftle, lat, lon, sigma=sigma, tolerance_threshold=tol,
+                                                return_eigvectors=True)
+        assert len(six) == 6
+        assert np.array_equal(six[0].values, ridges.values) and np.array_equal(six[1].values, eigmin.values)
+        assert six[3].dims == ("eigvectors", "longitude", "latitude") and six[4].dims == ("elements", "longitude", "latitude")
+        assert list(six[3]["eigvectors"].values) == ["d2dadxdy", "d2dadydx"]
+        assert list(six[4]["elements"].values) == ["ddadx", "ddady"]
+        assert six[2].dims == six[5].dims == ("longitude", "latitude")
+        scale = np.nanmax(np.abs(ref6[2]))
+        np.testing.assert_allclose(six[2].values.T, ref6[2], rtol=0, atol=1e-12 * scale)           # raw product
+        np.testing.assert_allclose(six[3].values.transpose(0, 2, 1), ref6[3], rtol=0, atol=1e-12)  # unit vectors
+        np.testing.assert_allclose(six[4].values.transpose(0, 2, 1), ref6[4], rtol=1e-12, atol=0)  # gradient
+        # arctan(e0/e1) is ill-conditioned where e1 ~ 0 (the angle jumps between -90 and +90): compare elsewhere
+        ok = np.abs(ref6[3][1]) > 1e-6
+        a_ref = np.where(np.isnan(ref6[5]), 0, ref6[5])
+        a_got = np.where(np.isnan(six[5].values.T), 0, six[5].values.T)
+        np.testing.assert_allclose(a_got[ok], a_ref[ok], rtol=0, atol=1e-6)
