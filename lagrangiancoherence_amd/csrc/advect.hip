@@ -513,45 +513,59 @@ struct TapL {
     float tx, ty;
 };
 
-template <int ORDER>
-__device__ __forceinline__ TapL locate_wrap_l(const AdvectArgs<float> &A, float x, float y, float &cx_out,
-                                              float &cy_out) {
-    float cx = (x - A.lon_min) * A.sx;
-    float cy = (y - A.lat_min) * A.sy;
+// Index-space coordinate of a position (tools.py:21-22 with the float path's multiply form) after scipy's
+// 'wrap' map.  Packed: one v_pk_add_f32 + one v_pk_mul_f32.  The in-range test is one unsigned compare
+// per axis on the float's bits (catches c < 0, c > n-1 and NaN); the exact wrap runs in the rare branch.
+__device__ __forceinline__ f2 index_coords(const AdvectArgs<float> &A, f2 p) {
+    f2 c = (p - (f2){A.lon_min, A.lat_min}) * (f2){A.sx, A.sy};
     const float szx = (float)(A.nx_f - 1), szy = (float)(A.ny_f - 1);
-    if ((unsigned)(__float_as_uint(cx) > __float_as_uint(szx)) | (unsigned)(__float_as_uint(cy) > __float_as_uint(szy))) {
-        cx = wrap_coord<float>(cx, szx);
-        cy = wrap_coord<float>(cy, szy);
+    if ((unsigned)(__float_as_uint(c.x) > __float_as_uint(szx)) | (unsigned)(__float_as_uint(c.y) > __float_as_uint(szy))) {
+        c.x = wrap_coord<float>(c.x, szx);
+        c.y = wrap_coord<float>(c.y, szy);
     }
-    cx_out = cx;
-    cy_out = cy;
+    return c;
+}
+
+// Window origin and fractions of a wrapped coordinate.  No index clamp here: a wrapped finite coordinate
+// lies in [0, n-1] (+ rounding < 1), NaN converts to 0; the LDS path range-checks the tile-relative
+// index anyway and the global path clamps (window_global).
+__device__ __forceinline__ TapL tap_of(f2 c) {
     TapL t;
-    t.tx = __builtin_amdgcn_fractf(cx);
-    t.ty = __builtin_amdgcn_fractf(cy);
-    const unsigned x0 = min(floor_to_uint(cx), (unsigned)(A.nx_f - 1));
-    const unsigned y0 = min(floor_to_uint(cy), (unsigned)(A.ny_f - 1));
-    t.x0 = (int)x0;
-    t.y0 = (int)y0;
+    t.tx = __builtin_amdgcn_fractf(c.x);
+    t.ty = __builtin_amdgcn_fractf(c.y);
+    t.x0 = (int)floor_to_uint(c.x);
+    t.y0 = (int)floor_to_uint(c.y);
     return t;
 }
 
 template <int ORDER>
 __device__ __forceinline__ f2 window_global(const float *__restrict__ lvl, const AdvectArgs<float> &A, const TapL &t,
                                             const float wx[4], const float wy[4]) {
-    // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that, i.e. padded (y0, x0)
+    // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that, i.e. padded (y0, x0).
+    // The unsigned min is memory safety (garbage coordinates saturate).
+    const unsigned x0 = min((unsigned)t.x0, (unsigned)(A.nx_f - 1)), y0 = min((unsigned)t.y0, (unsigned)(A.ny_f - 1));
     TapF g;
-    g.byte_off = (__umul24((unsigned)t.y0, (unsigned)A.pitch) + (unsigned)t.x0) * 8u +
-                 (ORDER == 3 ? 0u : ((unsigned)A.pitch + 1u) * 8u);
+    g.byte_off = (__umul24(y0, (unsigned)A.pitch) + x0) * 8u + (ORDER == 3 ? 0u : ((unsigned)A.pitch + 1u) * 8u);
     g.tx = t.tx;
     g.ty = t.ty;
     return fetch_f<ORDER>(lvl, g, (unsigned)A.pitch * 8u, wx, wy);
 }
 
+// ``tile_addr``: LDS byte address of the wave's tile.  The window address is one 24-bit mad + one
+// shift-add (left to itself the compiler picks the quarter-rate v_mul_lo_u32 here).
+typedef __attribute__((address_space(3))) const f2 lds_f2;
+
+__device__ __forceinline__ unsigned lds_address(const void *shared_ptr) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)shared_ptr;
+}
+
 template <int ORDER>
-__device__ __forceinline__ f2 window_lds(const f2 *__restrict__ tile, int rx, int ry, const TapL &t, const float wx[4],
-                                         const float wy[4]) {
+__device__ __forceinline__ f2 window_lds(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry, const TapL &t,
+                                         const float wx[4], const float wy[4]) {
     constexpr int LT_PITCH = TileGeom<ORDER>::PITCH;
-    const f2 *p = tile + (__umul24((unsigned)ry, (unsigned)LT_PITCH) + (unsigned)rx);
+    unsigned row_addr;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(tile_addr));
+    lds_f2 *p = (lds_f2 *)(size_t)(row_addr + ((unsigned)rx << 3));
     if (ORDER == 1) {
         const f2 n00 = p[0], n01 = p[1], n10 = p[LT_PITCH], n11 = p[LT_PITCH + 1];
         const f2 r0 = n00 + t.tx * (n01 - n00);
@@ -561,11 +575,31 @@ __device__ __forceinline__ f2 window_lds(const f2 *__restrict__ tile, int rx, in
     f2 acc = {0.0f, 0.0f};
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const f2 *q = p + a * LT_PITCH;
+        lds_f2 *q = p + a * LT_PITCH;
         const f2 r = wx[0] * q[0] + wx[1] * q[1] + wx[2] * q[2] + wx[3] * q[3];
         acc += wy[a] * r;
     }
     return acc;
+}
+
+// trajectory.py:89-94 on a packed position: latitude clamp in one v_med3_f32 (a NaN input makes med3
+// return min3 = y_min, which is Q8's rule; ``ymax_v`` lives in a VGPR because a VOP3 takes one SGPR);
+// the cyclic wrap is the exact reference sequence in a rare branch.
+__device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 &p, float ymax_v) {
+    p.y = __builtin_amdgcn_fmed3f(p.y, A.y_min, ymax_v);
+    if (A.cyclic) {
+        if (!(fabsf(p.x) < 180.0f)) {  // rare (Q7)
+            float x = p.x;
+            if (!(x > -180.0f)) x = pymod180<float>(x);
+            if (!(x < 180.0f)) x = -180.0f + pymod180<float>(x);
+            p.x = x;
+        }
+    } else {
+        float x = p.x;
+        x = x < A.x_min ? A.x_min : x;  // NaN stays NaN, as in the reference
+        x = x > A.x_max ? A.x_max : x;
+        p.x = x;
+    }
 }
 
 template <int ORDER, int KFIX>
@@ -595,21 +629,28 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     }
     // From here on every lane of the wave runs the loop (dead lanes predicated off): the staging
     // below is a whole-wave operation.
-    float x = 0.0f, y = 0.0f, dtcx = 0.0f, hdtcx = 0.0f;
+    f2 p = {0.0f, 0.0f};    // (longitude, latitude): adjacent registers, so index map and update are packed ops
+    f2 dd = {0.0f, 0.0f};   // degrees per (m/s) over a full step: (dt*conversion_x, dt*conversion_y)
+    f2 hd = {0.0f, 0.0f};   // ... over a SETTLS half step
     const size_t idx = live ? (size_t)iy * A.nx + ix : 0;
     const size_t plane = (size_t)A.ny * A.nx;
     if (live) {
-        x = A.seed_lon[ix];
-        y = A.seed_lat[iy];
+        p.x = A.seed_lon[ix];
+        p.y = A.seed_lat[iy];
         const float cx_conv =
-            180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((y * (float)3.141592653589793) / 180.0f)));
-        dtcx = A.dt * cx_conv;
-        hdtcx = A.half_dt * cx_conv;
+            180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((p.y * (float)3.141592653589793) / 180.0f)));
+        dd = (f2){A.dt * cx_conv, A.dtcy};
+        hd = (f2){A.half_dt * cx_conv, A.hdtcy};
         if (A.traj_x) {
-            A.traj_x[idx] = x;
-            A.traj_y[idx] = y;
+            A.traj_x[idx] = p.x;
+            A.traj_y[idx] = p.y;
         }
     }
+    float ymax_v = A.y_max;
+    asm volatile("" : "+v"(ymax_v));  // keep it in a VGPR (see clamp_position_p)
+    const unsigned tile_addr = lds_address(tile);
+    unsigned pitch_bytes = (unsigned)LT_PITCH * 8u;
+    asm volatile("" : "+s"(pitch_bytes));  // one SGPR for the whole kernel (a VOP3 literal is not encodable)
     const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
     const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;  // >= LT_COLS, LT_ROWS (checked by the launcher)
@@ -619,40 +660,45 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     float wx[4], wy[4];
     for (int s = 0; s < A.nsteps; ++s) {
         // ---- 1. Euler sample (global) and iteration 0's tap ---------------------------------
-        float cx0 = 0.0f, cy0 = 0.0f, cx1 = 0.0f, cy1 = 0.0f;
+        f2 c0 = {0.0f, 0.0f}, c1 = {0.0f, 0.0f};
         f2 e = {0.0f, 0.0f};
         constexpr int WOFF = ORDER == 3 ? 0 : LC_PAD_LO;  // padded window origin = (y0 + WOFF, x0 + WOFF)
         TapL t = {0, 0, 0.0f, 0.0f};
         if (live) {
-            t = locate_wrap_l<ORDER>(A, x, y, cx0, cy0);
+            c0 = index_coords(A, p);
+            t = tap_of(c0);
             if (ORDER == 3) {
                 cubic_weights_f(t.tx, wx);
                 cubic_weights_f(t.ty, wy);
             }
             e = window_global<ORDER>(lvl, A, t, wx, wy);
-            y = fmaf(A.dtcy, e.y, y);
-            x = fmaf(dtcx, e.x, x);
-            clamp_position_f(A, x, y);
-            t = locate_wrap_l<ORDER>(A, x, y, cx1, cy1);
+            p = dd * e + p;
+            clamp_position_p(A, p, ymax_v);
+            c1 = index_coords(A, p);
+            t = tap_of(c1);
         }
         // ---- 2. anchor the tile on the patch's centre lane (first live lane if that one is dead) ----
         const unsigned long long alive = __ballot(live);
-        int ox = 0, oy = 0;
+        int sox = 0, soy = 0;  // tile origin minus WOFF, in field-node coordinates (wave-uniform)
         const bool have_tile = alive != 0ull && K > 0;
         if (have_tile) {
             constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
             const int ref = (alive >> CENTRE) & 1ull ? CENTRE : (int)__ffsll((long long)alive) - 1;
             // centre of the window's predicted travel: every iteration moves a parcel by about the
             // Euler displacement (Q4)
-            const int mx = t.x0 + (int)((cx1 - cx0) * kpred), my = t.y0 + (int)((cy1 - cy0) * kpred);
+            const f2 dc = (c1 - c0) * kpred;
+            const int mx = t.x0 + (int)dc.x, my = t.y0 + (int)dc.y;
             const int rxm = __builtin_amdgcn_readlane(mx, ref), rym = __builtin_amdgcn_readlane(my, ref);
-            ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);  // padded coordinates
-            oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
+            const int ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);  // padded coordinates
+            const int oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
+            sox = ox - WOFF;
+            soy = oy - WOFF;
         }
         // ---- 3. stage ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) ---------------------------
         __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
         if (have_tile) {
-            const float *src = elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)(ox + st_col)) * 2;
+            const float *src = elv + ((size_t)__umul24((unsigned)(soy + WOFF), (unsigned)pad_cols) +
+                                      (unsigned)(sox + WOFF + st_col)) * 2;
 #pragma unroll
             for (int r = 0; r < LT_ROWS; r += G::ROWS_PER_PASS) {
                 f4 v;
@@ -665,38 +711,33 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (live) {
-                if (k > 0) {
-                    float ucx, ucy;
-                    t = locate_wrap_l<ORDER>(A, x, y, ucx, ucy);
-                }
+                if (k > 0) t = tap_of(index_coords(A, p));
                 if (ORDER == 3) {
                     cubic_weights_f(t.tx, wx);
                     cubic_weights_f(t.ty, wy);
                 }
-                const int rx = t.x0 - (ox - WOFF), ry = t.y0 - (oy - WOFF);  // the subtrahends are wave-uniform
+                const int rx = t.x0 - sox, ry = t.y0 - soy;  // the subtrahends are wave-uniform (SGPRs)
                 const bool inside =
                     have_tile && (unsigned)rx <= (unsigned)(LT_COLS - WIN) && (unsigned)ry <= (unsigned)(LT_ROWS - WIN);
                 f2 w;
                 if (inside)
-                    w = window_lds<ORDER>(tile, rx, ry, t, wx, wy);
+                    w = window_lds<ORDER>(tile_addr, pitch_bytes, rx, ry, t, wx, wy);
                 else
                     w = window_global<ORDER>(elv, A, t, wx, wy);
-                const f2 d = e + w;
-                y = fmaf(A.hdtcy, d.y, y);
-                x = fmaf(hdtcx, d.x, x);
-                clamp_position_f(A, x, y);
+                p = hd * (e + w) + p;
+                clamp_position_p(A, p, ymax_v);
             }
         }
         if (live && A.traj_x) {
-            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
-            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+            A.traj_x[(size_t)(s + 1) * plane + idx] = p.x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = p.y;
         }
         lvl += A.level_elems;
         elv += A.level_elems;
     }
     if (live) {
-        A.x_out[idx] = x;
-        A.y_out[idx] = y;
+        A.x_out[idx] = p.x;
+        A.y_out[idx] = p.y;
     }
 }
 
