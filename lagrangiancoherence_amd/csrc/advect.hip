@@ -602,6 +602,15 @@ __device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 
     }
 }
 
+// Control flow: rocprof shows the VALU (~80 % of issue slots) and the CU's scalar pipe (SALU + branches,
+// ~75 %) saturating together, so the loop is written with ONE rare branch per sample instead of one per
+// special case.  Every lane first runs the common case unconditionally -- coordinate already in
+// [0, n-1), window inside the wave's tile, new longitude strictly inside the wrap/clamp bounds -- and
+// records in ``bad`` whether any assumption failed; only then the exact sequence (scipy's wrap map, a
+// global gather, the reference's clamps) is re-run for those lanes from the saved position.  The common
+// case never faults on garbage: LDS reads cannot fault (out-of-range DS reads return 0) and the global
+// gather clamps its indices.  Lanes without a seed (grid edge, pole rows) shadow a neighbouring seed so
+// that they follow the same path; only their stores are masked.
 template <int ORDER, int KFIX>
 __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<float> A) {
 #pragma clang fp contract(fast)
@@ -609,6 +618,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     typedef TileGeom<ORDER> G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
     constexpr int WIN = ORDER + 1;  // window edge in nodes
+    constexpr int WOFF = ORDER == 3 ? 0 : LC_PAD_LO;  // padded window origin = (y0 + WOFF, x0 + WOFF)
     __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
     const int per_xcd = (A.ntiles + 7) / 8;
     const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
@@ -627,30 +637,27 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             live = false;
         }
     }
-    // From here on every lane of the wave runs the loop (dead lanes predicated off): the staging
-    // below is a whole-wave operation.
-    f2 p = {0.0f, 0.0f};    // (longitude, latitude): adjacent registers, so index map and update are packed ops
-    f2 dd = {0.0f, 0.0f};   // degrees per (m/s) over a full step: (dt*conversion_x, dt*conversion_y)
-    f2 hd = {0.0f, 0.0f};   // ... over a SETTLS half step
+    if (__ballot(live) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
+    // (longitude, latitude) in adjacent registers: index map and position update are packed operations
+    f2 p = {A.seed_lon[min(ix, A.nx - 1)], A.seed_lat[min(iy, A.ny - 1)]};
+    const float cx_conv =
+        180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((p.y * (float)3.141592653589793) / 180.0f)));
+    const f2 dd = {A.dt * cx_conv, A.dtcy};        // degrees per (m/s) over a full step (trajectory.py:55-57,86-87)
+    const f2 hd = {A.half_dt * cx_conv, A.hdtcy};  // ... over a SETTLS half step (trajectory.py:110-112)
     const size_t idx = live ? (size_t)iy * A.nx + ix : 0;
     const size_t plane = (size_t)A.ny * A.nx;
-    if (live) {
-        p.x = A.seed_lon[ix];
-        p.y = A.seed_lat[iy];
-        const float cx_conv =
-            180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((p.y * (float)3.141592653589793) / 180.0f)));
-        dd = (f2){A.dt * cx_conv, A.dtcy};
-        hd = (f2){A.half_dt * cx_conv, A.hdtcy};
-        if (A.traj_x) {
-            A.traj_x[idx] = p.x;
-            A.traj_y[idx] = p.y;
-        }
+    if (live && A.traj_x) {
+        A.traj_x[idx] = p.x;
+        A.traj_y[idx] = p.y;
     }
     float ymax_v = A.y_max;
-    asm volatile("" : "+v"(ymax_v));  // keep it in a VGPR (see clamp_position_p)
+    asm volatile("" : "+v"(ymax_v));  // keep it in a VGPR (a VOP3 takes one SGPR; see clamp_position_p)
     const unsigned tile_addr = lds_address(tile);
     unsigned pitch_bytes = (unsigned)LT_PITCH * 8u;
     asm volatile("" : "+s"(pitch_bytes));  // one SGPR for the whole kernel (a VOP3 literal is not encodable)
+    const f2 pmin = {A.lon_min, A.lat_min}, sc = {A.sx, A.sy};
+    // the common case needs the new longitude strictly inside these bounds (Q7 wrap / Q9 clamp otherwise)
+    const float xlo = A.cyclic ? -180.0f : A.x_min, xhi = A.cyclic ? 180.0f : A.x_max;
     const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
     const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;  // >= LT_COLS, LT_ROWS (checked by the launcher)
@@ -659,74 +666,94 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
     float wx[4], wy[4];
     for (int s = 0; s < A.nsteps; ++s) {
-        // ---- 1. Euler sample (global) and iteration 0's tap ---------------------------------
-        f2 c0 = {0.0f, 0.0f}, c1 = {0.0f, 0.0f};
-        f2 e = {0.0f, 0.0f};
-        constexpr int WOFF = ORDER == 3 ? 0 : LC_PAD_LO;  // padded window origin = (y0 + WOFF, x0 + WOFF)
-        TapL t = {0, 0, 0.0f, 0.0f};
-        if (live) {
-            c0 = index_coords(A, p);
-            t = tap_of(c0);
+        // ---- 1. Euler sample (global gather) ---------------------------------------------------
+        f2 c0 = (p - pmin) * sc;
+        f2 e;
+        {
+            TapL t = tap_of(c0);
+            // common case: 0 <= floor(c) <= n-2, i.e. c in [0, n-1) -- no wrap needed
+            bool bad = ((unsigned)t.x0 > (unsigned)(A.nx_f - 2)) | ((unsigned)t.y0 > (unsigned)(A.ny_f - 2));
             if (ORDER == 3) {
                 cubic_weights_f(t.tx, wx);
                 cubic_weights_f(t.ty, wy);
             }
             e = window_global<ORDER>(lvl, A, t, wx, wy);
-            p = dd * e + p;
-            clamp_position_p(A, p, ymax_v);
-            c1 = index_coords(A, p);
-            t = tap_of(c1);
+            f2 pn = dd * e + p;
+            pn.y = __builtin_amdgcn_fmed3f(pn.y, A.y_min, ymax_v);
+            bad |= !((pn.x > xlo) & (pn.x < xhi));
+            if (bad) {  // exact sequence
+                c0 = index_coords(A, p);
+                t = tap_of(c0);
+                if (ORDER == 3) {
+                    cubic_weights_f(t.tx, wx);
+                    cubic_weights_f(t.ty, wy);
+                }
+                e = window_global<ORDER>(lvl, A, t, wx, wy);
+                pn = dd * e + p;
+                clamp_position_p(A, pn, ymax_v);
+            }
+            p = pn;
         }
-        // ---- 2. anchor the tile on the patch's centre lane (first live lane if that one is dead) ----
-        const unsigned long long alive = __ballot(live);
-        int sox = 0, soy = 0;  // tile origin minus WOFF, in field-node coordinates (wave-uniform)
-        const bool have_tile = alive != 0ull && K > 0;
-        if (have_tile) {
+        f2 c = (p - pmin) * sc;  // iteration 0's coordinate (unwrapped; the iteration checks it)
+        // ---- 2. anchor the tile on the patch's centre lane -------------------------------------
+        // Tile origin (padded coordinates): centre of the window's predicted travel -- every iteration
+        // moves a parcel by about the Euler displacement (Q4).  Two v_readlane, no reduction.
+        int lo_x = 0x40000000, lo_y = 0x40000000, lim_x = 0, lim_y = 0;  // no tile: nothing is "inside"
+        unsigned base_addr = tile_addr;
+        if (K > 0) {
             constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
-            const int ref = (alive >> CENTRE) & 1ull ? CENTRE : (int)__ffsll((long long)alive) - 1;
-            // centre of the window's predicted travel: every iteration moves a parcel by about the
-            // Euler displacement (Q4)
-            const f2 dc = (c1 - c0) * kpred;
-            const int mx = t.x0 + (int)dc.x, my = t.y0 + (int)dc.y;
-            const int rxm = __builtin_amdgcn_readlane(mx, ref), rym = __builtin_amdgcn_readlane(my, ref);
-            const int ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);  // padded coordinates
+            const f2 dc = (c - c0) * kpred;
+            const int mx = (int)floor_to_uint(c.x) + (int)dc.x, my = (int)floor_to_uint(c.y) + (int)dc.y;
+            const int rxm = __builtin_amdgcn_readlane(mx, CENTRE), rym = __builtin_amdgcn_readlane(my, CENTRE);
+            const int ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
             const int oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
-            sox = ox - WOFF;
-            soy = oy - WOFF;
-        }
-        // ---- 3. stage ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) ---------------------------
-        __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
-        if (have_tile) {
-            const float *src = elv + ((size_t)__umul24((unsigned)(soy + WOFF), (unsigned)pad_cols) +
-                                      (unsigned)(sox + WOFF + st_col)) * 2;
+            // ---- 3. stage ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) -------------------------
+            __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
+            const float *src = elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)(ox + st_col)) * 2;
 #pragma unroll
             for (int r = 0; r < LT_ROWS; r += G::ROWS_PER_PASS) {
                 f4 v;
                 __builtin_memcpy(&v, src + (size_t)(r + st_row) * pad_cols * 2, 16);
                 *(f4 *)(tile + (r + st_row) * LT_PITCH + st_col) = v;
             }
+            __builtin_amdgcn_wave_barrier();
+            // window origins floor(c) the common case accepts: inside the tile AND in [0, n-2] (no wrap)
+            const int sox = ox - WOFF, soy = oy - WOFF;
+            const int hx = min(sox + LT_COLS - WIN, A.nx_f - 2), hy = min(soy + LT_ROWS - WIN, A.ny_f - 2);
+            const int lx = max(sox, 0), ly = max(soy, 0);
+            if (hx >= lx && hy >= ly) {
+                lo_x = lx;
+                lo_y = ly;
+                lim_x = hx - lx;
+                lim_y = hy - ly;
+                base_addr = tile_addr + (unsigned)(lx - sox) * 8u + (unsigned)(ly - soy) * ((unsigned)LT_PITCH * 8u);
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        // ---- 4. K iterations out of LDS (global gather for lanes whose window left the tile) ------
+        // ---- 4. K iterations out of LDS ----------------------------------------------------------
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (live) {
-                if (k > 0) t = tap_of(index_coords(A, p));
+            if (k > 0) c = (p - pmin) * sc;
+            TapL t = tap_of(c);
+            if (ORDER == 3) {
+                cubic_weights_f(t.tx, wx);
+                cubic_weights_f(t.ty, wy);
+            }
+            const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;  // the subtrahends are wave-uniform (SGPRs)
+            bool bad = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
+            const f2 w = window_lds<ORDER>(base_addr, pitch_bytes, rx, ry, t, wx, wy);
+            f2 pn = hd * (e + w) + p;
+            pn.y = __builtin_amdgcn_fmed3f(pn.y, A.y_min, ymax_v);
+            bad |= !((pn.x > xlo) & (pn.x < xhi));
+            if (bad) {  // exact sequence, global gather
+                t = tap_of(index_coords(A, p));
                 if (ORDER == 3) {
                     cubic_weights_f(t.tx, wx);
                     cubic_weights_f(t.ty, wy);
                 }
-                const int rx = t.x0 - sox, ry = t.y0 - soy;  // the subtrahends are wave-uniform (SGPRs)
-                const bool inside =
-                    have_tile && (unsigned)rx <= (unsigned)(LT_COLS - WIN) && (unsigned)ry <= (unsigned)(LT_ROWS - WIN);
-                f2 w;
-                if (inside)
-                    w = window_lds<ORDER>(tile_addr, pitch_bytes, rx, ry, t, wx, wy);
-                else
-                    w = window_global<ORDER>(elv, A, t, wx, wy);
-                p = hd * (e + w) + p;
-                clamp_position_p(A, p, ymax_v);
+                pn = hd * (e + window_global<ORDER>(elv, A, t, wx, wy)) + p;
+                clamp_position_p(A, pn, ymax_v);
             }
+            p = pn;
         }
         if (live && A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = p.x;
