@@ -365,10 +365,11 @@ __device__ __forceinline__ TapF locate_wrap_f(const AdvectArgs<float> &A, float 
 }
 
 __device__ __forceinline__ f2 fetch1_f(const float *__restrict__ lvl, const TapF &t, unsigned row_bytes) {
-    const char *p = (const char *)lvl + t.byte_off;
+    // two uniform bases + one 32-bit lane offset: both loads take the SGPR-base addressing form
+    const char *row0 = (const char *)lvl, *row1 = row0 + row_bytes;
     f4 a, b;
-    __builtin_memcpy(&a, p, 16);              // {u00, v00, u01, v01}
-    __builtin_memcpy(&b, p + row_bytes, 16);  // {u10, v10, u11, v11}
+    __builtin_memcpy(&a, row0 + t.byte_off, 16);  // {u00, v00, u01, v01}
+    __builtin_memcpy(&b, row1 + t.byte_off, 16);  // {u10, v10, u11, v11}
     const f2 r0 = a.xy + t.tx * (a.zw - a.xy);
     const f2 r1 = b.xy + t.tx * (b.zw - b.xy);
     return r0 + t.ty * (r1 - r0);
@@ -702,9 +703,9 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
         unsigned base_addr = tile_addr;
         if (K > 0) {
             constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
-            const f2 dc = (c - c0) * kpred;
-            const int mx = (int)floor_to_uint(c.x) + (int)dc.x, my = (int)floor_to_uint(c.y) + (int)dc.y;
-            const int rxm = __builtin_amdgcn_readlane(mx, CENTRE), rym = __builtin_amdgcn_readlane(my, CENTRE);
+            const f2 ca = (c - c0) * kpred + c;  // heuristic only: results do not depend on where the tile sits
+            const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
+            const int rym = __builtin_amdgcn_readlane((int)floor_to_uint(ca.y), CENTRE);
             const int ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
             const int oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
             // ---- 3. stage ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) -------------------------
