@@ -83,7 +83,7 @@ def run_c2(args, torch, flows, Engine, local_rank):
     def one():
         m = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         m[0].record()
-        f = eng.prepare_field(ud, vd, lat, lon, order)
+        f = eng.prepare_field(ud, vd, lat, lon, order, fuse_levels=args.fuse_levels)
         m[1].record()
         x, y = eng.advect(f, lat_d, lon_d, -900.0, K, order, True)
         m[2].record()
@@ -110,9 +110,10 @@ def run_c2(args, torch, flows, Engine, local_rank):
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {ny}x{nx} seeds = field nodes, moving ideal vortex, {nt} levels, "
-                               f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order},
+                               f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order,
+                   **({"fuse_levels": True} if args.fuse_levels else {})},
         "kernel_ms": ms,
-        "roofline": {"bound": "hbm", "kernel": "advect_kernel<double,%d>" % order, "achieved": ach,
+        "roofline": {"bound": "hbm", "kernel": "advect_kernel<double,%d%s>" % (order, ",fused" if args.fuse_levels else ""), "achieved": ach,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes_per_particle_timestep": bytes_pts},
     }), flush=True)
@@ -148,6 +149,9 @@ def main():
                     help="return_traj=True: also store the positions after every step (not the headline)")
     ap.add_argument("--wind-scale", type=float, default=1.0,
                     help="multiply the synthetic wind (stress case: stronger stretching; not the headline)")
+    ap.add_argument("--fuse-levels", action="store_true",
+                    help="c2 only: sample the fused image 2F[t]-F[t+1] once per SETTLS iteration in float64 too "
+                         "(rounding-level differences from the reference's two-sample order; default keeps that order)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c2"],
                     help="c3 (default, the headline): 4096^2 seeds on the 720x1440 fp32 flow; "
                          "c2: BASELINE configs[1], 1024^2 nodes, moving ideal vortex, 200 steps, fp64, N=1 only")

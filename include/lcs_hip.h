@@ -117,7 +117,9 @@ int lc_field_extrapolate(lc_ctx *ctx, const void *packed_dev, int dtype,
  *   packed_cub   image from lc_field_pack(order=3), or NULL when interp_order==1
  *   packed_ext   image from lc_field_extrapolate, or NULL.  NULL = two samples per
  *                SETTLS iteration in the reference's operation order (the float64
- *                default); non-NULL = one sample of the combined field (float32 path)
+ *                default, results identical to numpy/scipy's); non-NULL = one sample
+ *                of the combined field 2F[t]-F[t+1] (the float32 default; opt-in for
+ *                LC_F64, where it moves results by rounding only, ~1e-13 degrees)
  *   lat_min..lon_max   extremes of the FIELD coordinates (index scale, tools.py:21-22,
  *                and the clamp bounds, trajectory.py:63-66)
  *   seed_lat[ny], seed_lon[nx]   seed coordinates (dtype elements, device).  The

@@ -274,7 +274,10 @@ __device__ __forceinline__ T settls_bracket(const AdvectArgs<T> &A, T e, T c, T 
     return (e + T(2) * c) - n;
 }
 
-template <typename T, int ORDER, bool WRAP>
+// FUSED (opt-in, lc_advect with packed_ext in LC_F64): each SETTLS iteration samples the fused image
+// ext[t] = 2 F[t] - F[t+1] once instead of F[t] and F[t+1] separately.  Interpolation is linear in the
+// field, so the value differs from the reference's (e + 2c) - n only by rounding (~1 ulp of the wind).
+template <typename T, int ORDER, bool WRAP, bool FUSED = false>
 __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image, int iy, int ix) {
 #pragma clang fp contract(off)
     T x = A.seed_lon[ix];
@@ -290,6 +293,7 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
         A.traj_y[idx] = y;
     }
     const T *lvl = image + (size_t)A.t0 * A.level_elems;
+    const T *elv = FUSED ? A.ext + (size_t)A.t0 * A.level_elems : nullptr;
     for (int s = 0; s < A.nsteps; ++s) {
         const T *nxt = lvl + A.level_elems;
         Pair<T> e = sample<T, ORDER, WRAP>(lvl, A, x, y);        // trajectory.py:82-84
@@ -300,6 +304,13 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
         clamp_position<T>(A, x, y);
         for (int k = 0; k < A.K; ++k) {                          // :100
             const Tap<T> tap = locate<T, ORDER, WRAP>(A, x, y);  // one position, two time levels
+            if (FUSED) {
+                const Pair<T> w = fetch<T, ORDER>(elv, A, tap);
+                y = y + A.hdtcy * (e.v + w.v);
+                x = axpy<T>(hdtcx, e.u + w.u, x);
+                clamp_position<T>(A, x, y);
+                continue;
+            }
             Pair<T> c = fetch<T, ORDER>(lvl, A, tap);             // :105,107
             Pair<T> n = fetch<T, ORDER>(nxt, A, tap);             // :106,108
             c.u = round_sample<T>(A, c.u);
@@ -315,6 +326,7 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
             A.traj_y[(size_t)(s + 1) * plane + idx] = y;
         }
         lvl = nxt;
+        if (FUSED) elv += A.level_elems;
     }
     A.x_out[idx] = x;
     A.y_out[idx] = y;
@@ -786,21 +798,23 @@ struct LdsLaunch<float, ORDER> {
     }
 };
 
-template <typename T, int ORDER>
+template <typename T, int ORDER, bool FUSED>
 struct InteriorPath {
     static __device__ __forceinline__ void run(const AdvectArgs<T> &A, int iy, int ix) {
-        advect_seed<T, ORDER, true>(A, A.img, iy, ix);
+        advect_seed<T, ORDER, true, FUSED>(A, A.img, iy, ix);
     }
 };
-template <int ORDER>
-struct InteriorPath<float, ORDER> {
+template <int ORDER, bool FUSED>
+struct InteriorPath<float, ORDER, FUSED> {
     static __device__ __forceinline__ void run(const AdvectArgs<float> &A, int iy, int ix) {
-        advect_seed_f32<ORDER>(A, iy, ix);
+        advect_seed_f32<ORDER>(A, iy, ix);  // looks at A.ext itself
     }
 };
 
-template <typename T, int ORDER>
-__global__ void __launch_bounds__(BLOCK) advect_kernel(const AdvectArgs<T> A) {
+// double, order 1 sits at 69 VGPRs (7 waves per SIMD); asking for 8 costs nothing measurable per wave and
+// lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
+template <typename T, int ORDER, bool FUSED = false>
+__global__ void __launch_bounds__(BLOCK, (sizeof(T) == 8 && ORDER == 1) ? 8 : 1) advect_kernel(const AdvectArgs<T> A) {
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give
     // XCD k the k-th contiguous eighth of the tile list -- its L2 then serves one latitude band.
     const int per_xcd = (A.ntiles + 7) / 8;
@@ -815,7 +829,7 @@ __global__ void __launch_bounds__(BLOCK) advect_kernel(const AdvectArgs<T> A) {
     if (pole)
         advect_seed<T, 1, false>(A, A.lin, iy, ix);
     else
-        InteriorPath<T, ORDER>::run(A, iy, ix);
+        InteriorPath<T, ORDER, FUSED>::run(A, iy, ix);
 }
 
 template <typename T>
@@ -876,11 +890,16 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // LCS_LDS_TILES=0/1 overrides (profiling).
     bool use_lds = true;
     if (const char *ev = getenv("LCS_LDS_TILES")) use_lds = ev[0] == '1';
+    const bool fused64 = sizeof(T) == 8 && A.ext != nullptr;  // opt-in single-sample iterations in float64
     if (order == 3) {
-        if (!(use_lds && LdsLaunch<T, 3>::launch(A, grid, ctx->stream)))
+        if (fused64)
+            hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+        else if (!(use_lds && LdsLaunch<T, 3>::launch(A, grid, ctx->stream)))
             hipLaunchKernelGGL((advect_kernel<T, 3>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
     } else {
-        if (!(use_lds && LdsLaunch<T, 1>::launch(A, grid, ctx->stream)))
+        if (fused64)
+            hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+        else if (!(use_lds && LdsLaunch<T, 1>::launch(A, grid, ctx->stream)))
             hipLaunchKernelGGL((advect_kernel<T, 1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
     }
     LC_HIP_CHECK(hipGetLastError());

@@ -107,7 +107,8 @@ class Engine:
         ``fuse_levels``: also build ext[t] = 2 F[t] - F[t+1] so each SETTLS iteration takes one
         gather instead of two (linear interpolation => same value up to rounding).  Default: on for
         float32 (which cannot be bit-identical to scipy's double evaluation anyway), off for float64
-        (keeps the reference's operation order)."""
+        (keeps the reference's operation order and numpy/scipy's exact results; ``True`` there trades
+        that for speed -- positions move by ~1e-13 degrees)."""
         if interp_order not in (1, 3):
             raise ValueError(f"interp_order {interp_order} unsupported (1 and 3 are implemented; "
                              "0 fails in the reference too, LCS/tools.py:24-30)")

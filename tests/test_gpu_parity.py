@@ -441,3 +441,22 @@ def test_lcs_host_float32_route(eng):
         assert out["x_dep"].dtype == np.float32
         assert np.array_equal(out["x_dep"], _np(r["x_dep"])) and np.array_equal(out["y_dep"], _np(r["y_dep"]))
         assert np.array_equal(out["sigma"], _np(r["sigma"]))
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_float64_fused_levels_option(eng, O, order):
+    """prepare_field(fuse_levels=True) in float64: one sample of 2F[t]-F[t+1] per SETTLS iteration instead of
+    the reference's two.  Opt-in; results move by rounding only (the default path stays identical to the
+    oracle's operation order)."""
+    u, v, lat, lon = flows.config2(n=96, nt=13)
+    f_exact = eng.prepare_field(u, v, lat, lon, order)
+    f_fused = eng.prepare_field(u, v, lat, lon, order, fuse_levels=True)
+    assert f_exact.ext is None and f_fused.ext is not None
+    xe, ye = eng.advect(f_exact, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
+    xf, yf = eng.advect(f_fused, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
+    xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=order,
+                                  cyclic_xboundary=True)
+    for got, ref in ((xf, xo), (yf, yo)):
+        d = np.abs(_np(got) - ref)
+        assert np.minimum(d, np.abs(d - 360)).max() < 1e-10            # rounding-level (fp64 tolerance, degrees)
+    assert np.abs(_np(xe) - xo).max() < 1e-9 and np.abs(_np(ye) - yo).max() < 1e-9
