@@ -1,0 +1,72 @@
+"""Reduce the SQ / TCP / GRBM counter passes of one bench command (gpurun_out/<tag>/p*/ as written by the
+--pmc commands in profiles/README.md) to <out_prefix>_pmc_sq_tcp.json, with the derived per-unit figures
+DESIGN.md quotes.
+
+    python profiles/summarize_sq.py <run_dir> <out_prefix> '<workload json>' <nsteps>
+
+Derived (per launch of each advect kernel; W = waves, S = time steps per launch):
+  valu_instr_per_wave_timestep   SQ_INSTS_VALU / (W*S)
+  salu_instr_per_wave_timestep   (SQ_INSTS_SALU + SQ_INSTS_BRANCH) / (W*S)
+  valu_issue_frac                SQ_ACTIVE_INST_VALU / (cycles * CUs)      -- each SIMD issues one VALU op per 4 cycles
+  scalar_issue_frac              (SQ_INSTS_SALU + SQ_INSTS_BRANCH) / (cycles * CUs)   -- one scalar pipe per CU
+  lds_active_frac                SQ_LDS_IDX_ACTIVE / (cycles * CUs)
+  lds_bank_conflict_frac         SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  tcp_lookups_per_cu_cycle       TCP_TOTAL_CACHE_ACCESSES / (cycles * CUs)
+with cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs) and CUs = 256.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+CUS = 256
+
+
+def short(name):
+    n = name.replace("void ", "")
+    if "(anonymous namespace)::" in n:
+        n = n.split("(anonymous namespace)::", 1)[1]
+    return n.split("(")[0]
+
+
+def main():
+    run, out, workload, nsteps = sys.argv[1], sys.argv[2], json.loads(sys.argv[3]), int(sys.argv[4])
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(os.path.join(run, "p*", "*", "*_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k.startswith("advect"):
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    kernels = {}
+    for k, d in agg.items():
+        c = {n: sum(v) / len(v) for n, v in d.items()}
+        der = {}
+        if "GRBM_GUI_ACTIVE" in c and "SQ_WAVES" in c:
+            cu_cycles = c["GRBM_GUI_ACTIVE"] / 8 * CUS
+            ws = c["SQ_WAVES"] * nsteps
+            sal = c.get("SQ_INSTS_SALU", 0) + c.get("SQ_INSTS_BRANCH", 0)
+            der = {
+                "valu_instr_per_wave_timestep": c.get("SQ_INSTS_VALU", 0) / ws,
+                "salu_instr_per_wave_timestep": sal / ws,
+                "lds_instr_per_wave_timestep": c.get("SQ_INSTS_LDS", 0) / ws,
+                "vmem_rd_instr_per_wave_timestep": c.get("SQ_INSTS_VMEM_RD", 0) / ws,
+                "valu_issue_frac": c.get("SQ_ACTIVE_INST_VALU", 0) / cu_cycles,
+                "scalar_issue_frac": sal / cu_cycles,
+                "lds_active_frac": c.get("SQ_LDS_IDX_ACTIVE", 0) / cu_cycles,
+                "lds_bank_conflict_frac": (c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else 0.0,
+                "tcp_lookups_per_cu_cycle": c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / cu_cycles,
+                "l2_hit_frac": (c.get("TCC_HIT_sum", 0) / (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))) if c.get("TCC_HIT_sum") else None,
+            }
+        kernels[k] = {**c, "derived": der}
+    json.dump({"workload": workload, "kernels": kernels,
+               "note": "rocprofv3 --pmc passes (counter sets in profiles/README.md) over bench.py --steps 1 --warmup 0; "
+                       "per-launch averages; GRBM_GUI_ACTIVE is summed over 8 XCDs"},
+              open(out + "_pmc_sq_tcp.json", "w"), indent=1, sort_keys=True)
+    for k, v in kernels.items():
+        print(k, json.dumps(v["derived"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
