@@ -624,7 +624,7 @@ __device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 
 // case never faults on garbage: LDS reads cannot fault (out-of-range DS reads return 0) and the global
 // gather clamps its indices.  Lanes without a seed (grid edge, pole rows) shadow a neighbouring seed so
 // that they follow the same path; only their stores are masked.
-template <int ORDER, int KFIX>
+template <int ORDER, int KFIX, bool CYCLIC>
 __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<float> A) {
 #pragma clang fp contract(fast)
     const int K = KFIX >= 0 ? KFIX : A.K;  // KFIX: SETTLS_order known at compile time (the iteration loop unrolls)
@@ -670,7 +670,9 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     asm volatile("" : "+s"(pitch_bytes));  // one SGPR for the whole kernel (a VOP3 literal is not encodable)
     const f2 pmin = {A.lon_min, A.lat_min}, sc = {A.sx, A.sy};
     // the common case needs the new longitude strictly inside these bounds (Q7 wrap / Q9 clamp otherwise)
-    const float xlo = A.cyclic ? -180.0f : A.x_min, xhi = A.cyclic ? 180.0f : A.x_max;
+    // (cyclic: |x| < 180 is one compare with a source modifier; hence the template parameter)
+    const float xlo = A.x_min, xhi = A.x_max;
+    auto x_needs_care = [&](float x) { return CYCLIC ? !(fabsf(x) < 180.0f) : !((x > xlo) & (x < xhi)); };
     const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
     const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;  // >= LT_COLS, LT_ROWS (checked by the launcher)
@@ -678,9 +680,35 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     // staging geometry of this lane: ROWS_PER_PASS tile rows per pass, 16 B (2 nodes) per lane
     const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
     float wx[4], wy[4];
+    f2 dprev = {0.0f, 0.0f};  // previous level's Euler displacement in index space: predicts this level's travel
+    constexpr int NPASS = LT_ROWS / G::ROWS_PER_PASS;
+    // order 3 keeps the tile loads behind the Euler sample: 16 more live VGPRs across it cost two waves
+    // per SIMD, and that kernel is LDS-bandwidth bound anyway (measured: 21.7 vs 21.0-21.2 ms)
+    constexpr bool PREFETCH = ORDER == 1;
+    constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
     for (int s = 0; s < A.nsteps; ++s) {
-        // ---- 1. Euler sample (global gather) ---------------------------------------------------
         f2 c0 = (p - pmin) * sc;
+        // ---- 1. anchor the tile and issue its loads ------------------------------------------------
+        // Tile origin (padded coordinates): centre of the windows' predicted travel.  The Euler step and
+        // every iteration move a parcel by about one Euler displacement (Q4), and that displacement
+        // changes little from one 15-minute level to the next, so the previous level's stands in for this
+        // one's -- which lets the tile loads fly together with the Euler gather instead of after it (one
+        // exposed global round trip per level, not two: 8.1 -> 7.65 ms on C3).  Heuristic only: results do
+        // not depend on where the tile sits.  Two v_readlane, no reduction.
+        int ox = 0, oy = 0;
+        f4 stage[NPASS];
+        auto anchor_and_load = [&](f2 ca) {
+            const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
+            const int rym = __builtin_amdgcn_readlane((int)floor_to_uint(ca.y), CENTRE);
+            ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
+            oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
+            const float *src = elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)(ox + st_col)) * 2;
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r)
+                __builtin_memcpy(&stage[r], src + (size_t)(r * G::ROWS_PER_PASS + st_row) * pad_cols * 2, 16);
+        };
+        if (PREFETCH && K > 0) anchor_and_load(dprev * (1.0f + kpred) + c0);
+        // ---- 2. Euler sample (global gather) ---------------------------------------------------
         f2 e;
         {
             TapL t = tap_of(c0);
@@ -693,7 +721,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             e = window_global<ORDER>(lvl, A, t, wx, wy);
             f2 pn = dd * e + p;
             pn.y = __builtin_amdgcn_fmed3f(pn.y, A.y_min, ymax_v);
-            bad |= !((pn.x > xlo) & (pn.x < xhi));
+            bad |= x_needs_care(pn.x);
             if (bad) {  // exact sequence
                 c0 = index_coords(A, p);
                 t = tap_of(c0);
@@ -708,27 +736,15 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             p = pn;
         }
         f2 c = (p - pmin) * sc;  // iteration 0's coordinate (unwrapped; the iteration checks it)
-        // ---- 2. anchor the tile on the patch's centre lane -------------------------------------
-        // Tile origin (padded coordinates): centre of the window's predicted travel -- every iteration
-        // moves a parcel by about the Euler displacement (Q4).  Two v_readlane, no reduction.
+        dprev = c - c0;
+        if (!PREFETCH && K > 0) anchor_and_load(dprev * kpred + c);  // this level's own displacement
+        // ---- 3. tile into LDS: ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) ----------------------
         int lo_x = 0x40000000, lo_y = 0x40000000, lim_x = 0, lim_y = 0;  // no tile: nothing is "inside"
         unsigned base_addr = tile_addr;
         if (K > 0) {
-            constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
-            const f2 ca = (c - c0) * kpred + c;  // heuristic only: results do not depend on where the tile sits
-            const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
-            const int rym = __builtin_amdgcn_readlane((int)floor_to_uint(ca.y), CENTRE);
-            const int ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
-            const int oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
-            // ---- 3. stage ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) -------------------------
             __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
-            const float *src = elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)(ox + st_col)) * 2;
 #pragma unroll
-            for (int r = 0; r < LT_ROWS; r += G::ROWS_PER_PASS) {
-                f4 v;
-                __builtin_memcpy(&v, src + (size_t)(r + st_row) * pad_cols * 2, 16);
-                *(f4 *)(tile + (r + st_row) * LT_PITCH + st_col) = v;
-            }
+            for (int r = 0; r < NPASS; ++r) *(f4 *)(tile + (r * G::ROWS_PER_PASS + st_row) * LT_PITCH + st_col) = stage[r];
             __builtin_amdgcn_wave_barrier();
             // window origins floor(c) the common case accepts: inside the tile AND in [0, n-2] (no wrap)
             const int sox = ox - WOFF, soy = oy - WOFF;
@@ -756,7 +772,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             const f2 w = window_lds<ORDER>(base_addr, pitch_bytes, rx, ry, t, wx, wy);
             f2 pn = hd * (e + w) + p;
             pn.y = __builtin_amdgcn_fmed3f(pn.y, A.y_min, ymax_v);
-            bad |= !((pn.x > xlo) & (pn.x < xhi));
+            bad |= x_needs_care(pn.x);
             if (bad) {  // exact sequence, global gather
                 t = tap_of(index_coords(A, p));
                 if (ORDER == 3) {
@@ -790,10 +806,15 @@ struct LdsLaunch<float, ORDER> {
     static bool launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
         // the fixed-size tile must fit inside one padded time level
         if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return false;
-        if (A.K == 4)  // the setting the reference's example and drivers use
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4>), dim3(grid), dim3(BLOCK), 0, st, A);
+        // K = 4 is the setting the reference's example and drivers use
+        if (A.K == 4 && A.cyclic)
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, true>), dim3(grid), dim3(BLOCK), 0, st, A);
+        else if (A.K == 4)
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, false>), dim3(grid), dim3(BLOCK), 0, st, A);
+        else if (A.cyclic)
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, true>), dim3(grid), dim3(BLOCK), 0, st, A);
         else
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1>), dim3(grid), dim3(BLOCK), 0, st, A);
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, false>), dim3(grid), dim3(BLOCK), 0, st, A);
         return true;
     }
 };
