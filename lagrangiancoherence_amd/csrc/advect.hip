@@ -679,6 +679,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     const float kpred = 0.5f * (float)(K > 0 ? K - 1 : 0);  // half of the predicted travel, in Euler displacements
     // staging geometry of this lane: ROWS_PER_PASS tile rows per pass, 16 B (2 nodes) per lane
     const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
+    const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 8u;  // bytes inside a level
     float wx[4], wy[4];
     f2 dprev = {0.0f, 0.0f};  // previous level's Euler displacement in index space: predicts this level's travel
     constexpr int NPASS = LT_ROWS / G::ROWS_PER_PASS;
@@ -702,10 +703,11 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             const int rym = __builtin_amdgcn_readlane((int)floor_to_uint(ca.y), CENTRE);
             ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
             oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
-            const float *src = elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)(ox + st_col)) * 2;
+            // uniform base (SGPR pair) + this lane's constant 32-bit offset: no per-level address arithmetic
+            const char *src = (const char *)elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)ox) * 8;
 #pragma unroll
             for (int r = 0; r < NPASS; ++r)
-                __builtin_memcpy(&stage[r], src + (size_t)(r * G::ROWS_PER_PASS + st_row) * pad_cols * 2, 16);
+                __builtin_memcpy(&stage[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_off, 16);
         };
         if (PREFETCH && K > 0) anchor_and_load(dprev * (1.0f + kpred) + c0);
         // ---- 2. Euler sample (global gather) ---------------------------------------------------
