@@ -208,6 +208,9 @@ def main():
     dlat, dlon = float(slat[1] - slat[0]), float(slon[1] - slon[0])
     torch.cuda.synchronize()
 
+    # LCS_NATIVE_HALO=1: halo exchange through the C ABI (lc_halo_exchange, RCCL directly) instead of
+    # torch.distributed point-to-point (the default; both are RCCL over xGMI with the nccl backend)
+    comm = sharded.native_comm(eng, rank, world) if (world > 1 and os.environ.get("LCS_NATIVE_HALO")) else None
     ev = {k: [] for k in ("pack", "advect", "halo", "sigma")}
 
     def one_step(record: bool):
@@ -219,7 +222,7 @@ def main():
                          ny_global=ny_global, halo=(n_lo, n_hi), return_traj=args.traj)
         x_ext, y_ext = res[0], res[1]
         marks[2].record()
-        sharded.halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world)
+        sharded.halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world, engine=eng, comm=comm)
         in_row0 = lo - n_lo
         marks[3].record()
         sig = eng.sigma(x_ext, y_ext, slat_d[in_row0:in_row0 + x_ext.shape[0]], dlat, dlon, ny_global=ny_global,

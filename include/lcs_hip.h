@@ -52,7 +52,8 @@ enum lc_status {
     LC_EINVAL = -1,       /* bad argument (null pointer, bad size, bad enum) */
     LC_EUNSUPPORTED = -2, /* e.g. interp_order not in {1,3}                  */
     LC_EHIP = -3,         /* a HIP runtime call failed                       */
-    LC_ENOMEM = -4
+    LC_ENOMEM = -4,
+    LC_ERCCL = -5         /* RCCL missing or an RCCL call failed             */
 };
 
 enum lc_tensor_layout {
@@ -208,6 +209,31 @@ int lc_gaussian_filter(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int n
 int lc_ridge_classify(lc_ctx *ctx, const void *hxx, const void *hxy, const void *hyy,
                       const void *gx, const void *gy, size_t n, double tolerance,
                       void *mask_out, void *eigmin_out, void *dt_out, void *eigvec_out);
+
+/* ---- multi-GPU: halo exchange on RCCL ----------------------------------------
+ * New (the reference is single-process).  One process per GPU,
+ * seed rows block-partitioned, wind replicated; lc_advect needs no communication
+ * (row0 / ny_global).  Between lc_advect and lc_sigma every rank needs the 2 boundary
+ * rows of (x_dep, y_dep) of the previous and the next rank (4th-order stencil,
+ * LCS/tools.py:202-207): lc_halo_exchange does that in place, point-to-point over
+ * RCCL (xGMI), on the context's stream, non-periodic in rank, no collective.
+ *
+ *   lc_comm_unique_id   rank 0 makes the 128-byte id; the caller hands it to every rank
+ *                       (MPI, a file, torch.distributed ...)
+ *   lc_comm_create      collective over the nranks processes; ctx fixes the device
+ *   lc_halo_exchange    x_ext, y_ext: [n_rows][nx] device buffers whose middle
+ *                       n_rows - n_lo - n_hi rows hold this rank's departure points
+ *                       (write them there with lc_advect on a sub-view); the first n_lo /
+ *                       last n_hi rows receive the neighbours' boundary rows.  n_lo must be
+ *                       2 except on rank 0 (0), n_hi 2 except on the last rank (0).
+ * RCCL is loaded at run time (dlopen), shared with the host process if it already
+ * carries one; without it these calls return LC_ERCCL and everything else works. */
+typedef struct lc_comm lc_comm;
+int lc_comm_unique_id(void *id_out, size_t id_bytes /* >= 128 */);
+int lc_comm_create(lc_ctx *ctx, int nranks, int rank, const void *id, size_t id_bytes, lc_comm **out);
+int lc_comm_destroy(lc_comm *comm);
+int lc_halo_exchange(lc_ctx *ctx, lc_comm *comm, void *x_ext, void *y_ext, int dtype,
+                     int n_rows, int nx, int n_lo, int n_hi);
 
 /* ---- one-call host entry point ----------------------------------------------
  * What a reference-side binding would call from LCS.__call__ (LCS/LCS.py:129-157):

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblcs_hip.so")
 
 LC_F32, LC_F64, LC_F64_WIND_F32 = 0, 1, 2
-LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM = 0, -1, -2, -3, -4
+LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM, LC_ERCCL = 0, -1, -2, -3, -4, -5
 LC_LAYOUT_REFERENCE, LC_LAYOUT_PHYSICAL = 0, 1
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
@@ -41,6 +41,10 @@ PROTOTYPES = {
     "lc_fourth_order_derivative": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lc_gaussian_filter": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp]),
     "lc_ridge_classify": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _d, _vp, _vp, _vp, _vp]),
+    "lc_comm_unique_id": (_i, [_vp, _sz]),
+    "lc_comm_create": (_i, [_vp, _i, _i, _vp, _sz, C.POINTER(_vp)]),
+    "lc_comm_destroy": (_i, [_vp]),
+    "lc_halo_exchange": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "lc_lcs_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i,
                          _d, _i, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _vp]),
 }
@@ -49,7 +53,7 @@ _lib = None
 
 
 class LCSError(RuntimeError):
-    """A C-ABI call returned LC_EHIP / LC_ENOMEM."""
+    """A C-ABI call returned LC_EHIP / LC_ERCCL."""
 
 
 def load(path: str | None = None):

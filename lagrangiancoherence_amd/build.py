@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblcs_hip.so")
-SOURCES = ["api.hip", "pack.hip", "advect.hip", "sigma.hip", "ridges.hip"]
+SOURCES = ["api.hip", "pack.hip", "advect.hip", "sigma.hip", "ridges.hip", "halo.hip"]
 ARCH = "gfx950"
 
 
@@ -40,7 +40,7 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> 
         return LIB
     cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", *extra_flags,
-           "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
+           "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

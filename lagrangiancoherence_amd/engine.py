@@ -272,6 +272,37 @@ class Engine:
                                                self._ptr(vec) if return_eigvec else None), self.lib)
         return (mask, eigmin, dt, vec) if return_eigvec else (mask, eigmin, dt)
 
+    # ------------------------------------------------------------------ multi-GPU (RCCL through the C ABI)
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self) -> bytes:
+        """The id rank 0 creates and every rank passes to :meth:`comm_create` (``lc_comm_unique_id``)."""
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        _capi.check(self.lib.lc_comm_unique_id(buf, self.COMM_ID_BYTES), self.lib)
+        return buf.raw
+
+    def comm_create(self, nranks: int, rank: int, unique_id: bytes):
+        """RCCL communicator over ``nranks`` processes, this one on this engine's GPU (collective call)."""
+        comm = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), self.COMM_ID_BYTES)
+        _capi.check(self.lib.lc_comm_create(self.ctx, int(nranks), int(rank), buf, self.COMM_ID_BYTES, C.byref(comm)),
+                    self.lib)
+        return comm
+
+    def comm_destroy(self, comm):
+        if comm:
+            self.lib.lc_comm_destroy(comm)
+
+    def halo_exchange(self, comm, x_ext, y_ext, n_lo: int, n_hi: int):
+        """In-place 2-row halo exchange of the departure points with the previous / next rank
+        (``lc_halo_exchange``: RCCL send/recv on the current stream, no staging copies)."""
+        if x_ext.shape != y_ext.shape or x_ext.dtype != y_ext.dtype or not (x_ext.is_contiguous() and y_ext.is_contiguous()):
+            raise ValueError("x_ext and y_ext must be contiguous (rows, nx) tensors of one dtype")
+        dtype = np.dtype(str(x_ext.dtype).replace("torch.", ""))
+        self._use_current_stream()
+        _capi.check(self.lib.lc_halo_exchange(self.ctx, comm, self._ptr(x_ext), self._ptr(y_ext), _NP2LC[dtype],
+                                              int(x_ext.shape[0]), int(x_ext.shape[1]), int(n_lo), int(n_hi)), self.lib)
+
     def gaussian_filter(self, a, sigma):
         """scipy.ndimage.gaussian_filter(a, sigma) on the device (LCS/LCS.py:187-190)."""
         torch = self.torch

@@ -19,7 +19,7 @@ from __future__ import annotations
 HALO = 2  # rows; LCS/tools.py:202-207 (4th-order, +-2 points), SURVEY Q12
 
 __all__ = ["HALO", "row_partition", "halo_rows", "halo_exchange", "halo_exchange_into", "ensemble_partition",
-           "sharded_lcs", "ensemble_lcs"]
+           "sharded_lcs", "ensemble_lcs", "native_comm"]
 
 
 def row_partition(ny_global: int, world: int, rank: int):
@@ -45,8 +45,26 @@ def ensemble_partition(n_members: int, world: int, rank: int):
     return list(range(lo, lo + base + (1 if rank < rem else 0)))
 
 
-def halo_exchange_into(x_ext, y_ext, n_lo: int, n_hi: int, rank: int, world: int, group=None):
-    """In-place halo exchange.  ``x_ext``, ``y_ext``: ``(n_lo + n + n_hi, nx)`` buffers whose middle ``n``
+def native_comm(engine, rank: int, world: int, group=None):
+    """RCCL communicator of the C ABI (``lc_comm_create``) for this engine's GPU, created once and kept on
+    the engine.  Rank 0 makes the id; ``torch.distributed`` (any backend) only carries those 128 bytes."""
+    import torch.distributed as dist
+    comm = getattr(engine, "_lc_comm", None)
+    if comm is None:
+        box = [engine.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        comm = engine.comm_create(world, rank, box[0])
+        engine._lc_comm = comm
+    return comm
+
+
+def halo_exchange_into(x_ext, y_ext, n_lo: int, n_hi: int, rank: int, world: int, group=None, engine=None, comm=None):
+    """In-place halo exchange.  With ``engine`` and ``comm`` (see :func:`native_comm`) the exchange is the C
+    ABI's ``lc_halo_exchange`` (RCCL send/recv straight from / into the buffers, no staging copies);
+    otherwise ``torch.distributed`` point-to-point as described below.
+
+    ``x_ext``, ``y_ext``: ``(n_lo + n + n_hi, nx)`` buffers whose middle ``n``
     rows hold this rank's departure points; the first ``n_lo`` / last ``n_hi`` rows are filled with the
     neighbours' boundary rows.  One message per neighbour per direction carries both arrays
     (2 rows x nx x 2 arrays: 64 KiB at nx=4096 fp32 -- latency-bound on xGMI; no collective)."""
@@ -57,6 +75,9 @@ def halo_exchange_into(x_ext, y_ext, n_lo: int, n_hi: int, rank: int, world: int
     n = x_ext.shape[0] - n_lo - n_hi
     if n < HALO:
         raise ValueError("local block thinner than the halo")
+    if comm is not None:
+        engine.halo_exchange(comm, x_ext, y_ext, n_lo, n_hi)
+        return
     # gloo cannot move device tensors: stage the (tiny) messages through the host.  Only used when
     # rehearsing the N>1 path without RCCL (several ranks on one GPU); nccl sends device memory.
     via_host = x_ext.is_cuda and dist.get_backend(group) == "gloo"
@@ -104,12 +125,13 @@ def halo_exchange(x, y, rank: int, world: int, ny_global: int, lo: int, hi: int,
 
 def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, world: int, SETTLS_order=0,
                 interp_order=1, cyclic_xboundary=True, t0=0, nsteps=None, fd_fp32_cast=True,
-                tensor_layout="reference", group=None, redundant_halo=False):
+                tensor_layout="reference", group=None, redundant_halo=False, native_halo=False):
     """This rank's rows of (sigma, x_dep, y_dep) for a row-sharded seed grid.
 
     ``redundant_halo=True`` advects the halo rows locally instead of exchanging them
     (0.1 % extra work at 4096 rows/GPU); the results are bit-identical and the
-    tests use it to check the exchange.
+    tests use it to check the exchange.  ``native_halo=True`` exchanges through the C ABI
+    (``lc_halo_exchange``, RCCL directly) instead of ``torch.distributed`` point-to-point.
     """
     import numpy as np
     seed_lat_global = np.asarray(seed_lat_global, dtype=field.dtype)
@@ -126,7 +148,8 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
     else:
         x_ext, y_ext = engine.advect(field, seed_lat_global[lo:hi], seed_lon, timestep, SETTLS_order, interp_order,
                                      cyclic_xboundary, t0, nsteps, row0=lo, ny_global=nyg, halo=(n_lo, n_hi))
-        halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world, group)
+        comm = native_comm(engine, rank, world, group) if (native_halo and world > 1) else None
+        halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world, group, engine=engine, comm=comm)
         in_row0 = lo - n_lo
         x, y = x_ext[n_lo:n_lo + hi - lo], y_ext[n_lo:n_lo + hi - lo]
     dlat = float(seed_lat_global[1] - seed_lat_global[0])

@@ -59,3 +59,33 @@ def test_sharded_engine_bit_identical_to_unsharded(world, order):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_native_rccl_communicator_single_rank():
+    """C-ABI communicator / halo entry points on one GPU: RCCL resolves at run time, a 1-rank communicator is
+    created and destroyed, the exchange of a 1-rank grid is a no-op, and bad halo sizes are refused.  (The
+    send/recv path itself needs two GPUs; the CPU tests cover the row bookkeeping it shares with the
+    torch.distributed path.)"""
+    import numpy as np
+    import torch
+    from lagrangiancoherence_amd.engine import Engine
+    from lagrangiancoherence_amd import sharded
+    eng = Engine(0)
+    uid = eng.comm_unique_id()
+    assert isinstance(uid, bytes) and len(uid) == 128 and any(uid)
+    comm = eng.comm_create(1, 0, uid)
+    x = torch.arange(12 * 16, dtype=torch.float32, device="cuda").reshape(12, 16).contiguous()
+    y = -x.clone()
+    x0, y0 = x.clone(), y.clone()
+    eng.halo_exchange(comm, x, y, 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x0) and torch.equal(y, y0)
+    with pytest.raises(ValueError):
+        eng.halo_exchange(comm, x, y, 2, 0)                # rank 0 of 1 has no neighbour below
+    with pytest.raises(ValueError):
+        eng.comm_create(2, 5, uid)                         # rank outside [0, nranks)
+    eng.comm_destroy(comm)
+    # the sharded driver with native_halo on a 1-rank grid takes the same code path as without
+    assert sharded.native_comm(eng, 0, 1) is not None
+    eng.comm_destroy(eng._lc_comm)
+    eng.close()
