@@ -108,20 +108,27 @@ __device__ void prefilter_line_blocked(T *c, size_t stride, int n) {
         prefilter_line<T>(c, stride, n);
         return;
     }
-    const double zn1 = pow(z, (double)(n - 1));
-    double c0 = gain * (double)c[0] + zn1 * (gain * (double)c[(size_t)(n - 1) * stride]);
+    // Causal initial value (scipy _init_causal_mirror).  For n >= 64 the mirrored terms carry
+    // z^(n-1) <= 1e-36 and the direct terms beyond the 64th are below |z|^64 = 2.5e-37 of the line's
+    // scale -- far under double rounding -- so they are not read (same horizon as the longitude sweep).
+    constexpr int HORIZON = 64;
+    const bool mirrored = n < HORIZON;
+    const double zn1 = mirrored ? pow(z, (double)(n - 1)) : 0.0;
+    double c0 = gain * (double)c[0];
+    if (mirrored) c0 += zn1 * (gain * (double)c[(size_t)(n - 1) * stride]);
     double zi = z;
-    for (int i0 = 1; i0 < n - 1 && zi != 0.0; i0 += B) {
+    const int last = mirrored ? n - 1 : HORIZON;  // direct terms i = 1 .. last-1
+    for (int i0 = 1; i0 < last; i0 += B) {
         double a[B], b[B];
 #pragma unroll
         for (int q = 0; q < B; ++q) {
             const int i = min(i0 + q, n - 2);
             a[q] = (double)c[(size_t)i * stride];
-            b[q] = (double)c[(size_t)(n - 1 - i) * stride];
+            b[q] = mirrored ? (double)c[(size_t)(n - 1 - i) * stride] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < B; ++q) {
-            if (i0 + q < n - 1) {
+            if (i0 + q < last) {
                 c0 += zi * (gain * a[q] + zn1 * gain * b[q]);
                 zi *= z;
             }
