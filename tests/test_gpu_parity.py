@@ -460,3 +460,29 @@ def test_float64_fused_levels_option(eng, O, order):
         d = np.abs(_np(got) - ref)
         assert np.minimum(d, np.abs(d - 360)).max() < 1e-10            # rounding-level (fp64 tolerance, degrees)
     assert np.abs(_np(xe) - xo).max() < 1e-9 and np.abs(_np(ye) - yo).max() < 1e-9
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_non_finite_and_huge_wind_values_stay_contained(eng, dtype):
+    """NaN, +-inf and 1e30 m/s at a few wind nodes: every kernel variant finishes (the rare-case branches
+    of the fast float kernel see NaN/garbage coordinates), latitudes stay inside the clamp bounds (Q8: a NaN
+    latitude becomes y_min), and at order 1 only parcels that touched a poisoned cell are affected."""
+    u, v, lat, lon = flows.era5_like(nt=9, ny=90, nx=180)
+    u, v, lat, lon = (a.astype(dtype) for a in (u, v, lat, lon))
+    u[3, 40, 60] = np.nan
+    v[5, 20, 100] = np.inf
+    u[2, 70, 10] = -np.inf
+    v[1, 5, 5] = 1e30
+    u[6, 80, 170] = -1e30
+    slat, slon = flows.seed_grid(300, 400, lat, lon)
+    for order in (1, 3):
+        f = eng.prepare_field(u, v, lat, lon, order)
+        for cyclic in (True, False):
+            x, y = eng.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=order, cyclic_xboundary=cyclic)
+            xn, yn = _np(x), _np(y)
+            assert np.nanmin(yn) >= lat.min() and np.nanmax(yn) <= lat.max()
+            assert not np.isnan(yn).any()                                      # Q8
+            if order == 1:
+                assert (~np.isfinite(xn)).mean() < 0.01
+            sig = _np(eng.sigma(x, y, slat, slat[1] - slat[0], slon[1] - slon[0]))
+            assert sig.shape == xn.shape
