@@ -312,7 +312,7 @@ def main():
                     "HBM-traffic, figure (SURVEY 8d)",
         },
         "roofline_sigma": {
-            "bound": "hbm", "kernel": "sigma_kernel<float,float>", "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
+            "bound": "hbm", "kernel": "sigma_kernel_f32", "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": sigma_gbps / copy_gbps,
             "traffic": tr_sig[0] if tr_sig else None,
             "algorithmic_bytes_per_cell": 3 * s_p,
