@@ -808,6 +808,10 @@ struct LdsLaunch<float, ORDER> {
     static bool launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
         // the fixed-size tile must fit inside one padded time level
         if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return false;
+        // SETTLS_order = 0 (the library default): one Euler sample per level and nothing to stage a tile
+        // for -- the direct-gather kernel is the faster one (2.2 vs 2.45 ms on C3; an Euler-from-LDS variant
+        // with its tile loaded a level ahead measured 2.5 ms)
+        if (A.K == 0) return false;
         // K = 4 is the setting the reference's example and drivers use
         if (A.K == 4 && A.cyclic)
             hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, true>), dim3(grid), dim3(BLOCK), 0, st, A);
