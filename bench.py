@@ -322,7 +322,7 @@ def main():
     # ---- CPU baseline: the oracle (numpy+scipy port) on a bounded sample, rank 0, N=1 only ----
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         from oracle import lcs_oracle as O
-        n_s, st_s = 1024, 32
+        n_s, st_s = 1024, min(32, nsteps)
         sl, so = flows.seed_grid(n_s, n_s, lat, lon)
         c0 = time.perf_counter()
         O.lcs(u[:st_s + 1], v[:st_s + 1], lat, lon, timestep=dt, SETTLS_order=K, interp_order=order,
