@@ -28,7 +28,9 @@ namespace {
 
 // 8 x 32 seeds per workgroup: each wave owns an 8 x 8 patch.  Measured on C3 (ms, direct kernel):
 // 64x4 17.9, 32x8 12.6, 16x16 11.2, 8x32 10.9, 4x64 10.85, 2x128 11.1, 1x256 13.5 -- compact patches
-// touch the fewest distinct cache lines per gather.
+// touch the fewest distinct cache lines per gather.  Four waves stacked in latitude per workgroup (no
+// barrier ties them; it decides which waves share a CU's vector L1): 1 / 4 / 8 / 16 waves measure
+// 8.3 / 7.6 / 8.1 / 9.1 ms with the LDS kernel, 2x2 and 4x1 arrangements 7.7 and 8.4.
 constexpr int TILE_W = 8;
 constexpr int TILE_H = 32;
 constexpr int BLOCK = TILE_W * TILE_H;
@@ -498,14 +500,16 @@ __device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
 // A wave's 64 seeds (8 x 8 patch) sit within a few field cells of each other and a SETTLS
 // sub-step moves them a fraction of a cell, so the K iterations of one time level read a
 // window of ext[t] a few nodes wide.  Per time level each WAVE:
-//   1. takes the Euler sample from global memory and locates iteration 0's tap;
-//   2. anchors a fixed-size tile (TileGeom<ORDER> nodes) on the patch's centre lane, shifted half
-//      way along that lane's predicted travel (Euler displacement x (K-1)) -- two v_readlane,
-//      no reduction;
-//   3. copies the tile of ext[t] into its own LDS region with coalesced 16-byte row loads;
+//   1. anchors a fixed-size tile (TileGeom<ORDER> nodes) on the patch's centre lane, shifted to the
+//      middle of that lane's predicted travel -- two v_readlane, no reduction -- and issues the
+//      tile's coalesced 16-byte row loads.  Order 1 predicts the travel from the PREVIOUS level's
+//      Euler displacement, so these loads fly together with step 2's gather; order 3 (4 loads per
+//      lane) anchors on this level's displacement after step 2;
+//   2. takes the Euler sample with direct gathers from img[t];
+//   3. writes the tile of ext[t] into its own LDS region;
 //   4. runs the K iterations reading windows with ds_read2_b64; a lane whose window falls
-//      outside the tile (jets, polar rows, the +-180 seam, stretched patches) gathers from
-//      global memory instead.
+//      outside the tile (jets, polar rows, the +-180 seam, patches the flow has stretched) redoes
+//      that sample with the exact sequence and a global gather.
 // Tiles are per wave, so there is no workgroup barrier anywhere (LDS operations of one wave
 // execute in order) and waves of a block drift freely.  Same arithmetic as the direct-gather
 // float path; only the memory the window is read from differs.
