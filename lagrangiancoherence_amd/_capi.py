@@ -61,7 +61,8 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # LCS_LIB: an experiment build of the same library (python -m lagrangiancoherence_amd.build --out ...)
+    p = path or os.environ.get("LCS_LIB") or LIB_PATH
     # One HIP runtime per process: torch wheels bundle their own ROCm libraries, and loading ours
     # (linked against /opt/rocm) first leaves the process with two HSA runtimes and "no ROCm-capable
     # device".  Importing torch first makes our DT_NEEDED entries resolve to the copies torch loaded.

@@ -35,18 +35,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = True, extra_flags=(), out: str | None = None) -> str:
+    """``out``/``extra_flags``: experiment variants (e.g. ``-DLCS_LDS_READ2``) built beside the product
+    library and selected at run time with ``LCS_LIB=<path>`` (see ``_capi.load``)."""
+    if out is None and not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", *extra_flags,
-           "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES], "-ldl"]
+           "-o", out or LIB, *[os.path.join(CSRC, s) for s in SOURCES], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
-    print(LIB)
+    # python -m lagrangiancoherence_amd.build [--force] [--out path.so] [-Dflag ...]
+    argv = sys.argv[1:]
+    out = argv[argv.index("--out") + 1] if "--out" in argv else None
+    flags = [a for a in argv if a.startswith("-D") or a.startswith("-m")]
+    print(build_library(force="--force" in argv, extra_flags=flags, out=out))

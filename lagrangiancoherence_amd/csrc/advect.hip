@@ -520,9 +520,34 @@ template <int ORDER>
 struct TileGeom {
     static constexpr int COLS = ORDER == 3 ? 32 : 16;   // one row = COLS/2 lanes x 16 B
     static constexpr int ROWS = ORDER == 3 ? 16 : 8;
-    static constexpr int PITCH = COLS + 2;              // rows stay 16-byte aligned and shift 4 banks
+#ifndef LCS_O3_PITCH
+#define LCS_O3_PITCH (32 + 2)
+#endif
+    static constexpr int PITCH = ORDER == 3 ? LCS_O3_PITCH : COLS + 2;  // rows stay 16-byte aligned
     static constexpr int LANES_PER_ROW = COLS / 2;
     static constexpr int ROWS_PER_PASS = 64 / LANES_PER_ROW;
+};
+
+// Order 3 also takes the Euler sample out of LDS: its direct form is 8 sixteen-byte gathers per lane and level
+// (~27 vector-L1 tag lookups each: 13 of the kernel's 20 ms of TCP time on C3, next to 13.5 ms of VALU work),
+// while a small tile of img[t] around the patch's CURRENT position is one coalesced 16-byte load per lane.
+// (Order 1 gathers 2 x 16 B per lane; there the tile was measured slower, 8.2 vs 7.6 ms.)
+#ifndef LCS_E_ROWS
+#define LCS_E_ROWS 8
+#endif
+#ifndef LCS_E_PITCH
+#define LCS_E_PITCH 18
+#endif
+template <int ORDER>
+struct EulerGeom {
+#ifdef LCS_NO_EULER_TILE
+    static constexpr bool ON = false;
+#else
+    static constexpr bool ON = ORDER == 3;
+#endif
+    static constexpr int COLS = 16, ROWS = LCS_E_ROWS, PITCH = LCS_E_PITCH;
+    static constexpr int LANES_PER_ROW = COLS / 2, ROWS_PER_PASS = 64 / LANES_PER_ROW, NPASS = ROWS / ROWS_PER_PASS;
+    static constexpr int ELEMS = ON ? ROWS * PITCH : 0;
 };
 
 struct TapL {
@@ -555,18 +580,9 @@ __device__ __forceinline__ TapL tap_of(f2 c) {
     return t;
 }
 
+// start + the sample of one time level at a located window, gathered from global memory
 template <int ORDER>
-__device__ __forceinline__ f2 window_global(const float *__restrict__ lvl, const AdvectArgs<float> &A, const TapL &t,
-                                            const float wx[4], const float wy[4]) {
-    // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that, i.e. padded (y0, x0).
-    // The unsigned min is memory safety (garbage coordinates saturate).
-    const unsigned x0 = min((unsigned)t.x0, (unsigned)(A.nx_f - 1)), y0 = min((unsigned)t.y0, (unsigned)(A.ny_f - 1));
-    TapF g;
-    g.byte_off = (__umul24(y0, (unsigned)A.pitch) + x0) * 8u + (ORDER == 3 ? 0u : ((unsigned)A.pitch + 1u) * 8u);
-    g.tx = t.tx;
-    g.ty = t.ty;
-    return fetch_f<ORDER>(lvl, g, (unsigned)A.pitch * 8u, wx, wy);
-}
+__device__ __forceinline__ f2 window_global(const float *__restrict__ lvl, const AdvectArgs<float> &A, const TapL &t, f2 start);
 
 // ``tile_addr``: LDS byte address of the wave's tile.  The window address is one 24-bit mad + one
 // shift-add (left to itself the compiler picks the quarter-rate v_mul_lo_u32 here).
@@ -576,27 +592,121 @@ __device__ __forceinline__ unsigned lds_address(const void *shared_ptr) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)shared_ptr;
 }
 
-template <int ORDER>
-__device__ __forceinline__ f2 window_lds(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry, const TapL &t,
-                                         const float wx[4], const float wy[4]) {
-    constexpr int LT_PITCH = TileGeom<ORDER>::PITCH;
+#ifdef LCS_LDS_READ2
+typedef lds_f2 lds_node;
+#else
+// One ds_read_b64 per node, not ds_read2_b64 pairs: on gfx950 a wave's ds_read_b64 takes 2 LDS cycles (64
+// banks, 32-lane groups) while ds_read2_b64 takes 8 for twice the bytes (32 banks, 16-lane groups) -- half
+// the bandwidth, and conflicts between a node and its lower-left neighbour at these pitches (order 3 on C3:
+// LDS busy 81 % -> 52 % of the cycles).  The load/store optimiser pairs plain loads; volatile ones are left alone.
+typedef volatile lds_f2 lds_node;
+#endif
+
+template <int LT_PITCH>
+__device__ __forceinline__ lds_node *window_origin(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry) {
     unsigned row_addr;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(tile_addr));
-    lds_f2 *p = (lds_f2 *)(size_t)(row_addr + ((unsigned)rx << 3));
-    if (ORDER == 1) {
-        const f2 n00 = p[0], n01 = p[1], n10 = p[LT_PITCH], n11 = p[LT_PITCH + 1];
-        const f2 r0 = n00 + t.tx * (n01 - n00);
-        const f2 r1 = n10 + t.tx * (n11 - n10);
-        return r0 + t.ty * (r1 - r0);
-    }
-    f2 acc = {0.0f, 0.0f};
+    return (lds_node *)(size_t)(row_addr + ((unsigned)rx << 3));
+}
+
+// order 1: the 2x2 window and its two lerps
+template <int LT_PITCH>
+__device__ __forceinline__ f2 window_lds1(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry, const TapL &t) {
+    lds_node *p = window_origin<LT_PITCH>(tile_addr, pitch_bytes, rx, ry);
+    const f2 n00 = p[0], n01 = p[1], n10 = p[LT_PITCH], n11 = p[LT_PITCH + 1];
+    const f2 r0 = n00 + t.tx * (n01 - n00);
+    const f2 r1 = n10 + t.tx * (n11 - n10);
+    return r0 + t.ty * (r1 - r0);
+}
+
+// order 3: the 16 window reads are issued back to back BEFORE the weights are formed, so the LDS latency is
+// covered by the wave's own arithmetic (left alone, the compiler forms the weights first and then waits for
+// each row in turn).  Weights as (x, y) pairs: one packed polynomial for both axes.
+struct CubicW {
+    f2 w0, w1, w2, w3;  // {wx_k, wy_k}
+};
+// explicit fused multiply-adds: the rounding of these two functions must not depend on the call site
+__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+
+__device__ __forceinline__ CubicW cubic_weights_p(float tx, float ty) {
+    // scipy's cubic B-spline weights (get_spline_interpolation_weights) as polynomials in t, 11 packed ops:
+    //   w3 = t^3/6,  w0 = (1-t)^3/6 = (1/6 - t/2 + t^2/2) - w3,  w1 = 2/3 + t^2 (t/2 - 1),
+    //   w2 = 1/6 + t/2 + t^2 (1/2 - t/2)                                   (the four sum to 1)
+#pragma clang fp contract(off)
+    const f2 t = {tx, ty};
+    const f2 tt = t * t;
+    CubicW w;
+    w.w3 = tt * (t * splat(1.0f / 6.0f));
+    w.w0 = pkfma(tt, splat(0.5f), pkfma(t, splat(-0.5f), splat(1.0f / 6.0f))) - w.w3;
+    w.w1 = pkfma(tt, pkfma(t, splat(0.5f), splat(-1.0f)), splat(2.0f / 3.0f));
+    w.w2 = pkfma(tt, pkfma(t, splat(-0.5f), splat(0.5f)), pkfma(t, splat(0.5f), splat(1.0f / 6.0f)));
+    return w;
+}
+// ``start`` + the 16-tap sum (the caller's Euler velocity rides in on the first row's fma).  ONE function for
+// the LDS window and for the global-gather fallback: a lane's result must not depend on which of the two
+// served it (tile placement differs between sharded and unsharded runs, results must not).
+__device__ __forceinline__ f2 cubic_apply(const f2 (&q)[4][4], const TapL &t, f2 start) {
+#pragma clang fp contract(off)
+    const CubicW w = cubic_weights_p(t.tx, t.ty);
+    const f2 wx[4] = {splat(w.w0.x), splat(w.w1.x), splat(w.w2.x), splat(w.w3.x)};
+    const f2 wy[4] = {splat(w.w0.y), splat(w.w1.y), splat(w.w2.y), splat(w.w3.y)};
+    f2 acc = start;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        lds_f2 *q = p + a * LT_PITCH;
-        const f2 r = wx[0] * q[0] + wx[1] * q[1] + wx[2] * q[2] + wx[3] * q[3];
-        acc += wy[a] * r;
+        const f2 r = pkfma(wx[3], q[a][3], pkfma(wx[2], q[a][2], pkfma(wx[1], q[a][1], wx[0] * q[a][0])));
+        acc = pkfma(wy[a], r, acc);
     }
     return acc;
+}
+template <int LT_PITCH>
+__device__ __forceinline__ f2 window_lds3(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry, const TapL &t, f2 start) {
+    lds_node *p = window_origin<LT_PITCH>(tile_addr, pitch_bytes, rx, ry);
+    f2 q[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[a][b] = p[a * LT_PITCH + b];
+#ifndef LCS_O3_NO_HOIST
+    __builtin_amdgcn_sched_barrier(0);  // all 16 reads in flight before the weights are formed
+#endif
+    return cubic_apply(q, t, start);
+}
+
+// returns start + interpolated (u, v)
+template <int ORDER, int LT_PITCH>
+__device__ __forceinline__ f2 window_lds(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry, const TapL &t, f2 start) {
+    if (ORDER == 3) return window_lds3<LT_PITCH>(tile_addr, pitch_bytes, rx, ry, t, start);
+    return start + window_lds1<LT_PITCH>(tile_addr, pitch_bytes, rx, ry, t);
+}
+
+template <int ORDER>
+__device__ __forceinline__ f2 window_global(const float *__restrict__ lvl, const AdvectArgs<float> &A, const TapL &t, f2 start) {
+    // order 1 window starts at padded (y0+1, x0+1); order 3 one node up/left of that, i.e. padded (y0, x0).
+    // The unsigned min is memory safety (garbage coordinates saturate).
+    const unsigned x0 = min((unsigned)t.x0, (unsigned)(A.nx_f - 1)), y0 = min((unsigned)t.y0, (unsigned)(A.ny_f - 1));
+    const unsigned row_bytes = (unsigned)A.pitch * 8u;
+    const unsigned byte_off = (__umul24(y0, (unsigned)A.pitch) + x0) * 8u + (ORDER == 3 ? 0u : ((unsigned)A.pitch + 1u) * 8u);
+    if (ORDER == 3) {
+        const char *p = (const char *)lvl + byte_off;
+        f2 q[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f4 lo, hi;
+            __builtin_memcpy(&lo, p + a * row_bytes, 16);
+            __builtin_memcpy(&hi, p + a * row_bytes + 16, 16);
+            q[a][0] = lo.xy;
+            q[a][1] = lo.zw;
+            q[a][2] = hi.xy;
+            q[a][3] = hi.zw;
+        }
+        return cubic_apply(q, t, start);
+    }
+    TapF g;
+    g.byte_off = byte_off;
+    g.tx = t.tx;
+    g.ty = t.ty;
+    return start + fetch1_f(lvl, g, row_bytes);
 }
 
 // trajectory.py:89-94 on a packed position: latitude clamp in one v_med3_f32 (a NaN input makes med3
@@ -628,15 +738,19 @@ __device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 
 // case never faults on garbage: LDS reads cannot fault (out-of-range DS reads return 0) and the global
 // gather clamps its indices.  Lanes without a seed (grid edge, pole rows) shadow a neighbouring seed so
 // that they follow the same path; only their stores are masked.
+#ifndef LCS_O3_MINWAVES
+#define LCS_O3_MINWAVES 1
+#endif
 template <int ORDER, int KFIX, bool CYCLIC>
-__global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<float> A) {
+__global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1) advect_lds_kernel(const AdvectArgs<float> A) {
 #pragma clang fp contract(fast)
     const int K = KFIX >= 0 ? KFIX : A.K;  // KFIX: SETTLS_order known at compile time (the iteration loop unrolls)
     typedef TileGeom<ORDER> G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
     constexpr int WIN = ORDER + 1;  // window edge in nodes
     constexpr int WOFF = ORDER == 3 ? 0 : LC_PAD_LO;  // padded window origin = (y0 + WOFF, x0 + WOFF)
-    __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
+    typedef EulerGeom<ORDER> E;
+    __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH + E::ELEMS];
     const int per_xcd = (A.ntiles + 7) / 8;
     const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile_id >= A.ntiles) return;  // whole block
@@ -672,7 +786,17 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     const unsigned tile_addr = lds_address(tile);
     unsigned pitch_bytes = (unsigned)LT_PITCH * 8u;
     asm volatile("" : "+s"(pitch_bytes));  // one SGPR for the whole kernel (a VOP3 literal is not encodable)
+    f2 *etile = tile + LT_ROWS * LT_PITCH;  // Euler tile of img[t] (order 3)
+    const unsigned etile_addr = lds_address(etile);
+    unsigned epitch_bytes = (unsigned)E::PITCH * 8u;
+    asm volatile("" : "+s"(epitch_bytes));
+    const int e_row = lane / E::LANES_PER_ROW, e_col = (lane % E::LANES_PER_ROW) * 2;
     const f2 pmin = {A.lon_min, A.lat_min}, sc = {A.sx, A.sy};
+    // Index-space coordinate, subtract first (tools.py:21-22): a seed sitting exactly on the grid origin must map
+    // to exactly 0 -- the one-fma form p*sc - (pmin*sc) leaves a residual of up to +-3e-5 there, and a negative
+    // one wraps to the far end of the periodic axis (measured 2 % faster, rejected).  Same expression as
+    // index_coords(), so the exact-redo path sees the same coordinate as the common path.
+    auto to_index = [&](f2 q) { return (q - pmin) * sc; };
     // the common case needs the new longitude strictly inside these bounds (Q7 wrap / Q9 clamp otherwise)
     // (cyclic: |x| < 180 is one compare with a source modifier; hence the template parameter)
     const float xlo = A.x_min, xhi = A.x_max;
@@ -684,15 +808,18 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
     // staging geometry of this lane: ROWS_PER_PASS tile rows per pass, 16 B (2 nodes) per lane
     const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
     const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 8u;  // bytes inside a level
-    float wx[4], wy[4];
     f2 dprev = {0.0f, 0.0f};  // previous level's Euler displacement in index space: predicts this level's travel
     constexpr int NPASS = LT_ROWS / G::ROWS_PER_PASS;
-    // order 3 keeps the tile loads behind the Euler sample: 16 more live VGPRs across it cost two waves
-    // per SIMD, and that kernel is LDS-bandwidth bound anyway (measured: 21.7 vs 21.0-21.2 ms)
+    // With the Euler sample gathered directly (order 3 without its Euler tile) the tile loads stay behind it:
+    // 16 more live VGPRs across the 8 gathers cost two waves per SIMD (measured: 21.7 vs 21.0-21.2 ms)
+#ifdef LCS_O3_NO_PREFETCH
     constexpr bool PREFETCH = ORDER == 1;
+#else
+    constexpr bool PREFETCH = ORDER == 1 || E::ON;
+#endif
     constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
     for (int s = 0; s < A.nsteps; ++s) {
-        f2 c0 = (p - pmin) * sc;
+        f2 c0 = to_index(p);
         // ---- 1. anchor the tile and issue its loads ------------------------------------------------
         // Tile origin (padded coordinates): centre of the windows' predicted travel.  The Euler step and
         // every iteration move a parcel by about one Euler displacement (Q4), and that displacement
@@ -714,36 +841,52 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
                 __builtin_memcpy(&stage[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_off, 16);
         };
         if (PREFETCH && K > 0) anchor_and_load(dprev * (1.0f + kpred) + c0);
-        // ---- 2. Euler sample (global gather) ---------------------------------------------------
+        // ---- 2. Euler sample: global gather (order 1) / LDS tile of img[t] (order 3) ------------------
         f2 e;
         {
             TapL t = tap_of(c0);
             // common case: 0 <= floor(c) <= n-2, i.e. c in [0, n-1) -- no wrap needed
             bool bad = ((unsigned)t.x0 > (unsigned)(A.nx_f - 2)) | ((unsigned)t.y0 > (unsigned)(A.ny_f - 2));
-            if (ORDER == 3) {
-                cubic_weights_f(t.tx, wx);
-                cubic_weights_f(t.ty, wy);
+            const f2 zero = {0.0f, 0.0f};
+            if (E::ON) {
+                // tile origin: the centre lane's window in the middle of the tile
+                const int exm = __builtin_amdgcn_readlane(t.x0, CENTRE), eym = __builtin_amdgcn_readlane(t.y0, CENTRE);
+                const int eox = min(max(exm + WOFF - (E::COLS - WIN) / 2, 0), pad_cols - E::COLS);
+                const int eoy = min(max(eym + WOFF - (E::ROWS - WIN) / 2, 0), pad_rows - E::ROWS);
+                const char *src = (const char *)lvl + ((size_t)__umul24((unsigned)eoy, (unsigned)pad_cols) + (unsigned)eox) * 8;
+                const unsigned e_off = ((unsigned)e_row * (unsigned)pad_cols + (unsigned)e_col) * 8u;
+                f4 es[E::NPASS > 0 ? E::NPASS : 1];
+#pragma unroll
+                for (int r = 0; r < E::NPASS; ++r)
+                    __builtin_memcpy(&es[r], src + (size_t)(r * E::ROWS_PER_PASS) * pad_cols * 8 + e_off, 16);
+                __builtin_amdgcn_wave_barrier();  // the previous level's reads of this region are done
+#pragma unroll
+                for (int r = 0; r < E::NPASS; ++r) *(f4 *)(etile + (r * E::ROWS_PER_PASS + e_row) * E::PITCH + e_col) = es[r];
+                __builtin_amdgcn_wave_barrier();
+                // window origins the tile serves: inside it AND in [0, n-2] (the same rule as for the ext tile)
+                const int sox = eox - WOFF, soy = eoy - WOFF;
+                const int hx = min(sox + E::COLS - WIN, A.nx_f - 2), hy = min(soy + E::ROWS - WIN, A.ny_f - 2);
+                const int lx = max(sox, 0), ly = max(soy, 0);
+                const int rx = t.x0 - lx, ry = t.y0 - ly;
+                bad |= ((unsigned)rx > (unsigned)(hx - lx)) | ((unsigned)ry > (unsigned)(hy - ly)) | (hx < lx) | (hy < ly);
+                const unsigned ebase = etile_addr + (unsigned)(lx - sox) * 8u + (unsigned)(ly - soy) * ((unsigned)E::PITCH * 8u);
+                e = window_lds<ORDER, E::PITCH>(ebase, epitch_bytes, rx, ry, t, zero);
+            } else {
+                e = window_global<ORDER>(lvl, A, t, zero);
             }
-            e = window_global<ORDER>(lvl, A, t, wx, wy);
             f2 pn = dd * e + p;
-            pn.y = __builtin_amdgcn_fmed3f(pn.y, A.y_min, ymax_v);
             bad |= x_needs_care(pn.x);
             if (bad) {  // exact sequence
                 c0 = index_coords(A, p);
                 t = tap_of(c0);
-                if (ORDER == 3) {
-                    cubic_weights_f(t.tx, wx);
-                    cubic_weights_f(t.ty, wy);
-                }
-                e = window_global<ORDER>(lvl, A, t, wx, wy);
+                e = window_global<ORDER>(lvl, A, t, zero);
                 pn = dd * e + p;
                 clamp_position_p(A, pn, ymax_v);
             }
+            dprev = (pn - p) * sc;  // Euler displacement in index space
             p = pn;
         }
-        f2 c = (p - pmin) * sc;  // iteration 0's coordinate (unwrapped; the iteration checks it)
-        dprev = c - c0;
-        if (!PREFETCH && K > 0) anchor_and_load(dprev * kpred + c);  // this level's own displacement
+        if (!PREFETCH && K > 0) anchor_and_load(dprev * (1.0f + kpred) + c0);  // this level's own displacement
         // ---- 3. tile into LDS: ext[t][oy .. oy+LT_ROWS) x [ox .. ox+LT_COLS) ----------------------
         int lo_x = 0x40000000, lo_y = 0x40000000, lim_x = 0, lim_y = 0;  // no tile: nothing is "inside"
         unsigned base_addr = tile_addr;
@@ -765,31 +908,30 @@ __global__ void __launch_bounds__(BLOCK) advect_lds_kernel(const AdvectArgs<floa
             }
         }
         // ---- 4. K iterations out of LDS ----------------------------------------------------------
+        // The latitude clamp (trajectory.py:89-90) is DEFERRED: a latitude outside [y_min, y_max] maps to an index
+        // outside [0, n-1), which the next sample's window test flags, and every exact-redo path starts by
+        // clamping the position it was handed -- the same values as clamping after each update, one v_med3
+        // per level instead of one per sample.
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (k > 0) c = (p - pmin) * sc;
-            TapL t = tap_of(c);
-            if (ORDER == 3) {
-                cubic_weights_f(t.tx, wx);
-                cubic_weights_f(t.ty, wy);
-            }
+            // absolute index coordinate: its rounding must not depend on where the tile sits (row-sharded runs
+            // place tiles differently and must stay bit-identical to unsharded ones)
+            TapL t = tap_of(to_index(p));
             const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;  // the subtrahends are wave-uniform (SGPRs)
             bool bad = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
-            const f2 w = window_lds<ORDER>(base_addr, pitch_bytes, rx, ry, t, wx, wy);
-            f2 pn = hd * (e + w) + p;
-            pn.y = __builtin_amdgcn_fmed3f(pn.y, A.y_min, ymax_v);
+            const f2 ew = window_lds<ORDER, LT_PITCH>(base_addr, pitch_bytes, rx, ry, t, e);  // e + sample of ext[t]
+            f2 pn = hd * ew + p;
             bad |= x_needs_care(pn.x);
             if (bad) {  // exact sequence, global gather
-                t = tap_of(index_coords(A, p));
-                if (ORDER == 3) {
-                    cubic_weights_f(t.tx, wx);
-                    cubic_weights_f(t.ty, wy);
-                }
-                pn = hd * (e + window_global<ORDER>(elv, A, t, wx, wy)) + p;
+                f2 pc = p;
+                pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
+                t = tap_of(index_coords(A, pc));
+                pn = hd * window_global<ORDER>(elv, A, t, e) + pc;
                 clamp_position_p(A, pn, ymax_v);
             }
             p = pn;
         }
+        p.y = __builtin_amdgcn_fmed3f(p.y, A.y_min, ymax_v);  // the level's one latitude clamp (stores, next Euler sample)
         if (live && A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = p.x;
             A.traj_y[(size_t)(s + 1) * plane + idx] = p.y;

@@ -1,0 +1,160 @@
+// Issue-rate microbenchmark: cycles one SIMD needs per wave64 instruction, by opcode and by waves per SIMD.
+//   hipcc -O3 --offload-arch=gfx950 -o ubench_valu tools/ubench_valu.hip && ./ubench_valu
+// Each kernel runs N independent-chain instructions per wave in a loop; the grid is 256 CUs x 4 SIMDs x W
+// waves.  Reported: SIMD cycles per wave-instruction = time x clock / (instructions per wave x W), with the
+// clock taken from s_memtime / wall time inside the same launch.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define REP8(x) x x x x x x x x
+#define BODY(asm_line)                                                                   \
+    for (int it = 0; it < iters; ++it) {                                                 \
+        REP8(REP8(asm volatile(asm_line : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)) \
+    }
+
+enum Op { FMA, PKFMA, PKMUL, PKADD, CVTFLR, FRACT, MED3, MADU24, CMP, ADD, MIXPK, LDSB64, LDSREAD2, NOPS };
+
+template <int OP>
+__global__ void __launch_bounds__(256) k(float *out, long long *cyc, int iters) {
+    __shared__ f2 lds[2048];
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a1, a0}, p3 = {a3, a2};
+    const f2 pb = {1.0001f, 0.9999f}, pc = {0.5f, 0.25f};
+    const float b = 1.0001f, c = 0.5f;
+    unsigned u0 = threadIdx.x, u1 = u0 + 7, u2 = u0 + 9, u3 = u0 + 11;
+    lds[threadIdx.x] = p0;
+    lds[threadIdx.x + 256] = p1;
+    __syncthreads();
+    const unsigned la = (threadIdx.x & 63) * 8;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    if (OP == FMA) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));))
+        }
+    } else if (OP == ADD) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));))
+        }
+    } else if (OP == PKFMA) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5"
+                                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));))
+        }
+    } else if (OP == PKMUL) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4"
+                                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));))
+        }
+    } else if (OP == PKADD) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4"
+                                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));))
+        }
+    } else if (OP == MIXPK) {  // 2 packed + 2 plain
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_fma_f32 %2, %2, %6, %7\n v_pk_fma_f32 %1, %1, %4, %5\n v_fma_f32 %3, %3, %6, %7"
+                                   : "+v"(p0), "+v"(p1), "+v"(a2), "+v"(a3) : "v"(pb), "v"(pc), "v"(b), "v"(c));))
+        }
+    } else if (OP == CVTFLR) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_cvt_flr_i32_f32 %0, %4\n v_cvt_flr_i32_f32 %1, %5\n v_cvt_flr_i32_f32 %2, %4\n v_cvt_flr_i32_f32 %3, %5"
+                                   : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(b), "v"(c));))
+        }
+    } else if (OP == FRACT) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_fract_f32 %0, %0\n v_fract_f32 %1, %1\n v_fract_f32 %2, %2\n v_fract_f32 %3, %3"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));))
+        }
+    } else if (OP == MED3) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_med3_f32 %0, %0, %4, %5\n v_med3_f32 %1, %1, %4, %5\n v_med3_f32 %2, %2, %4, %5\n v_med3_f32 %3, %3, %4, %5"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));))
+        }
+    } else if (OP == MADU24) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_mad_u32_u24 %0, %0, %4, %5\n v_mad_u32_u24 %1, %1, %4, %5\n v_mad_u32_u24 %2, %2, %4, %5\n v_mad_u32_u24 %3, %3, %4, %5"
+                                   : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(u0), "v"(u1));))
+        }
+    } else if (OP == CMP) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %4\n v_cmp_lt_u32 vcc, %1, %4\n v_cmp_lt_u32 vcc, %2, %4\n v_cmp_lt_u32 vcc, %3, %4"
+                                   : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(u0), "v"(u1) : "vcc");))
+        }
+    } else if (OP == NOPS) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));))
+        }
+    } else if (OP == LDSB64) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:8\n ds_read_b64 %2, %4 offset:512\n ds_read_b64 %3, %4 offset:520\n s_waitcnt lgkmcnt(0)"
+                                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(la));))
+        }
+    } else if (OP == LDSREAD2) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("ds_read2_b64 %0, %2 offset1:1\n ds_read2_b64 %1, %2 offset0:64 offset1:65\n s_waitcnt lgkmcnt(0)"
+                                   : "+v"(*(float __attribute__((ext_vector_type(4))) *)&p0), "+v"(*(float __attribute__((ext_vector_type(4))) *)&p2) : "v"(la));))
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y + p2.x + p3.y + (float)(u0 + u1 + u2 + u3);
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int OP>
+void run(const char *name, int per_body) {
+    float *out;
+    long long *cyc;
+    hipMalloc(&out, sizeof(float) * 256 * 256 * 8 * 4);
+    hipMalloc(&cyc, sizeof(long long) * 256 * 8 * 4);
+    const int iters = 200;
+    printf("%-10s", name);
+    for (int wps : {1, 2, 4, 8}) {
+        const int blocks = 256 * wps;  // 256-thread blocks = 4 waves, one per SIMD
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<long long> h(blocks);
+        hipMemcpy(h.data(), cyc, sizeof(long long) * blocks, hipMemcpyDeviceToHost);
+        double avg = 0;
+        for (long long v : h) avg += (double)v;
+        avg /= blocks;
+        const double n_inst = (double)iters * 64 * per_body;  // per wave
+        // in-kernel cycles per instruction per wave, times waves sharing the SIMD
+        printf("  W=%d: %.2f cyc/inst/wave (%.2f SIMD-cyc/inst, %.3f ms)", wps, avg / n_inst, avg / n_inst / wps, ms);
+    }
+    printf("\n");
+    hipFree(out);
+    hipFree(cyc);
+}
+
+int main() {
+    run<FMA>("v_fma", 4);
+    run<ADD>("v_add", 4);
+    run<PKFMA>("v_pk_fma", 4);
+    run<PKMUL>("v_pk_mul", 4);
+    run<PKADD>("v_pk_add", 4);
+    run<MIXPK>("pk+plain", 4);
+    run<CVTFLR>("cvt_flr", 4);
+    run<FRACT>("v_fract", 4);
+    run<MED3>("v_med3", 4);
+    run<MADU24>("mad_u24", 4);
+    run<CMP>("v_cmp", 4);
+    run<NOPS>("s_nop", 4);
+    run<LDSB64>("ds_b64x4", 4);
+    run<LDSREAD2>("ds_rd2x2", 2);
+    return 0;
+}
