@@ -162,18 +162,23 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
 
 def ensemble_lcs(engine, field, seed_lat, seed_lon, timestep, n_members: int, nsteps: int, rank: int = 0,
                  world: int = 1, SETTLS_order=0, interp_order=1, cyclic_xboundary=True, fd_fp32_cast=True,
-                 tensor_layout="reference"):
+                 tensor_layout="reference", return_dpts=False):
     """BASELINE config 5: member ``e`` starts at time level ``t0 = e`` and runs ``nsteps`` steps over the
     same seed grid.  Members are sharded over ranks in contiguous blocks; nothing is exchanged (gathering
-    the sigma fields is the caller's business).  Returns ``(member_indices, sigma[len(members), ny, nx])``."""
+    the sigma fields is the caller's business).  Returns ``(member_indices, sigma[len(members), ny, nx])``,
+    with ``return_dpts`` also the members' departure points ``x_dep, y_dep`` (same shape)."""
     import torch
     if n_members - 1 + nsteps > field.nt - 1:
         raise ValueError(f"{n_members} members x {nsteps} steps need {n_members + nsteps} time levels, have {field.nt}")
     mine = ensemble_partition(n_members, world, rank)
-    out = []
+    out, xs, ys = [], [], []
     for e in mine:
         r = engine.lcs(field, seed_lat, seed_lon, timestep, SETTLS_order=SETTLS_order, interp_order=interp_order,
                        cyclic_xboundary=cyclic_xboundary, t0=e, nsteps=nsteps, fd_fp32_cast=fd_fp32_cast,
                        tensor_layout=tensor_layout)
         out.append(r["sigma"])
-    return mine, (torch.stack(out) if out else None)
+        if return_dpts:
+            xs.append(r["x_dep"])
+            ys.append(r["y_dep"])
+    st = lambda a: torch.stack(a) if a else None
+    return (mine, st(out), st(xs), st(ys)) if return_dpts else (mine, st(out))

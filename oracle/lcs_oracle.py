@@ -239,15 +239,20 @@ def fourth_order_derivative(arr, dim=0, isglobal=True):
 
 
 def derivative_spherical_coords(values, lat, lon, dim=0, isglobal=True,
-                                fd_fp32_cast=True):
+                                fd_fp32_cast=True, dlat=None, dlon=None):
     """LCS/tools.py:248-267.  ``values`` is ``(nlat, nlon)`` ascending.
 
     ``fd_fp32_cast=False`` is NOT reference behaviour; it exists so tests can
     bound the float32 noise of Q11 against a clean float64 stencil.
+    ``dlat``/``dlon`` (extension, default = the reference's ``coord[1]-coord[0]``):
+    the grid spacing when ``lat``/``lon`` are a WINDOW of a larger grid whose
+    first two coordinates define it (tests/_fullsize.py).
     """
     y = lat * np.pi / 180                                                    # :254
-    dx = (np.pi / 180) * (lon[1] - lon[0]) * EARTH_R * np.cos(y)             # :255
-    dy = (np.pi / 180) * (lat[1] - lat[0]) * EARTH_R                         # :256
+    dlon = (lon[1] - lon[0]) if dlon is None else dlon
+    dlat = (lat[1] - lat[0]) if dlat is None else dlat
+    dx = (np.pi / 180) * dlon * EARTH_R * np.cos(y)                          # :255
+    dy = (np.pi / 180) * dlat * EARTH_R                                      # :256
     src = values.astype("float32") if fd_fp32_cast else np.asarray(values)   # :258 (Q11)
     deriv = fourth_order_derivative(src, dim=dim, isglobal=isglobal)
     if dim == 0:
@@ -261,7 +266,7 @@ def derivative_spherical_coords(values, lat, lon, dim=0, isglobal=True,
 # a3  LCS.flowmap_gradient  (LCS/LCS.py:171-225)
 # --------------------------------------------------------------------------
 def flowmap_gradient(x_departure, y_departure, lat, lon, sigma=None,
-                     fd_fp32_cast=True):
+                     fd_fp32_cast=True, dlat=None, dlon=None):
     """Returns the ``(9, ny, nx)`` "def_tensor" in the reference's merge order
     ``dXdx,dXdy,dYdx,dYdy,dZdx,dZdy,dXdr,dYdr,dZdr``.  LCS/LCS.py:187-223."""
     if isinstance(sigma, (float, int)):                                      # :187-190
@@ -272,7 +277,7 @@ def flowmap_gradient(x_departure, y_departure, lat, lon, sigma=None,
     X = EARTH_R * np.sin(LAT) * np.cos(LON)                                  # :197
     Y = EARTH_R * np.sin(LAT) * np.sin(LON)                                  # :198
     Z = EARTH_R * np.cos(LAT)                                                # :199
-    kw = dict(lat=lat, lon=lon, fd_fp32_cast=fd_fp32_cast)
+    kw = dict(lat=lat, lon=lon, fd_fp32_cast=fd_fp32_cast, dlat=dlat, dlon=dlon)
     dXdx = derivative_spherical_coords(X, dim=1, **kw)                       # :200
     dXdy = derivative_spherical_coords(X, dim=0, **kw)
     dYdx = derivative_spherical_coords(Y, dim=1, **kw)

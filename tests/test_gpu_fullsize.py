@@ -50,17 +50,11 @@ def test_config3_full_size_subset_vs_oracle(eng, c3, order):
                                     lon.astype(np.float64), seed_lat=slat[rows].astype(np.float64),
                                     seed_lon=slon[cols].astype(np.float64), **kw)
 
-    def err(a, b):   # longitudes compared on the circle: 1 ulp can flip the +-180 rewrite (Q7)
-        d = np.abs(a - b)
-        return np.minimum(d, np.abs(d - 360))
-    eo = max(err(x32, x64).max(), np.abs(y32 - y64).max())
-    eg_x, eg_y = err(xg, x64), np.abs(yg - y64)
-    print(f"C3 order {order}: float32 oracle err {eo:.3e} deg; GPU err x {eg_x.max():.3e} y {eg_y.max():.3e} "
-          f"(median {np.median(eg_x):.2e})")
-    # 96 steps x 5 position updates in float32 at |x| ~ 180 (ulp 1.5e-5): a few 1e-4 degrees, amplified
-    # where the flow stretches.  The GPU must sit in the same band as the float32 oracle.
-    assert eg_x.max() <= max(4 * eo, 2e-3) and eg_y.max() <= max(4 * eo, 2e-3)
-    assert np.median(eg_x) <= 2e-4
+    from tests._fullsize import positions_check
+    # 96 steps x 5 position updates in float32 at |x| ~ 180 (ulp 1.5e-5): a few 1e-4 degrees, amplified where the
+    # flow stretches.  The GPU must sit in the band of the float32 oracle's own error: median, p99 and maximum.
+    positions_check(eng, f, slat, slon, rows, cols, xg, yg, (x32, y32), (x64, y64), f"C3 order {order}",
+                    (1e-4, 5e-4, 2e-3), interp_order=order)
 
 
 def test_config3_sharded_equals_unsharded_full_size(eng, c3):
