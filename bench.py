@@ -1,23 +1,36 @@
 #!/usr/bin/env python
 """Benchmark of the FTLE hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--scaling weak|strong]
 
-One "step" = one pass of the whole hot path over one batch of synthetic input:
-pack the wind series into the gather image, advect every seed through all time
-levels (fused kernel), exchange the 2-row halo (N>1), compute sigma_max.  Inputs
-(u, v, seeds) are resident in HBM before the timed region.
+One "step" = one pass of the whole hot path over one batch of synthetic input: pack the wind series into the
+gather image, advect every seed through all time levels (fused kernel), exchange the 2-row halo (N>1), compute
+sigma_max.  Inputs (u, v, seeds) are resident in HBM before the timed region.
 
-Workload (BASELINE.json configs[2], the 4096^2 grid the metric is quoted on):
-4096x4096 seeds per GPU on a 720x1440 synthetic ERA5-like field, 97 time levels
-(96 steps of 15 min), float32, SETTLS_order K=4, interp_order=1, cyclic.
-N>1: the seed grid is (4096*N) x 4096, row-sharded (weak scaling), wind replicated.
+Workloads (BASELINE.json configs; all float32, SETTLS_order K=4, interp_order 1, cyclic unless flags say otherwise):
+  c3 (default, the 4096^2 grid the metric is quoted on): 4096x4096 seeds on a 720x1440 synthetic ERA5-like field,
+     97 time levels (96 steps of 15 min).  N>1: --scaling weak (default) = (4096*N) x 4096 seeds, row-sharded;
+     --scaling strong = the one 4096^2 grid split over N ranks.  Wind replicated.
+  c4: 8192x8192 seeds, 385 levels (384 steps), row-sharded over N ranks with the halo exchange (fixed total work).
+  c5: 64 start times x 2048^2 seeds x 200 steps on a 264-level series, members sharded over N ranks, no exchange.
+  c2: BASELINE configs[1], 1024^2 field nodes = seeds, moving ideal vortex, 200 steps, float64, N=1 only.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the fused advection):
+  bound     the unit that limits it.  The advect kernels are bound by the vector ALU's instruction throughput
+            (time follows the VALU cycle count when instructions are removed; tools/ubench_valu.hip, DESIGN.md
+            section 4), not by HBM: their taps are served from LDS / L1 / L2.
+  achieved  algorithmic FLOP rate: flops_per_particle_timestep x particle-timesteps / HIP-event duration of the
+            advect launches (live, on the launch stream), TFLOP/s; peak = 157.3 TFLOP/s fp32 vector (78.6 fp64).
+  algorithmic_GBps   SURVEY 8d's byte figure B_adv(K, order) x particle-timesteps / that duration (it charges every
+            cache-served tap to memory, so it may exceed the HBM peak; kept for cross-round comparison only).
+  hbm       compulsory bytes (every image level + seeds + outputs once), their rate as a fraction of the 8 TB/s peak,
+            and -- when a committed rocprofv3 --pmc summary was collected on exactly this csrc/ (hash-stamped) for
+            this workload -- the measured traffic per launch and its fraction; otherwise null.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -28,13 +41,28 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_VECTOR_TFLOPS = 157.3   # same guide: peak FP32 vector
+FP64_VECTOR_TFLOPS = 78.6
 
 
 def b_adv(K: int, order: int, s_p: int, s_f: int) -> int:
     """Algorithmic bytes per particle-timestep."""
     taps = 4 if order == 1 else 16
     return 4 * s_p + taps * (2 + 4 * K) * s_f
+
+
+def flops_per_sample(order: int) -> int:
+    """Arithmetic of ONE (u, v) sample + position update, counted on the algorithm:
+    order 1: index map 4, fractions 2, three lerps on (u, v) 3x2x3 = 18, update 6            -> 30
+    order 3: index map 4, fractions 2, cubic weights 2x18 = 36, 16 taps x 2 x 2 = 64,
+             four row combines 4x2x2 = 16, update 6                                           -> 128"""
+    return 30 if order == 1 else 128
+
+
+def flops_pts(K: int, order: int, fused_levels: bool) -> int:
+    """Per particle-timestep: 1 Euler sample + K iterations of one sample (fused image 2F[t]-F[t+1]) or of two."""
+    return flops_per_sample(order) * (1 + (K if fused_levels else 2 * K))
 
 
 def measured_copy_peak(torch, nbytes: int = 1 << 30, reps: int = 10) -> float:
@@ -51,26 +79,74 @@ def measured_copy_peak(torch, nbytes: int = 1 << 30, reps: int = 10) -> float:
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
 
 
-def pmc_traffic(kernel_prefix: str, workload: dict):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summaries (profiles/*/
-    *_pmc_traffic.json, written by profiles/summarize.py from separate FETCH_SIZE / WRITE_SIZE passes of
-    this same command).  Counters cannot be read from inside the timed run; None if no summary matches."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_traffic.json"))):
+def stamped_counters(kernel: str, workload: dict, csrc: str):
+    """Counters of `kernel` from the committed rocprofv3 --pmc summaries (profiles/*/*_pmc_*.json, written by
+    profiles/summarize*.py from separate passes of this same command).  Counters cannot be read from inside the
+    timed run, so they are REPLAYED -- only from a summary whose workload matches and whose csrc_hash equals the
+    hash of the sources this process runs; anything else gives None."""
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") != workload:
+        if d.get("workload") != workload or d.get("csrc_hash") != csrc:
             continue
         for k, v in d.get("kernels", {}).items():
-            if k.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
-                best = (v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
-    return best
+            if k.replace(" ", "") != kernel.replace(" ", ""):
+                continue
+            if "hbm_bytes_per_launch" in v:
+                out["traffic"] = v["hbm_bytes_per_launch"]
+                out["traffic_source"] = os.path.relpath(f, ROOT)
+            if "derived" in v:
+                out["limiting_unit"] = {kk: round(vv, 4) for kk, vv in v["derived"].items() if vv is not None}
+                out["limiting_unit_source"] = os.path.relpath(f, ROOT)
+    return out
 
 
-def run_c2(args, torch, flows, Engine, local_rank):
+def roofline(kernel, bound, pts_per_launch, launches_ms, K, order, s_p, s_f, fused, compulsory_bytes, workload, csrc):
+    """The roofline object of one advect launch (per GPU).  `launches_ms`: mean HIP-event duration of one launch."""
+    sec = launches_ms / 1e3
+    fl = flops_pts(K, order, fused)
+    peak = FP32_VECTOR_TFLOPS if s_p == 4 else FP64_VECTOR_TFLOPS
+    ach = pts_per_launch * fl / sec / 1e12
+    by = b_adv(K, order, s_p, s_f)
+    st = stamped_counters(kernel, workload, csrc)
+    tr = st.get("traffic")
+    return {
+        "bound": bound, "kernel": kernel, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        "flops_per_particle_timestep": fl, "kernel_ms": launches_ms,
+        "traffic": tr,
+        "algorithmic_GBps": pts_per_launch * by / sec / 1e9, "algorithmic_bytes_per_particle_timestep": by,
+        "hbm": {"peak_GBps": HBM_PEAK_GBPS, "compulsory_bytes": compulsory_bytes,
+                "compulsory_frac": compulsory_bytes / sec / 1e9 / HBM_PEAK_GBPS,
+                "traffic_bytes": tr, "hbm_traffic_frac": (tr / sec / 1e9 / HBM_PEAK_GBPS) if tr else None,
+                "traffic_source": st.get("traffic_source")},
+        "limiting_unit": st.get("limiting_unit"), "limiting_unit_source": st.get("limiting_unit_source"),
+        "csrc_hash": csrc,
+        "note": "frac = algorithmic FLOP rate / vector peak; the kernel is bound by VALU instruction throughput "
+                "(conversions, address arithmetic and compares next to the FLOPs), see limiting_unit; "
+                "algorithmic_GBps is SURVEY 8d's tap-byte figure (cache-served, may exceed HBM peak); "
+                "traffic / limiting_unit are replayed from hash-stamped rocprofv3 summaries or null",
+    }
+
+
+def cpu_baseline(flows, u, v, lat, lon, dt, K, order, nsteps):
+    """The oracle (numpy + scipy port of the reference) on a bounded sample of the same field, one host core."""
+    from oracle import lcs_oracle as O
+    n_s, st_s = 1024, min(32, nsteps)
+    sl, so = flows.seed_grid(n_s, n_s, lat, lon)
+    c0 = time.perf_counter()
+    O.lcs(u[:st_s + 1], v[:st_s + 1], lat, lon, timestep=dt, SETTLS_order=K, interp_order=order,
+          cyclic_xboundary=True, seed_lat=sl, seed_lon=so)
+    c1 = time.perf_counter()
+    return {"value": n_s * n_s * st_s / (c1 - c0), "unit": "particle-timesteps/s", "cores": 1, "kind": "port",
+            "sample": f"{n_s}x{n_s} seeds x {st_s} steps of the same field and settings, advect+sigma, "
+                      f"oracle/lcs_oracle.py (scipy.ndimage.map_coordinates + LAPACK SVD, single thread), "
+                      f"{c1 - c0:.1f} s on a host with {os.cpu_count()} cores"}
+
+
+def run_c2(args, torch, flows, Engine, local_rank, csrc):
     """BASELINE configs[1] on one GPU (a parity config; reported for the float64 path's rate)."""
     K, order = args.settls, args.order
     u, v, lat, lon = flows.config2()
@@ -102,9 +178,10 @@ def run_c2(args, torch, flows, Engine, local_rank):
     el = time.perf_counter() - t0
     ms = {k: float(np.mean([m[i].elapsed_time(m[i + 1]) for m in marks])) for i, k in enumerate(("pack", "advect", "sigma"))}
     pts = ny * nx * (nt - 1)
-    bytes_pts = b_adv(K, order, 8, 8)
-    ach = pts * bytes_pts / (ms["advect"] / 1e3) / 1e9
-    print(json.dumps({
+    wl = {"workload": "c2", "order": order, "K": K, "dtype": "f64", "fuse_levels": bool(args.fuse_levels)}
+    img = 2 * (ny + 3) * (nx + 3) * 8
+    comp = img * (nt if not args.fuse_levels else 2 * nt - 1) + 4 * ny * nx * 8
+    out = {
         "metric": "particle-timesteps/sec, BASELINE configs[1] (float64)", "value": pts * args.steps / el,
         "unit": "particle-timesteps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -113,26 +190,19 @@ def run_c2(args, torch, flows, Engine, local_rank):
                                f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order,
                    **({"fuse_levels": True} if args.fuse_levels else {})},
         "kernel_ms": ms,
-        "roofline": {"bound": "hbm", "kernel": "advect_kernel<double,%d%s>" % (order, ",fused" if args.fuse_levels else ""), "achieved": ach,
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                     "algorithmic_bytes_per_particle_timestep": bytes_pts},
-    }), flush=True)
-
-
-def issue_counters(kernel_prefix: str, workload: dict):
-    """SQ/TCP-derived occupancy of the units that actually bound the kernel (committed --pmc summary)."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_sq_tcp.json")), reverse=True):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        if d.get("workload") != workload:
-            continue
-        for k, v in d.get("kernels", {}).items():
-            if k.startswith(kernel_prefix) and "derived" in v:
-                return {**{kk: round(vv, 4) for kk, vv in v["derived"].items()}, "source": os.path.relpath(f, ROOT)}
-    return None
+        "roofline": roofline(eng.last_advect_kernel(), "valu", pts, ms["advect"], K, order, 8, 8, bool(args.fuse_levels),
+                             comp, wl, csrc),
+    }
+    if not args.no_cpu_baseline:
+        from oracle import lcs_oracle as O
+        us, vs, la, lo = flows.config2(n=256, nt=21)
+        c0 = time.perf_counter()
+        O.lcs(us, vs, la, lo, timestep=-900.0, SETTLS_order=K, interp_order=order, cyclic_xboundary=True)
+        c1 = time.perf_counter()
+        out["cpu_baseline"] = {"value": 256 * 256 * 20 / (c1 - c0), "unit": "particle-timesteps/s", "cores": 1, "kind": "port",
+                               "sample": f"the same vortex at 256x256 nodes x 20 steps, float64, advect+sigma, "
+                                         f"oracle/lcs_oracle.py, single thread, {c1 - c0:.1f} s"}
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -140,8 +210,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seeds", type=int, default=4096, help="seed rows per GPU and seed columns")
-    ap.add_argument("--nt", type=int, default=97)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="c3 only: weak (default) = --seeds rows per GPU, strong = one --seeds x --seeds grid over all ranks")
+    ap.add_argument("--seeds", type=int, default=None, help="seed rows (per GPU when weak) and seed columns")
+    ap.add_argument("--nt", type=int, default=None, help="time levels (default 97 / 385 / 264 for c3 / c4 / c5)")
     ap.add_argument("--settls", type=int, default=4)
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,16 +228,16 @@ def main():
     ap.add_argument("--field", default=None, metavar="NY,NX",
                     help="resolution of the synthetic wind field (default 720,1440 = 0.25 degrees; not the "
                          "headline when changed: probes other seed-to-node density ratios)")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2"],
-                    help="c3 (default, the headline): 4096^2 seeds on the 720x1440 fp32 flow; "
-                         "c2: BASELINE configs[1], 1024^2 nodes, moving ideal vortex, 200 steps, fp64, N=1 only")
+    ap.add_argument("--members", type=int, default=64, help="c5: ensemble members (start times)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from lagrangiancoherence_amd import flows, sharded
+    from lagrangiancoherence_amd.build import csrc_hash
     from lagrangiancoherence_amd.engine import Engine
 
+    csrc = csrc_hash()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -185,12 +258,31 @@ def main():
             dist.init_process_group(backend)
 
     if args.workload == "c2":
-        return run_c2(args, torch, flows, Engine, local_rank)
-    K, order, nt = args.settls, args.order, args.nt
-    nsteps = nt - 1
-    ny_local = nx = args.seeds
-    ny_global = ny_local * world
+        if world > 1:
+            raise SystemExit("--workload c2 is a one-GPU configuration")
+        return run_c2(args, torch, flows, Engine, local_rank, csrc)
+
+    wk = args.workload
+    K, order = args.settls, args.order
     dt = -900.0
+    defaults = {"c3": (4096, 97), "c4": (8192, 385), "c5": (2048, 264)}[wk]
+    seeds = args.seeds or defaults[0]
+    nt = args.nt or defaults[1]
+    if wk == "c3":
+        scaling = args.scaling or "weak"
+        ny_global, nx, nsteps = (seeds * world if scaling == "weak" else seeds), seeds, nt - 1
+        members = [0]
+    elif wk == "c4":
+        scaling = "strong"
+        ny_global, nx, nsteps = seeds, seeds, nt - 1
+        members = [0]
+    else:
+        scaling = "strong"
+        ny_global, nx = seeds, seeds
+        nsteps = nt - args.members                       # 264 levels: 64 start times x 200 steps
+        members = sharded.ensemble_partition(args.members, world, rank)
+    if args.scaling and wk != "c3" and args.scaling != scaling:
+        raise SystemExit(f"--workload {wk} has a fixed total size (strong scaling)")
 
     # ---- synthetic input, then resident in HBM -------------------------------------------
     fny, fnx = (int(t) for t in args.field.split(",")) if args.field else (720, 1440)
@@ -201,8 +293,13 @@ def main():
     eng = Engine(local_rank)
     ud = eng.to_device(u, np.float32)
     vd = eng.to_device(v, np.float32)
-    lo, hi = sharded.row_partition(ny_global, world, rank)
-    n_lo, n_hi = sharded.halo_rows(ny_global, lo, hi)
+    if wk == "c5":
+        lo, hi = 0, ny_global                                    # every member advects the whole seed grid
+        rworld, rrank = 1, 0
+    else:
+        lo, hi = sharded.row_partition(ny_global, world, rank)
+        rworld, rrank = world, rank
+    n_lo, n_hi = sharded.halo_rows(ny_global, lo, hi) if rworld > 1 else (0, 0)
     slat_d = eng.to_device(slat, np.float32)      # seeds resident too: the event brackets hold kernels only
     slon_d = eng.to_device(slon, np.float32)
     dlat, dlon = float(slat[1] - slat[0]), float(slon[1] - slon[0])
@@ -210,29 +307,36 @@ def main():
 
     # LCS_NATIVE_HALO=1: halo exchange through the C ABI (lc_halo_exchange, RCCL directly) instead of
     # torch.distributed point-to-point (the default; both are RCCL over xGMI with the nccl backend)
-    comm = sharded.native_comm(eng, rank, world) if (world > 1 and os.environ.get("LCS_NATIVE_HALO")) else None
+    native = bool(os.environ.get("LCS_NATIVE_HALO"))
+    comm = sharded.native_comm(eng, rank, world) if (rworld > 1 and native) else None
     ev = {k: [] for k in ("pack", "advect", "halo", "sigma")}
+    ev_marks = []
+    in_row0 = lo - n_lo
 
-    def one_step(record: bool):
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        marks[0].record()
-        field = eng.prepare_field(ud, vd, lat, lon, order)
-        marks[1].record()
-        res = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo,
+    def member_pass(field, t0, marks):
+        res = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, t0, nsteps, row0=lo,
                          ny_global=ny_global, halo=(n_lo, n_hi), return_traj=args.traj)
         x_ext, y_ext = res[0], res[1]
-        marks[2].record()
-        sharded.halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world, engine=eng, comm=comm)
-        in_row0 = lo - n_lo
-        marks[3].record()
+        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
+        sharded.halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rrank, rworld, engine=eng, comm=comm)
+        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
         sig = eng.sigma(x_ext, y_ext, slat_d[in_row0:in_row0 + x_ext.shape[0]], dlat, dlon, ny_global=ny_global,
                         in_row0=in_row0, out_row0=lo, n_out_rows=hi - lo)
-        marks[4].record()
+        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
+        return sig, x_ext, y_ext
+
+    def one_step(record: bool):
+        marks = [torch.cuda.Event(enable_timing=True)]
+        marks[0].record()
+        field = eng.prepare_field(ud, vd, lat, lon, order)
+        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
+        last = None
+        for e in members:
+            last = member_pass(field, e if wk == "c5" else 0, marks)
         if record:
             ev_marks.append(marks)
-        return sig
+        return last + (field,) if last else (None, None, None, field)
 
-    ev_marks = []
     for _ in range(args.warmup):
         one_step(False)
 
@@ -245,36 +349,84 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sig = one_step(True)
+        sig, x_ext, y_ext, field = one_step(True)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    for marks in ev_marks:
-        for i, k in enumerate(("pack", "advect", "halo", "sigma")):
-            ev[k].append(marks[i].elapsed_time(marks[i + 1]))     # ms, on the launch stream
+    for marks in ev_marks:                            # marks: [start, pack, (advect, halo, sigma) x members]
+        ev["pack"].append(marks[0].elapsed_time(marks[1]))
+        adv = hal = sg = 0.0
+        for m in range(len(members)):
+            b = 1 + 3 * m
+            adv += marks[b].elapsed_time(marks[b + 1])
+            hal += marks[b + 1].elapsed_time(marks[b + 2])
+            sg += marks[b + 2].elapsed_time(marks[b + 3])
+        ev["advect"].append(adv)
+        ev["halo"].append(hal)
+        ev["sigma"].append(sg)
     ms = {k: float(np.mean(vv)) for k, vv in ev.items()}
-    assert bool(torch.isfinite(sig).all()), "non-finite sigma in the benchmark output"
+    if sig is not None:
+        assert bool(torch.isfinite(sig).all()), "non-finite sigma in the benchmark output"
+    advect_kernel = eng.last_advect_kernel()
 
-    pts_per_step = ny_global * nx * nsteps
+    # ---- halo check (outside the timed region): the rows received must equal, bit for bit, the same rows
+    # advected redundantly by this rank -- for the exchange path that was timed AND for the other one
+    halo_check = None
+    if rworld > 1:
+        a, b = lo - n_lo, hi + n_hi
+        xr, yr = eng.advect(field, slat_d[a:b], slon_d, dt, K, order, True, 0, nsteps, row0=a, ny_global=ny_global)
+
+        def rows_equal(xe, ye):
+            ok = bool(torch.equal(xe, xr) and torch.equal(ye, yr))
+            t = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        halo_check = {"rows_per_neighbour": sharded.HALO, "timed_path": "lc_halo_exchange" if native else "torch.distributed",
+                      "timed_path_ok": rows_equal(x_ext, y_ext)}
+        other = "torch.distributed" if native else "lc_halo_exchange"
+        try:
+            x2, y2 = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo,
+                                ny_global=ny_global, halo=(n_lo, n_hi))
+            c2 = None if native else sharded.native_comm(eng, rank, world)
+            sharded.halo_exchange_into(x2, y2, n_lo, n_hi, rrank, rworld, engine=eng, comm=c2)
+            halo_check[other.replace(".", "_") + "_ok"] = rows_equal(x2, y2)
+        except Exception as exc:  # e.g. RCCL refusing two ranks on one device in the gloo rehearsal
+            halo_check[other.replace(".", "_") + "_ok"] = None
+            halo_check[other.replace(".", "_") + "_error"] = str(exc)[:200]
+        assert halo_check["timed_path_ok"], "halo rows received differ from the redundantly advected ones"
+
+    n_mem_global = args.members if wk == "c5" else 1
+    pts_per_step = n_mem_global * ny_global * nx * nsteps
     value = pts_per_step * args.steps / elapsed
     copy_gbps = measured_copy_peak(torch)                                       # after the timed region
     s_f = s_p = 4
-    bytes_pts = b_adv(K, order, s_p, s_f)
-    adv_s = ms["advect"] / 1e3
-    achieved = (ny_local * nx * nsteps) * bytes_pts / adv_s / 1e9            # per GPU, dominant kernel
-    sig_s = ms["sigma"] / 1e3
-    sigma_gbps = (ny_local * nx) * 3 * s_p / sig_s / 1e9
+    n_launch = max(len(members), 1)
+    pts_launch = (hi - lo) * nx * nsteps                                        # per GPU, one advect launch
+    adv_ms = ms["advect"] / n_launch
+    sig_s = ms["sigma"] / n_launch / 1e3
+    sigma_gbps = (hi - lo) * nx * 3 * s_p / sig_s / 1e9
+    # compulsory HBM bytes of one launch: the nsteps+1 levels of img it reads, the nsteps of ext, seeds, outputs
+    lvl_bytes = 2 * (fny + 3) * (fnx + 3) * s_f * (2 if order == 3 else 1)
+    comp = lvl_bytes * (2 * nsteps + 1) + 2 * (hi - lo) * nx * s_p * (1 + (nsteps + 1 if args.traj else 0))
 
-    wl = {"seeds": args.seeds, "nt": nt, "order": order, "K": K, "dtype": "f32"}
-    if args.field or args.wind_scale != 1.0 or args.traj:
+    wl = {"workload": wk, "seeds": seeds, "nt": nt, "order": order, "K": K, "dtype": "f32"}
+    if args.field or args.wind_scale != 1.0 or args.traj or (wk == "c3" and scaling == "strong" and world > 1):
         wl["variant"] = True     # no committed counter summary matches a non-headline variant
-    tr_adv = pmc_traffic("advect_", wl) if world == 1 else None
-    tr_sig = pmc_traffic("sigma_kernel", wl) if world == 1 else None
+    names = {"c3": "BASELINE configs[2]", "c4": "BASELINE configs[3]", "c5": "BASELINE configs[4]"}
+    std = (seeds, nt) == defaults and not args.field
+    label = (f"{names[wk] if std else 'variant of ' + names[wk]}: "
+             + (f"{args.members} start times x " if wk == "c5" else "")
+             + f"{ny_global}x{nx} seeds"
+             + (f" ({hi - lo} rows per GPU, row-sharded)" if rworld > 1 else "")
+             + (f" ({len(members)} members per GPU)" if wk == "c5" and world > 1 else "")
+             + f" on a {fny}x{fnx} synthetic ERA5-like wind series, {nt} levels ({nsteps} steps"
+             + (" per member" if wk == "c5" else "") + ", dt=-900 s), fp32")
     out = {
-        "metric": "particle-timesteps/sec (+ FTLE Mcells/sec) at 4096^2 seeds per GPU",
+        "metric": "particle-timesteps/sec (+ FTLE Mcells/sec) at 4096^2 seeds per GPU" if wk == "c3" and scaling == "weak"
+                  else f"particle-timesteps/sec (+ FTLE Mcells/sec), workload {wk}, {scaling} scaling",
         "value": value,
         "unit": "particle-timesteps/s",
         "n_gpus": world,
@@ -282,58 +434,37 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[2]: {ny_local}x{nx} seeds per GPU (global {ny_global}x{nx}, row-sharded) on a "
-                        f"{fny}x{fnx} synthetic ERA5-like wind series, {nt} levels ({nsteps} steps, dt=-900 s), fp32",
+            "workload": label,
             "SETTLS_order": K, "interp_order": order, "cyclic_xboundary": True,
             **({"wind_scale": args.wind_scale} if args.wind_scale != 1.0 else {}),
             **({"field": [fny, fnx]} if args.field else {}),
             **({"return_traj": True} if args.traj else {}),
-            "step": "pack + fused advect + halo exchange + sigma; u/v/seeds resident in HBM",
+            "step": "pack + fused advect + halo exchange + sigma" + (" per member" if wk == "c5" else "")
+                    + "; u/v/seeds resident in HBM",
         },
-        "advect_particle_timesteps_per_s": ny_global * nx * nsteps / adv_s,
-        "ftle_mcells_per_s": ny_global * nx / sig_s / 1e6,
+        "advect_particle_timesteps_per_s": pts_launch * n_launch * world / (ms["advect"] / 1e3),
+        "ftle_mcells_per_s": (hi - lo) * nx * n_launch * world / (ms["sigma"] / 1e3) / 1e6,
         "kernel_ms": ms,
-        "roofline": {
-            "bound": "hbm", "kernel": "advect_lds_kernel<%d,%d,true>" % (order, 4 if K == 4 else -1),
-            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "measured_copy_peak": copy_gbps, "frac_of_measured_copy_peak": achieved / copy_gbps,
-            "traffic": tr_adv[0] if tr_adv else None,
-            "traffic_source": tr_adv[1] if tr_adv else None,
-            "algorithmic_bytes_per_launch": (ny_local * nx * nsteps) * bytes_pts,
-            "limiting_unit": issue_counters("advect_lds_kernel<%d," % order, wl) if world == 1 else None,
-            "algorithmic_bytes_per_particle_timestep": bytes_pts,
-            "note": "achieved = B_adv(K,order) x seeds x steps / HIP-event duration of the fused advect launch "
-                    "(per GPU); the taps are served from L2/Infinity Cache, so this is an algorithmic, not an "
-                    "HBM-traffic, figure (SURVEY 8d)",
-        },
+        "roofline": {**roofline(advect_kernel, "valu" if "lds" in advect_kernel else "tcp", pts_launch, adv_ms, K, order,
+                                s_p, s_f, True, comp, wl, csrc),
+                     "measured_copy_peak_GBps": copy_gbps},
         "roofline_sigma": {
             "bound": "hbm", "kernel": "sigma_kernel_f32", "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": sigma_gbps / copy_gbps,
-            "traffic": tr_sig[0] if tr_sig else None,
             "algorithmic_bytes_per_cell": 3 * s_p,
         },
     }
+    if halo_check is not None:
+        out["halo_check"] = halo_check
 
     # ---- CPU baseline: the oracle (numpy+scipy port) on a bounded sample, rank 0, N=1 only ----
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        from oracle import lcs_oracle as O
-        n_s, st_s = 1024, min(32, nsteps)
-        sl, so = flows.seed_grid(n_s, n_s, lat, lon)
-        c0 = time.perf_counter()
-        O.lcs(u[:st_s + 1], v[:st_s + 1], lat, lon, timestep=dt, SETTLS_order=K, interp_order=order,
-              cyclic_xboundary=True, seed_lat=sl, seed_lon=so)
-        c1 = time.perf_counter()
-        out["cpu_baseline"] = {
-            "value": n_s * n_s * st_s / (c1 - c0), "unit": "particle-timesteps/s", "cores": 1, "kind": "port",
-            "sample": f"{n_s}x{n_s} seeds x {st_s} steps of the same field and settings, advect+sigma, "
-                      f"oracle/lcs_oracle.py (scipy.ndimage.map_coordinates + LAPACK SVD, single thread), "
-                      f"{c1 - c0:.1f} s on a host with {os.cpu_count()} cores",
-        }
+        out["cpu_baseline"] = cpu_baseline(flows, u, v, lat, lon, dt, K, order, nsteps)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

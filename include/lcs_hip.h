@@ -74,6 +74,14 @@ int lc_ctx_set_stream(lc_ctx *ctx, void *hip_stream /* hipStream_t; NULL = the d
 int lc_ctx_use_own_stream(lc_ctx *ctx); /* back to the context's private stream */
 int lc_sync(lc_ctx *ctx);
 
+/* Kernel choice of lc_advect for float32 + packed_ext: 1 = per-wave LDS tiles (default), 0 = direct gathers.
+ * -1 restores the default.  The environment variable LCS_LDS_TILES (0/1) sets the initial value, read ONCE in
+ * lc_ctx_create (profiling A/B; results are bit-identical either way).  No reference counterpart. */
+int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode);
+/* Name of the kernel the context's last lc_advect call launched (static string, "" before the first call);
+ * what a profiler shows, so a benchmark labels its numbers with the kernel that actually ran. */
+const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx);
+
 /* ---- device memory (so a ctypes-only host needs nothing else) ---------- */
 int lc_malloc(lc_ctx *ctx, size_t bytes, void **dev_out);
 int lc_free(lc_ctx *ctx, void *dev);

@@ -26,6 +26,19 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def csrc_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and the public header: what a committed rocprof
+    summary is stamped with, so a number replayed from profiles/ can be tied to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "lcs_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -20,8 +20,6 @@
 // the 2x2 (order 1) or 4x4 (order 3) tap window of a wrapped coordinate is
 // always in range and its (u,v) pairs are contiguous along x, so one sample
 // position costs 2 (order 1, float) wide loads per level instead of 8 scalars.
-#include <cstdlib>
-
 #include "lcs_common.h"
 
 namespace {
@@ -947,27 +945,31 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1) advec
 
 template <typename T, int ORDER>
 struct LdsLaunch {
-    static bool launch(const AdvectArgs<T> &, int, hipStream_t) { return false; }
+    static const char *launch(const AdvectArgs<T> &, int, hipStream_t) { return nullptr; }
 };
 template <int ORDER>
 struct LdsLaunch<float, ORDER> {
-    static bool launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
+    // returns the launched kernel's name, or NULL when the LDS kernel does not apply
+    static const char *launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
         // the fixed-size tile must fit inside one padded time level
-        if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return false;
+        if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return nullptr;
         // SETTLS_order = 0 (the library default): one Euler sample per level and nothing to stage a tile
         // for -- the direct-gather kernel is the faster one (2.2 vs 2.45 ms on C3; an Euler-from-LDS variant
         // with its tile loaded a level ahead measured 2.5 ms)
-        if (A.K == 0) return false;
+        if (A.K == 0) return nullptr;
         // K = 4 is the setting the reference's example and drivers use
-        if (A.K == 4 && A.cyclic)
+        if (A.K == 4 && A.cyclic) {
             hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, true>), dim3(grid), dim3(BLOCK), 0, st, A);
-        else if (A.K == 4)
+            return ORDER == 3 ? "advect_lds_kernel<3, 4, true>" : "advect_lds_kernel<1, 4, true>";
+        } else if (A.K == 4) {
             hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, false>), dim3(grid), dim3(BLOCK), 0, st, A);
-        else if (A.cyclic)
+            return ORDER == 3 ? "advect_lds_kernel<3, 4, false>" : "advect_lds_kernel<1, 4, false>";
+        } else if (A.cyclic) {
             hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, true>), dim3(grid), dim3(BLOCK), 0, st, A);
-        else
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, false>), dim3(grid), dim3(BLOCK), 0, st, A);
-        return true;
+            return ORDER == 3 ? "advect_lds_kernel<3, -1, true>" : "advect_lds_kernel<1, -1, true>";
+        }
+        hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, false>), dim3(grid), dim3(BLOCK), 0, st, A);
+        return ORDER == 3 ? "advect_lds_kernel<3, -1, false>" : "advect_lds_kernel<1, -1, false>";
     }
 };
 
@@ -1060,21 +1062,29 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // 10.7-11.9 ms against 11.0 for direct gathers: its global-gather fallback is per lane, so the worst
     // case costs the tile bookkeeping only.  An adaptive "skip the tile when most lanes miss" vote was
     // measured and dropped (it costs 5 % everywhere to save 8 % in that extreme).
-    // LCS_LDS_TILES=0/1 overrides (profiling).
-    bool use_lds = true;
-    if (const char *ev = getenv("LCS_LDS_TILES")) use_lds = ev[0] == '1';
+    // lc_ctx_set_lds_tiles / LCS_LDS_TILES (read once at context creation) override (profiling).
+    const bool use_lds = ctx->lds_tiles != 0;
     const bool fused64 = sizeof(T) == 8 && A.ext != nullptr;  // opt-in single-sample iterations in float64
+    const bool f64 = sizeof(T) == 8;
+    const char *name = nullptr;
     if (order == 3) {
-        if (fused64)
+        if (fused64) {
             hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-        else if (!(use_lds && LdsLaunch<T, 3>::launch(A, grid, ctx->stream)))
+            name = "advect_kernel<double, 3, true>";
+        } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream)))) {
             hipLaunchKernelGGL((advect_kernel<T, 3>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+            name = f64 ? "advect_kernel<double, 3, false>" : "advect_kernel<float, 3, false>";
+        }
     } else {
-        if (fused64)
+        if (fused64) {
             hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-        else if (!(use_lds && LdsLaunch<T, 1>::launch(A, grid, ctx->stream)))
+            name = "advect_kernel<double, 1, true>";
+        } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream)))) {
             hipLaunchKernelGGL((advect_kernel<T, 1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+            name = f64 ? "advect_kernel<double, 1, false>" : "advect_kernel<float, 1, false>";
+        }
     }
+    ctx->last_advect_kernel = name;
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }

@@ -1,6 +1,7 @@
 // C ABI glue: contexts, device memory, error strings, field packing entry point,
 // Gaussian smoothing of the departure fields, and the one-call host entry point.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,9 +40,21 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
         return LC_EHIP;
     }
     c->stream = c->own_stream;
+    c->lds_tiles = 1;
+    if (const char *ev = getenv("LCS_LDS_TILES")) c->lds_tiles = ev[0] == '0' ? 0 : 1;  // read once, here
+    c->last_advect_kernel = "";
     *out = c;
     return LC_OK;
 }
+
+extern "C" int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode) {
+    LC_REQUIRE(ctx, "lc_ctx_set_lds_tiles: null context");
+    LC_REQUIRE(mode >= -1 && mode <= 1, "lc_ctx_set_lds_tiles: mode must be -1, 0 or 1");
+    ctx->lds_tiles = mode < 0 ? 1 : mode;
+    return LC_OK;
+}
+
+extern "C" const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_advect_kernel : ""; }
 
 extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
     if (!ctx) return LC_OK;
@@ -265,6 +278,11 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     LC_REQUIRE(nt >= 2 && ny_f >= 4 && nx_f >= 4 && ny >= 1 && nx >= 1, "lc_lcs_host: bad sizes");
     LC_REQUIRE((traj_x == nullptr) == (traj_y == nullptr), "lc_lcs_host: traj_x/traj_y must be set together");
     LC_REQUIRE(!sigma_out || (ny >= 5 && nx >= 5), "lc_lcs_host: sigma needs at least a 5x5 seed grid");
+    // validated before any allocation (a negative nsteps must not turn into a huge hipMalloc)
+    LC_REQUIRE(settls_order >= 0, "lc_lcs_host: SETTLS_order must be >= 0");
+    LC_REQUIRE(t0 >= 0 && nsteps >= 0 && t0 + nsteps <= nt - 1, "lc_lcs_host: steps [%d,%d) need levels up to %d, have %d",
+               t0, t0 + nsteps, t0 + nsteps, nt);
+    LC_REQUIRE(gauss_sigma >= 0.0 || gauss_sigma != gauss_sigma, "lc_lcs_host: gauss_sigma must be >= 0 (0 = no smoothing)");
     if (interp_order != 1 && interp_order != 3) {
         lc_set_error("lc_lcs_host: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
         return LC_EUNSUPPORTED;
@@ -321,7 +339,7 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     if (sigma_out) {
         LC_TRY(sig.alloc(sbytes));
         const void *xs = x.p, *ys = y.p;
-        if (gauss_sigma > 0) {
+        if (gauss_sigma > 1e-15) {  // sigma = 0: scipy returns an unsmoothed copy
             LC_TRY(gx.alloc(sbytes));
             LC_TRY(gy.alloc(sbytes));
             LC_TRY(gtmp.alloc(sbytes));

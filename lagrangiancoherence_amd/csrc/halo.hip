@@ -12,9 +12,19 @@
 // works -- on a machine without it, and so that a host process that already carries an RCCL (PyTorch
 // does) shares that copy instead of loading a second one.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include "lcs_common.h"
+
+// The handful of RCCL declarations this file uses, stated here so that the library builds without the RCCL
+// headers (the functions themselves are resolved with dlopen at run time).  Values as in <rccl/rccl.h>
+// (NCCL ABI: ncclFloat32 = 7, ncclFloat64 = 8, 128-byte unique id); a static_assert-style check against the
+// real header runs in tests/test_capi_symbols.py where that header is installed.
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
 
 struct lc_comm {
     ncclComm_t comm;

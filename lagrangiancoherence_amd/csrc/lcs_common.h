@@ -11,6 +11,8 @@ struct lc_ctx {
     int device;
     hipStream_t own_stream;
     hipStream_t stream;  // the one work is enqueued on (own or borrowed)
+    int lds_tiles;       // lc_advect float32 kernel choice: 1 LDS tiles, 0 direct gathers (LCS_LDS_TILES at creation)
+    const char *last_advect_kernel;
 };
 
 void lc_set_error(const char *fmt, ...);

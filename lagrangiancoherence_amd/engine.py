@@ -80,6 +80,14 @@ class Engine:
         except Exception:
             pass
 
+    def set_lds_tiles(self, mode: int):
+        """lc_advect float32 kernel choice: 1 per-wave LDS tiles (default), 0 direct gathers, -1 default."""
+        _capi.check(self.lib.lc_ctx_set_lds_tiles(self.ctx, int(mode)), self.lib)
+
+    def last_advect_kernel(self) -> str:
+        """Name of the kernel the last :meth:`advect` call launched (as a profiler shows it)."""
+        return self.lib.lc_ctx_last_advect_kernel(self.ctx).decode()
+
     # ------------------------------------------------------------------ plumbing
     def _use_current_stream(self):
         s = self.torch.cuda.current_stream(self.device).cuda_stream
@@ -168,6 +176,10 @@ class Engine:
         x_buf = self._empty((n_lo + ny + n_hi, nx), dtype)
         y_buf = self._empty((n_lo + ny + n_hi, nx), dtype)
         x, y = x_buf[n_lo:n_lo + ny], y_buf[n_lo:n_lo + ny]
+        if halo:  # rows to be received: NaN until the exchange fills them, so a skipped exchange cannot pass unnoticed
+            for buf in (x_buf, y_buf):
+                buf[:n_lo].fill_(float("nan"))
+                buf[n_lo + ny:].fill_(float("nan"))
         tx = ty = None
         if return_traj:
             tx = self._empty((nsteps + 1, ny, nx), dtype)
@@ -328,7 +340,8 @@ class Engine:
                           nsteps, return_traj)
         x, y = res[0], res[1]
         xs, ys = x, y
-        if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool):
+        # scipy's gaussian_filter returns an unsmoothed copy for sigma = 0 (LCS/LCS.py:187-190): skip the filter
+        if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool) and gauss_sigma > 1e-15:
             xs = self.gaussian_filter(x, gauss_sigma)
             ys = self.gaussian_filter(y, gauss_sigma)
         # spacing evaluated in the coordinate dtype, as lat[1]-lat[0] is in numpy (tools.py:255-256)

@@ -15,6 +15,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lagrangiancoherence_amd.build import csrc_hash  # noqa: E402  (stamps the summary with the sources it was measured on)
+
 
 def short(name):
     n = name.replace("void ", "")
@@ -54,7 +57,7 @@ def main():
             d["hbm_bytes_per_launch"] = (2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024
         if k in stats:
             d["avg_ms_kernel_trace"] = stats[k]
-    json.dump({"workload": workload, "kernels": pmc,
+    json.dump({"workload": workload, "csrc_hash": csrc_hash(), "kernels": pmc,
                "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts half)"},
               open(out + "_pmc_traffic.json", "w"), indent=1, sort_keys=True)
     print(json.dumps(pmc, indent=1))

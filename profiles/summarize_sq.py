@@ -21,6 +21,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lagrangiancoherence_amd.build import csrc_hash  # noqa: E402  (stamps the summary with the sources it was measured on)
+
 CUS = 256
 
 
@@ -60,7 +63,7 @@ def main():
                 "l2_hit_frac": (c.get("TCC_HIT_sum", 0) / (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))) if c.get("TCC_HIT_sum") else None,
             }
         kernels[k] = {**c, "derived": der}
-    json.dump({"workload": workload, "kernels": kernels,
+    json.dump({"workload": workload, "csrc_hash": csrc_hash(), "kernels": kernels,
                "note": "rocprofv3 --pmc passes (counter sets in profiles/README.md) over bench.py --steps 1 --warmup 0; "
                        "per-launch averages; GRBM_GUI_ACTIVE is summed over 8 XCDs"},
               open(out + "_pmc_sq_tcp.json", "w"), indent=1, sort_keys=True)

@@ -1,5 +1,5 @@
 """bench.py prints exactly one JSON line carrying the driver's contract fields plus `roofline` and
-`cpu_baseline` (a miniature workload here; the headline sizes are bench.py's defaults)."""
+`cpu_baseline` (miniature workloads here; the headline sizes are bench.py's defaults)."""
 import json
 import os
 import subprocess
@@ -11,24 +11,73 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_prints_one_json_line_with_the_contract_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--seeds", "256", "--nt", "5"], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+def _bench(*args, env=None, launcher=()):
+    r = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env={**os.environ, **(env or {})})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    d = _bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--seeds", "256", "--nt", "5")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "particle-timesteps/s" and d["value"] > 0 and d["vs_baseline"] is None
-    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic"
+    # the label says what actually ran: a 256^2 x 4-step variant, not the headline configuration
+    assert d["config"]["workload"].startswith("variant of BASELINE configs[2]: 256x256 seeds")
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm", "algorithmic_GBps", "csrc_hash"):
         assert k in rf, k
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    # the fused LDS-tile kernel is bound by vector-ALU instruction throughput; the fraction is a physical one
+    assert rf["bound"] == "valu" and rf["kernel"] == "advect_lds_kernel<1, 4, true>"
+    assert rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert 0 < rf["frac"] <= 1 and 0 < rf["hbm"]["compulsory_frac"] <= 1
+    # no committed counter summary matches a miniature variant: replayed fields are null, never stale numbers
+    assert rf["traffic"] is None and rf["limiting_unit"] is None and rf["hbm"]["hbm_traffic_frac"] is None
+    assert d["roofline_sigma"]["bound"] == "hbm" and 0 < d["roofline_sigma"]["frac"] <= 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     # value = seeds x steps-per-pass x passes / wall time
     assert abs(d["value"] - 256 * 256 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+
+
+def test_bench_direct_kernel_is_named_as_such():
+    d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--settls", "0", "--no-cpu-baseline")
+    assert d["roofline"]["kernel"] == "advect_kernel<float, 1, false>" and d["roofline"]["bound"] == "tcp"
+    d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--no-cpu-baseline", env={"LCS_LDS_TILES": "0"})
+    assert d["roofline"]["kernel"] == "advect_kernel<float, 1, false>"
+
+
+@pytest.mark.parametrize("wk,extra,units", [
+    ("c4", ["--seeds", "512", "--nt", "9"], 512 * 512 * 8),
+    ("c5", ["--seeds", "256", "--nt", "14", "--members", "4"], 4 * 256 * 256 * 10),
+])
+def test_bench_c4_c5_workloads(wk, extra, units):
+    d = _bench("--workload", wk, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra)
+    assert d["scaling"] == "strong" and wk in d["metric"]
+    assert abs(d["value"] - units * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    assert d["config"]["workload"].startswith("variant of BASELINE configs[%d]" % (3 if wk == "c4" else 4))
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_rehearsal_carries_a_halo_check(scaling):
+    """N=2 over gloo with both ranks on GPU 0 (RCCL refuses two ranks on one device): the JSON line carries
+    halo_check, and the exchanged rows equal the redundantly advected ones bit for bit."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = _bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--seeds", "256", "--nt", "5", "--scaling", scaling,
+               launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port)),
+               env={"LCS_BENCH_BACKEND": "gloo", "LCS_BENCH_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling
+    hc = d["halo_check"]
+    assert hc["timed_path"] == "torch.distributed" and hc["timed_path_ok"] is True
+    rows = 512 if scaling == "weak" else 256
+    assert abs(d["value"] - rows * 256 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6

@@ -64,3 +64,23 @@ def test_engine_refuses_to_run_without_gpu():
     from lagrangiancoherence_amd.engine import Engine
     with pytest.raises(RuntimeError, match="no CPU path"):
         Engine(0)
+
+
+def test_local_rccl_declarations_match_the_installed_header():
+    """csrc/halo.hip states the few RCCL declarations it uses (so the library builds without RCCL headers);
+    where <rccl/rccl.h> is installed, the values must agree."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no RCCL header on this machine")
+    text = open(hdr).read()
+    assert re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+128\b", text)
+    assert re.search(r"ncclSuccess\s*=\s*0\b", text)
+    assert re.search(r"ncclFloat32\s*=\s*7\b", text) and re.search(r"ncclFloat64\s*=\s*8\b", text)
+    src = open(os.path.join(ROOT, "lagrangiancoherence_amd", "csrc", "halo.hip")).read()
+    assert "#include <rccl" not in src
+    assert "ncclFloat32 = 7, ncclFloat64 = 8" in src and "char internal[128]" in src
+
+
+def test_context_options_reject_bad_arguments(lib):
+    assert lib.lc_ctx_set_lds_tiles(None, 1) == _capi.LC_EINVAL
+    assert lib.lc_ctx_last_advect_kernel(None) == b""

@@ -11,10 +11,10 @@ eng = Engine(0)
 u, v, lat, lon = flows.era5_like(nt=nt)
 slat, slon = flows.seed_grid(4096, 4096, lat, lon)
 f = eng.prepare_field(u, v, lat, lon, order)
-os.environ["LCS_LDS_TILES"] = "1"
+eng.set_lds_tiles(1)
 x1, y1 = eng.advect(f, slat, slon, -900.0, 4, order, True)
 x1b, y1b = eng.advect(f, slat, slon, -900.0, 4, order, True)
-os.environ["LCS_LDS_TILES"] = "0"
+eng.set_lds_tiles(0)
 x0, y0 = eng.advect(f, slat, slon, -900.0, 4, order, True)
 torch.cuda.synchronize()
 print("LDS run-to-run identical:", bool(torch.equal(x1, x1b) and torch.equal(y1, y1b)))
