@@ -56,6 +56,20 @@ enum lc_status {
     LC_ERCCL = -5         /* RCCL missing or an RCCL call failed             */
 };
 
+/* lc_advect's cyclic_x argument: what happens to a longitude that leaves [lon_min, lon_max]
+ * (LCS/trajectory.py:92-97, 118-123). */
+enum lc_xboundary {
+    LC_X_CLAMP_POINT = 0, /* cyclic_xboundary=False, each parcel clamped on its own (NOT the reference when a parcel
+                             leaves the box: see LC_X_CLAMP_REFERENCE_OUTER) */
+    LC_X_CYCLIC = 1,      /* cyclic_xboundary=True: wrap hard-coded to +-180 with Python's floor-mod (Q7)          */
+    /* cyclic_xboundary=False exactly as the reference computes it: `positions_x[np.where(x < x_min)] = x_min` on a
+     * DataArray is orthogonal indexing, so every (row, col) in the cross product of offending rows and offending
+     * columns is set (trajectory.py:96-97, 122-123).  lc_advect runs the fused kernel first and, only
+     * if a parcel really left the box, re-runs sub-step by sub-step with that rule (synchronous in this mode;
+     * needs the whole seed grid: row0 = 0, ny = ny_global). */
+    LC_X_CLAMP_REFERENCE_OUTER = 2
+};
+
 enum lc_tensor_layout {
     LC_LAYOUT_REFERENCE = 0, /* 9 comps reshaped row-major to 3x3 (LCS/LCS.py:152-153) */
     LC_LAYOUT_PHYSICAL = 1   /* Jacobian d(X,Y,Z)/d(x,y); NOT reference behaviour      */
@@ -139,6 +153,7 @@ int lc_field_extrapolate(lc_ctx *ctx, const void *packed_dev, int dtype,
  *                applies to the global row index.  Single GPU: 0, ny.
  *   timestep     seconds, sign = direction; fields are always consumed in stored
  *                order t0, t0+1, ... (trajectory.py:58-60,80)
+ *   cyclic_x     enum lc_xboundary
  *   t0, nsteps   first time level and number of steps (t0+nsteps <= nt-1);
  *                the reference is t0=0, nsteps=nt-1
  *   x_out,y_out  [ny*nx] departure longitude / latitude, degrees

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "liblcs_hip.so")
 LC_F32, LC_F64, LC_F64_WIND_F32 = 0, 1, 2
 LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM, LC_ERCCL = 0, -1, -2, -3, -4, -5
 LC_LAYOUT_REFERENCE, LC_LAYOUT_PHYSICAL = 0, 1
+LC_X_CLAMP_POINT, LC_X_CYCLIC, LC_X_CLAMP_REFERENCE_OUTER = 0, 1, 2
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 

@@ -53,6 +53,7 @@ struct AdvectArgs {
     int wind_f32;  // double instantiation only: the wind is float32-valued -> numpy's promotion rules (Q10)
     T *x_out, *y_out, *traj_x, *traj_y;
     int ntx, ntiles;
+    unsigned *clamp_flag;  // NULL, or set to 1 when the non-cyclic longitude clamp moves any parcel (Q9)
 };
 
 template <typename T>
@@ -246,9 +247,11 @@ __device__ __forceinline__ void clamp_position(const AdvectArgs<T> &A, T &x, T &
         if (!(x > T(-180))) x = pymod180<T>(x);
         if (!(x < T(180))) x = T(-180) + pymod180<T>(x);
     } else {
-        // per-point clamp (documented divergence from the outer-indexing defect Q9)
-        if (x < A.x_min) x = A.x_min;
-        if (x > A.x_max) x = A.x_max;
+        // per-point clamp; the reference's outer-product assignment (Q9) is lc_advect's LC_X_CLAMP_REFERENCE_OUTER
+        if (x < A.x_min || x > A.x_max) {
+            if (A.clamp_flag) *A.clamp_flag = 1u;
+            x = x < A.x_min ? A.x_min : A.x_max;
+        }
     }
 }
 
@@ -425,9 +428,9 @@ __device__ __forceinline__ void clamp_position_f(const AdvectArgs<float> &A, flo
             if (!(x > -180.0f)) x = pymod180<float>(x);
             if (!(x < 180.0f)) x = -180.0f + pymod180<float>(x);
         }
-    } else {
-        x = x < A.x_min ? A.x_min : x;  // NaN stays NaN, as in the reference
-        x = x > A.x_max ? A.x_max : x;
+    } else if (x < A.x_min || x > A.x_max) {  // NaN stays NaN, as in the reference
+        if (A.clamp_flag) *A.clamp_flag = 1u;
+        x = x < A.x_min ? A.x_min : A.x_max;
     }
 }
 
@@ -719,11 +722,9 @@ __device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 
             if (!(x < 180.0f)) x = -180.0f + pymod180<float>(x);
             p.x = x;
         }
-    } else {
-        float x = p.x;
-        x = x < A.x_min ? A.x_min : x;  // NaN stays NaN, as in the reference
-        x = x > A.x_max ? A.x_max : x;
-        p.x = x;
+    } else if (p.x < A.x_min || p.x > A.x_max) {  // NaN stays NaN, as in the reference
+        if (A.clamp_flag) *A.clamp_flag = 1u;
+        p.x = p.x < A.x_min ? A.x_min : A.x_max;
     }
 }
 
@@ -1007,6 +1008,167 @@ __global__ void __launch_bounds__(BLOCK, (sizeof(T) == 8 && ORDER == 1) ? 8 : 1)
         InteriorPath<T, ORDER, FUSED>::run(A, iy, ix);
 }
 
+
+// ======================================================================================
+// LC_X_CLAMP_REFERENCE_OUTER -- the reference's non-cyclic longitude clamp, as written (Q9):
+//     positions_x[np.where(positions_x < x_min)] = x_min          (LCS/trajectory.py:96-97, 122-123)
+// on a DataArray is ORTHOGONAL indexing: every (row, col) in the cross product of the rows and the columns
+// that hold an offending parcel is set.  That couples all seeds after every sub-step, so this path runs one
+// sub-step per launch with the positions in global memory: [sample + update + flag rows/cols below x_min]
+// -> [flag rows/cols above x_max, on the array as it stands after the first assignment] -> next sub-step,
+// which applies both cross products while loading.  Two-sample form and operation order of advect_seed.
+// Only reached when a parcel really left the box (lc_advect tries the fused kernel first).
+// ======================================================================================
+template <typename T>
+struct OuterArgs {
+    T *x, *y, *eu, *ev;                    // positions (= x_out, y_out) and the level's Euler sample
+    unsigned *rlo, *clo, *rhi, *chi;       // this sub-step's flags
+    const unsigned *p_rlo, *p_clo, *p_rhi, *p_chi;  // the previous sub-step's (NULL before the first)
+};
+
+template <typename T>
+__device__ __forceinline__ T outer_applied(const AdvectArgs<T> &A, const unsigned *rlo, const unsigned *clo,
+                                           const unsigned *rhi, const unsigned *chi, int iy, int ix, T x) {
+    if (rlo) {
+        if (rlo[iy] && clo[ix]) x = A.x_min;  // first assignment ...
+        if (rhi[iy] && chi[ix]) x = A.x_max;  // ... then the second, on top of it
+    }
+    return x;
+}
+
+template <typename T, int ORDER>
+__global__ void outer_substep_kernel(const AdvectArgs<T> A, const OuterArgs<T> O, int level, int is_iter) {
+#pragma clang fp contract(off)
+    const size_t n = (size_t)A.ny * A.nx;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int iy = (int)(i / A.nx), ix = (int)(i - (size_t)iy * A.nx);
+        T x = outer_applied<T>(A, O.p_rlo, O.p_clo, O.p_rhi, O.p_chi, iy, ix, O.x[i]);
+        T y = O.y[i];
+        const T ys = A.seed_lat[iy];
+        const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((ys * T(3.141592653589793)) / T(180))));
+        const bool pole = iy < A.order || iy >= A.ny_global - A.order;  // tools.py:24-33 (Q3); row0 == 0 here
+        const T *lvl = (pole ? A.lin : A.img) + (size_t)level * A.level_elems;
+        if (!is_iter) {
+            Pair<T> e = pole ? sample<T, 1, false>(lvl, A, x, y) : sample<T, ORDER, true>(lvl, A, x, y);
+            e.u = round_sample<T>(A, e.u);
+            e.v = round_sample<T>(A, e.v);
+            O.eu[i] = e.u;
+            O.ev[i] = e.v;
+            y = y + lat_increment<T>(A, A.dtcy, e.v);          // trajectory.py:86
+            x = axpy<T>(A.dt * cx_conv, e.u, x);               // :87
+        } else {
+            const T *nxt = lvl + A.level_elems;
+            Pair<T> c, nn;
+            if (pole) {
+                const Tap<T> tap = locate<T, 1, false>(A, x, y);
+                c = fetch<T, 1>(lvl, A, tap);
+                nn = fetch<T, 1>(nxt, A, tap);
+            } else {
+                const Tap<T> tap = locate<T, ORDER, true>(A, x, y);
+                c = fetch<T, ORDER>(lvl, A, tap);
+                nn = fetch<T, ORDER>(nxt, A, tap);
+            }
+            c.u = round_sample<T>(A, c.u);
+            c.v = round_sample<T>(A, c.v);
+            nn.u = round_sample<T>(A, nn.u);
+            nn.v = round_sample<T>(A, nn.v);
+            const T eu = O.eu[i], ev = O.ev[i];
+            y = y + lat_increment<T>(A, A.hdtcy, settls_bracket<T>(A, ev, c.v, nn.v));   // :110
+            x = axpy<T>(A.half_dt * cx_conv, settls_bracket<T>(A, eu, c.u, nn.u), x);     // :112
+        }
+        y = (y > A.y_min) ? y : A.y_min;  // :89-90 / 115-116 (Q8)
+        y = (y < A.y_max) ? y : A.y_max;
+        O.x[i] = x;
+        O.y[i] = y;
+        if (x < A.x_min) {                // rows / columns of np.where(positions_x < x_min)
+            O.rlo[iy] = 1u;
+            O.clo[ix] = 1u;
+        }
+    }
+}
+
+template <typename T>
+__global__ void outer_hi_kernel(const AdvectArgs<T> A, const OuterArgs<T> O) {
+    const size_t n = (size_t)A.ny * A.nx;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int iy = (int)(i / A.nx), ix = (int)(i - (size_t)iy * A.nx);
+        T x = O.x[i];
+        if (O.rlo[iy] && O.clo[ix]) x = A.x_min;  // the array np.where(positions_x > x_max) looks at
+        if (x > A.x_max) {
+            O.rhi[iy] = 1u;
+            O.chi[ix] = 1u;
+        }
+    }
+}
+
+template <typename T>
+__global__ void outer_store_kernel(const AdvectArgs<T> A, const OuterArgs<T> O, T *dst_x, T *dst_y, int seeds_only) {
+    const size_t n = (size_t)A.ny * A.nx;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int iy = (int)(i / A.nx), ix = (int)(i - (size_t)iy * A.nx);
+        if (seeds_only) {  // trajectory.py:68-70: the seed grid
+            dst_x[i] = A.seed_lon[ix];
+            dst_y[i] = A.seed_lat[iy];
+        } else {
+            dst_x[i] = outer_applied<T>(A, O.rlo, O.clo, O.rhi, O.chi, iy, ix, O.x[i]);
+            dst_y[i] = O.y[i];
+        }
+    }
+}
+
+template <typename T>
+int advect_outer_impl(lc_ctx *ctx, AdvectArgs<T> A) {
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)A.ny * A.nx;
+    const size_t nflag = 2 * ((size_t)A.ny + A.nx);
+    T *e = nullptr;
+    unsigned *flags = nullptr;
+    LC_HIP_CHECK(hipMallocAsync((void **)&e, 2 * n * sizeof(T), st));
+    hipError_t er = hipMallocAsync((void **)&flags, 2 * nflag * sizeof(unsigned), st);
+    if (er != hipSuccess) {
+        (void)hipFreeAsync(e, st);
+        LC_HIP_CHECK(er);
+    }
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    OuterArgs<T> O = {};
+    O.x = A.x_out;
+    O.y = A.y_out;
+    O.eu = e;
+    O.ev = e + n;
+    hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.x_out, A.y_out, 1);
+    if (A.traj_x) hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.traj_x, A.traj_y, 1);
+    int sub = 0;
+    for (int s = 0; s < A.nsteps; ++s) {
+        for (int k = 0; k <= A.K; ++k, ++sub) {
+            unsigned *cur = flags + (size_t)(sub & 1) * nflag, *prev = flags + (size_t)((sub & 1) ^ 1) * nflag;
+            (void)hipMemsetAsync(cur, 0, nflag * sizeof(unsigned), st);
+            O.rlo = cur;
+            O.clo = cur + A.ny;
+            O.rhi = O.clo + A.nx;
+            O.chi = O.rhi + A.ny;
+            O.p_rlo = sub ? prev : nullptr;
+            O.p_clo = prev + A.ny;
+            O.p_rhi = O.p_clo + A.nx;
+            O.p_chi = O.p_rhi + A.ny;
+            if (A.order == 3)
+                hipLaunchKernelGGL((outer_substep_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, A, O, A.t0 + s, k > 0);
+            else
+                hipLaunchKernelGGL((outer_substep_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, A, O, A.t0 + s, k > 0);
+            hipLaunchKernelGGL((outer_hi_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O);
+        }
+        if (A.traj_x)
+            hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O,
+                               A.traj_x + (size_t)(s + 1) * n, A.traj_y + (size_t)(s + 1) * n, 0);
+    }
+    if (sub) hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.x_out, A.y_out, 0);
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(e, st);
+    (void)hipFreeAsync(flags, st);
+    LC_HIP_CHECK(le);
+    ctx->last_advect_kernel = "outer_substep_kernel";
+    return LC_OK;
+}
+
 template <typename T>
 int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *packed_ext, int nt, int ny_f,
                 int nx_f,
@@ -1044,7 +1206,17 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.hdtcy = (T)((0.5 * timestep) * conv_y);
     A.K = K;
     A.order = order;
-    A.cyclic = cyclic;
+    const bool outer = cyclic == LC_X_CLAMP_REFERENCE_OUTER;
+    A.cyclic = cyclic == LC_X_CYCLIC;
+    A.clamp_flag = nullptr;
+    unsigned *clamp_flag = nullptr;
+    if (outer) {
+        // fused kernel first, with a flag that says whether the clamp ever moved a parcel; if not, per-point and
+        // outer-product clamps coincide (both are no-ops) and the fused result IS the reference's
+        LC_HIP_CHECK(hipMallocAsync((void **)&clamp_flag, sizeof(unsigned), ctx->stream));
+        (void)hipMemsetAsync(clamp_flag, 0, sizeof(unsigned), ctx->stream);
+        A.clamp_flag = clamp_flag;
+    }
     A.t0 = t0;
     A.nsteps = nsteps;
     A.x_out = (T *)x_out;
@@ -1085,6 +1257,19 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         }
     }
     ctx->last_advect_kernel = name;
+    if (outer) {
+        unsigned moved = 0;
+        hipError_t e1 = hipGetLastError();
+        if (e1 == hipSuccess) e1 = hipMemcpyAsync(&moved, clamp_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+        (void)hipFreeAsync(clamp_flag, ctx->stream);
+        LC_HIP_CHECK(e1);
+        A.clamp_flag = nullptr;
+        if (moved) {
+            A.ext = nullptr;  // the exact path keeps the reference's two-sample form
+            return advect_outer_impl<T>(ctx, A);
+        }
+    }
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }
@@ -1186,6 +1371,12 @@ extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed
     LC_REQUIRE(row0 >= 0 && row0 + ny <= ny_global, "lc_advect: rows [%d,%d) outside global grid of %d rows", row0,
                row0 + ny, ny_global);
     LC_REQUIRE(settls_order >= 0, "lc_advect: SETTLS_order must be >= 0");
+    LC_REQUIRE(cyclic_x >= LC_X_CLAMP_POINT && cyclic_x <= LC_X_CLAMP_REFERENCE_OUTER, "lc_advect: bad cyclic_x %d", cyclic_x);
+    if (cyclic_x == LC_X_CLAMP_REFERENCE_OUTER && (row0 != 0 || ny != ny_global)) {
+        lc_set_error("lc_advect: LC_X_CLAMP_REFERENCE_OUTER couples every seed row after every sub-step and cannot be "
+                     "row-sharded (rows [%d,%d) of %d)", row0, row0 + ny, ny_global);
+        return LC_EUNSUPPORTED;
+    }
     LC_REQUIRE(t0 >= 0 && nsteps >= 0 && t0 + nsteps <= nt - 1, "lc_advect: steps [%d,%d) need levels up to %d, have %d",
                t0, t0 + nsteps, t0 + nsteps, nt);
     LC_REQUIRE(x_out && y_out, "lc_advect: null output");

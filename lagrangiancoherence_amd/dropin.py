@@ -17,8 +17,10 @@ Deliberate differences from the reference (all outside the arithmetic):
   * ``isglobal=True`` runs the 0.5 degree regrid and the T20 spectral truncation on the
     device (``preprocess.py``); the truncation restates windspharm/SPHEREPACK's published
     algorithm in float64 and is NOT pinned against pyspharm (not installable here);
-  * non-cyclic longitude clamp is per point (the reference's outer-product indexing
-    is a defect, SURVEY Q9);
+  * ``cyclic_xboundary=False`` (the default of both call forms) reproduces the reference's clamp as it is
+    written -- outer-product assignment over offending rows x columns (LCS/trajectory.py:96-97):
+    the fused kernel runs first and, only if a parcel really left the longitude range, the engine re-runs
+    sub-step by sub-step with that rule (``lc_advect`` mode ``LC_X_CLAMP_REFERENCE_OUTER``);
   * mixed float32/float64 inputs are computed in float64 (engine.common_dtype).
 """
 from __future__ import annotations

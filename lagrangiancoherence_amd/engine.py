@@ -19,10 +19,24 @@ import numpy as np
 
 from . import _capi
 
-__all__ = ["Engine", "PackedField", "lcs_host", "common_dtype"]
+__all__ = ["Engine", "PackedField", "lcs_host", "common_dtype", "x_boundary_mode"]
 
 _NP2LC = {np.dtype(np.float32): _capi.LC_F32, np.dtype(np.float64): _capi.LC_F64}
 _LAYOUTS = {"reference": _capi.LC_LAYOUT_REFERENCE, "physical": _capi.LC_LAYOUT_PHYSICAL}
+
+
+def x_boundary_mode(cyclic_xboundary, noncyclic_clamp=None, whole_grid=True) -> int:
+    """lc_advect's ``cyclic_x`` (enum lc_xboundary).  ``cyclic_xboundary=False`` defaults to the reference's own
+    outer-product clamp (``noncyclic_clamp='reference_outer'``, LCS/trajectory.py:96-97, Q9) whenever the call
+    covers the whole seed grid; a row-sharded call cannot (the rule couples all rows) and takes ``'pointwise'``,
+    which differs from the reference only if a parcel leaves the longitude range."""
+    if cyclic_xboundary:
+        return _capi.LC_X_CYCLIC
+    if noncyclic_clamp is None:
+        noncyclic_clamp = "reference_outer" if whole_grid else "pointwise"
+    if noncyclic_clamp not in ("pointwise", "reference_outer"):
+        raise ValueError(f"noncyclic_clamp {noncyclic_clamp!r}: 'pointwise' or 'reference_outer'")
+    return _capi.LC_X_CLAMP_REFERENCE_OUTER if noncyclic_clamp == "reference_outer" else _capi.LC_X_CLAMP_POINT
 
 
 def common_dtype(*arrays) -> np.dtype:
@@ -159,8 +173,11 @@ class Engine:
 
     # ------------------------------------------------------------------ K1
     def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
-               cyclic_xboundary=True, t0=0, nsteps=None, return_traj=False, row0=0, ny_global=None, halo=None):
+               cyclic_xboundary=True, t0=0, nsteps=None, return_traj=False, row0=0, ny_global=None, halo=None,
+               noncyclic_clamp=None):
         """Departure points of the seed rows given.  Returns (x, y[, traj_x, traj_y]) device tensors.
+
+        ``noncyclic_clamp`` (only with ``cyclic_xboundary=False``): see :func:`x_boundary_mode`.
 
         ``halo=(n_lo, n_hi)``: return ``(n_lo + ny + n_hi, nx)`` buffers with the results in the middle
         rows, so a row-sharded caller can receive its neighbours' rows in place (sharded.py)."""
@@ -190,8 +207,8 @@ class Engine:
             self._ptr(field.ext if (field.cub is not None) == (interp_order == 3) else None),
             _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[dtype], field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max,
             self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, float(timestep), int(SETTLS_order),
-            int(interp_order), int(bool(cyclic_xboundary)), int(t0), nsteps, self._ptr(x), self._ptr(y),
-            self._ptr(tx), self._ptr(ty)), self.lib)
+            int(interp_order), x_boundary_mode(cyclic_xboundary, noncyclic_clamp, int(row0) == 0 and ny == ny_global),
+            int(t0), nsteps, self._ptr(x), self._ptr(y), self._ptr(tx), self._ptr(ty)), self.lib)
         if halo:
             x, y = x_buf, y_buf
         return (x, y, tx, ty) if return_traj else (x, y)
@@ -331,13 +348,13 @@ class Engine:
     # ------------------------------------------------------------------ whole path
     def lcs(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
             cyclic_xboundary=True, t0=0, nsteps=None, gauss_sigma=None, fd_fp32_cast=True,
-            tensor_layout="reference", return_traj=False):
+            tensor_layout="reference", return_traj=False, noncyclic_clamp=None):
         """advect -> (smooth) -> sigma on one GPU.  Returns dict of device tensors."""
         dtype = field.dtype
         seed_lat = np.asarray(seed_lat, dtype=dtype)
         seed_lon = np.asarray(seed_lon, dtype=dtype)
         res = self.advect(field, seed_lat, seed_lon, timestep, SETTLS_order, interp_order, cyclic_xboundary, t0,
-                          nsteps, return_traj)
+                          nsteps, return_traj, noncyclic_clamp=noncyclic_clamp)
         x, y = res[0], res[1]
         xs, ys = x, y
         # scipy's gaussian_filter returns an unsmoothed copy for sigma = 0 (LCS/LCS.py:187-190): skip the filter
@@ -362,7 +379,7 @@ class Engine:
 # ---------------------------------------------------------------------------
 def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cyclic_xboundary=False,
              seed_lat=None, seed_lon=None, t0=0, nsteps=None, gauss_sigma=None, fd_fp32_cast=True,
-             tensor_layout="reference", return_traj=False, want_sigma=True, device=0):
+             tensor_layout="reference", return_traj=False, want_sigma=True, device=0, noncyclic_clamp=None):
     """numpy in, numpy out, via the one-call C entry point.  Returns a dict."""
     lib = _capi.load()
     dtype = common_dtype(u, v, lat_f, lon_f, seed_lat, seed_lon)
@@ -393,7 +410,8 @@ def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cycli
         gs = float(gauss_sigma) if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool) else 0.0
         _capi.check(lib.lc_lcs_host(
             ctx, p(u), p(v), _NP2LC[dtype], nt, ny_f, nx_f, p(lat_f), p(lon_f), p(seed_lat), ny, p(seed_lon), nx,
-            float(timestep), int(SETTLS_order), int(interp_order), int(bool(cyclic_xboundary)), int(t0), nsteps, gs,
+            float(timestep), int(SETTLS_order), int(interp_order), x_boundary_mode(cyclic_xboundary, noncyclic_clamp),
+            int(t0), nsteps, gs,
             int(bool(fd_fp32_cast)), _LAYOUTS[tensor_layout], p(out.get("sigma")), p(out["x_dep"]), p(out["y_dep"]),
             p(out.get("traj_x")), p(out.get("traj_y"))), lib)
     finally:

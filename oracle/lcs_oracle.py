@@ -124,7 +124,7 @@ def _clamp(positions_x, positions_y, x_min, x_max, y_min, y_max,
 def parcel_propagation(U, V, lat, lon, timestep=1, SETTLS_order=0,
                        interp_order=3, cyclic_xboundary=False,
                        return_traj=False, seed_lat=None, seed_lon=None,
-                       t0=0, nsteps=None, noncyclic_clamp="pointwise"):
+                       t0=0, nsteps=None, noncyclic_clamp="reference_outer"):
     """Euler + K accumulate-"SETTLS" sub-steps.  LCS/trajectory.py:41-142.
 
     ``U, V``: ``(nt, nlat, nlon)``.  Returns ``(x, y)`` of shape ``(ny, nx)``
@@ -343,14 +343,16 @@ def sigma_max_closed_form(def_tensor, tensor_layout="reference"):
 # --------------------------------------------------------------------------
 def lcs(U, V, lat, lon, timestep=1, SETTLS_order=0, interp_order=3,
         cyclic_xboundary=False, gauss_sigma=None, seed_lat=None, seed_lon=None,
-        t0=0, nsteps=None, tensor_layout="reference", fd_fp32_cast=True):
+        t0=0, nsteps=None, tensor_layout="reference", fd_fp32_cast=True,
+        noncyclic_clamp="reference_outer"):
     """advect -> flowmap_gradient -> sigma_max; returns (sigma, x_dep, y_dep)."""
     x_dep, y_dep = parcel_propagation(U, V, lat, lon, timestep=timestep,
                                       SETTLS_order=SETTLS_order,
                                       interp_order=interp_order,
                                       cyclic_xboundary=cyclic_xboundary,
                                       seed_lat=seed_lat, seed_lon=seed_lon,
-                                      t0=t0, nsteps=nsteps)                  # :129-134
+                                      t0=t0, nsteps=nsteps,
+                                      noncyclic_clamp=noncyclic_clamp)       # :129-134
     slat = lat if seed_lat is None else seed_lat
     slon = lon if seed_lon is None else seed_lon
     dt = flowmap_gradient(x_dep, y_dep, np.asarray(slat), np.asarray(slon),

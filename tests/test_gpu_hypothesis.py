@@ -77,21 +77,18 @@ def test_float32_kernels_agree_with_each_other_and_the_oracle(fny, fnx, nt, K, o
     slat, slon = flows.seed_grid(sny, snx, lat, lon)
     f = eng.prepare_field(u, v, lat, lon, order)
     out = {}
-    old = os.environ.get("LCS_LDS_TILES")
     try:
         for flag in ("0", "1"):
-            os.environ["LCS_LDS_TILES"] = flag
-            x, y = eng.advect(f, slat, slon, dt, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic)
+            eng.set_lds_tiles(int(flag))
+            x, y = eng.advect(f, slat, slon, dt, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic,
+                              noncyclic_clamp="pointwise")     # the fused kernels' own per-point clamp
             out[flag] = (x.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64))
     finally:
-        if old is None:
-            os.environ.pop("LCS_LDS_TILES", None)
-        else:
-            os.environ["LCS_LDS_TILES"] = old
+        eng.set_lds_tiles(-1)
     xo, yo = O.parcel_propagation(u.astype(np.float64), v.astype(np.float64), lat.astype(np.float64),
                                   lon.astype(np.float64), timestep=dt, SETTLS_order=K, interp_order=order,
                                   cyclic_xboundary=cyclic, seed_lat=slat.astype(np.float64),
-                                  seed_lon=slon.astype(np.float64))
+                                  seed_lon=slon.astype(np.float64), noncyclic_clamp="pointwise")
 
     def dist(a, b, periodic):
         d = np.abs(a - b)

@@ -99,12 +99,63 @@ def test_advect_f64_random_field(eng, O, order, K, dt):
 def test_advect_noncyclic_clamp(eng, O):
     u, v, lat, lon = _rand_field(11, nt=4, scale=60.0)
     f = eng.prepare_field(u, v, lat, lon, 1)
-    x, y = eng.advect(f, lat, lon, 7200.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=False)
+    x, y = eng.advect(f, lat, lon, 7200.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=False,
+                      noncyclic_clamp="pointwise")
     xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=7200.0, SETTLS_order=2, interp_order=1,
                                     cyclic_xboundary=False, noncyclic_clamp="pointwise")
     np.testing.assert_allclose(_np(x), xr_, rtol=0, atol=POS_ATOL64)
     np.testing.assert_allclose(_np(y), yr_, rtol=0, atol=POS_ATOL64)
     assert _np(x).min() >= lon.min() and _np(x).max() <= lon.max()
+
+
+@pytest.mark.parametrize("order", [1, 3])
+@pytest.mark.parametrize("K", [0, 2])
+def test_advect_noncyclic_reference_outer_clamp(eng, O, order, K):
+    """cyclic_xboundary=False as the reference computes it (Q9): `positions_x[np.where(x < x_min)] = x_min` on a
+    DataArray sets the whole cross product of offending rows x columns (LCS/trajectory.py:96-97, 122-123)."""
+    u, v, lat, lon = _rand_field(11 + K, nt=4, scale=60.0)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    kw = dict(timestep=7200.0, SETTLS_order=K, interp_order=order, cyclic_xboundary=False)
+    x, y, tx, ty = eng.advect(f, lat, lon, 7200.0, K, order, False, return_traj=True)   # default = reference_outer
+    assert eng.last_advect_kernel() == "outer_substep_kernel"
+    xr_, yr_ = O.parcel_propagation(u, v, lat, lon, noncyclic_clamp="reference_outer", return_traj=True, **kw)
+    xp_, _ = O.parcel_propagation(u, v, lat, lon, noncyclic_clamp="pointwise", **kw)
+    assert np.abs(xr_[-1] - xp_).max() > 1.0          # the two rules really differ on this input
+    np.testing.assert_allclose(_np(tx), xr_, rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(ty), yr_, rtol=0, atol=POS_ATOL64)
+    assert np.array_equal(_np(x), _np(tx)[-1]) and np.array_equal(_np(y), _np(ty)[-1])
+
+
+def test_advect_noncyclic_reference_outer_float32_and_fast_path(eng, O):
+    # float32: same band as the float32 oracle against float64
+    u, v, lat, lon = _rand_field(5, nt=4, scale=60.0, dtype=np.float32)
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    x, y = eng.advect(f, lat, lon, 7200.0, 2, 1, False)
+    kw = dict(timestep=7200.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=False, noncyclic_clamp="reference_outer")
+    x32, _ = O.parcel_propagation(u, v, lat, lon, **kw)
+    x64, _ = O.parcel_propagation(*(a.astype(np.float64) for a in (u, v, lat, lon)), **kw)
+    # a 1-ulp difference can move a parcel across the bound and switch a whole row x column cross product:
+    # compare where float32 oracle and float64 oracle agree on the clamp pattern
+    same = np.abs(x32 - x64) < 1e-2
+    eg = np.abs(_np(x).astype(np.float64) - x64)[same]
+    eo = np.abs(x32 - x64)[same]
+    print(f"outer clamp float32: gpu median {np.median(eg):.2e} p99 {np.percentile(eg, 99):.2e} max {eg.max():.2e}; "
+          f"oracle32 median {np.median(eo):.2e} p99 {np.percentile(eo, 99):.2e}")
+    assert same.mean() > 0.9 and (eg < 1e-2).mean() > 0.97      # the same rows x columns were clamped
+    assert np.median(eg) <= max(4 * np.median(eo), 1e-5) and np.percentile(eg, 90) < 1e-3
+    # purely meridional wind: no longitude changes, nothing leaves the box (any zonal wind pushes the last seed
+    # column out, whose index wraps to node 1 under Q2): the fused kernel's answer stands, no sub-step path
+    u2, v2 = np.zeros_like(u), v * np.float32(0.1)
+    f2 = eng.prepare_field(u2, v2, lat, lon, 1)
+    xa, ya = eng.advect(f2, lat, lon, 7200.0, 2, 1, False)
+    assert eng.last_advect_kernel() != "outer_substep_kernel"
+    xb, yb = eng.advect(f2, lat, lon, 7200.0, 2, 1, False, noncyclic_clamp="pointwise")
+    assert np.array_equal(_np(xa), _np(xb)) and np.array_equal(_np(ya), _np(yb))
+    # the rule couples every row: a row-sharded call cannot offer it and says so
+    with pytest.raises(ValueError, match="row-sharded"):
+        eng.advect(f2, lat[2:9], lon, 7200.0, 2, 1, False, row0=2, ny_global=lat.size, noncyclic_clamp="reference_outer")
+    xs, _ = eng.advect(f2, lat[2:9], lon, 7200.0, 2, 1, False, row0=2, ny_global=lat.size)   # default: per point
+    assert np.array_equal(_np(xs), _np(xb)[2:9])
 
 
 def test_kat_zero_wind_and_uniform_wind(eng):
@@ -415,10 +466,10 @@ def test_float_path_options_and_tiny_field(eng, O, order):
     u, v, lat, lon = _rand_field(92, nt=6, ny=40, nx=64, dtype=np.float32, scale=30.0)
     f = eng.prepare_field(u, v, lat, lon, order)
     x, y, tx, ty = eng.advect(f, lat, lon, -3600.0, SETTLS_order=2, interp_order=order, cyclic_xboundary=False,
-                              return_traj=True)
+                              return_traj=True, noncyclic_clamp="pointwise")   # the fused kernel's own clamp
     tx64, ty64 = O.parcel_propagation(u.astype(np.float64), v.astype(np.float64), lat.astype(np.float64),
                                       lon.astype(np.float64), timestep=-3600.0, SETTLS_order=2, interp_order=order,
-                                      cyclic_xboundary=False, return_traj=True)
+                                      cyclic_xboundary=False, return_traj=True, noncyclic_clamp="pointwise")
     ex, ey = np.abs(_np(tx) - tx64), np.abs(_np(ty) - ty64)
     # random (spatially uncorrelated) wind: neighbouring nodes differ by tens of m/s, so float32 position
     # rounding is amplified quickly; the bulk must still agree closely and nothing may run away

@@ -89,3 +89,48 @@ def test_native_rccl_communicator_single_rank():
     assert sharded.native_comm(eng, 0, 1) is not None
     eng.comm_destroy(eng._lc_comm)
     eng.close()
+
+
+def _native_worker(rank, world, port, q):
+    """One rank per GPU: lc_halo_exchange (RCCL send/recv inside one group call) on real neighbours."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # carries only the 128-byte RCCL id
+    try:
+        from lagrangiancoherence_amd import flows, sharded
+        from lagrangiancoherence_amd.engine import Engine
+        torch.cuda.set_device(rank)
+        eng = Engine(rank)
+        u, v, lat, lon = flows.era5_like(nt=7, ny=72, nx=144)
+        slat, slon = flows.seed_grid(203, 320, lat, lon)
+        f = eng.prepare_field(u, v, lat, lon, 1)
+        out = sharded.sharded_lcs(eng, f, slat, slon, -900.0, rank, world, SETTLS_order=4, interp_order=1, native_halo=True)
+        red = sharded.sharded_lcs(eng, f, slat, slon, -900.0, rank, world, SETTLS_order=4, interp_order=1, redundant_halo=True)
+        full = eng.lcs(f, slat, slon, -900.0, SETTLS_order=4, interp_order=1)
+        lo, hi = out["rows"]
+        ok = (torch.equal(out["sigma"], full["sigma"][lo:hi]) and torch.equal(red["sigma"], out["sigma"])
+              and bool(torch.isfinite(out["sigma"]).all()))
+        q.put((rank, "ok" if ok else f"mismatch rows {lo}:{hi}"))
+        eng.comm_destroy(eng._lc_comm)
+        eng.close()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="lc_halo_exchange's send/recv path needs two GPUs")
+def test_native_rccl_halo_exchange_two_gpus():
+    world = min(torch.cuda.device_count(), 4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
