@@ -129,6 +129,26 @@ int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype,
 int lc_field_extrapolate(lc_ctx *ctx, const void *packed_dev, int dtype,
                          int nt, int ny_f, int nx_f, void *ext_dev);
 
+/* ---- global pre-processing of LCS.__call__(isglobal=True) -----------------
+ * lc_regrid_common_grid replaces LCS/LCS.py:107-114: `u.interp(latitude=lats, longitude=lons, method='linear')`
+ * with the holes (targets outside the source range, NaN results) filled from `u.reindex(method='nearest')`.
+ * One fused kernel: latitude lerp, longitude lerp (scipy.interpolate.interp1d's operation order), nearest
+ * fill.  src [nt][ny_s][nx_s] in `dtype` on the device, coordinates ascending, as host doubles; out
+ * [nt][ny_d][nx_d] float64 on the device (xarray's interp result is float64).  The reference's target grid is
+ * lats = linspace(-89.75, 89.75, 360), lons = linspace(-180, 179.5, 721). */
+int lc_regrid_common_grid(lc_ctx *ctx, const void *src_dev, int dtype, int nt, int ny_s, int nx_s,
+                          const double *src_lat_host, const double *src_lon_host,
+                          const double *dst_lat_host, int ny_d, const double *dst_lon_host, int nx_d,
+                          double *out_dev);
+
+/* lc_spectral_truncate replaces LCS/LCS.py:115-118: windspharm `VectorWind(u, v).truncate(f, truncation=T)`
+ * = spherical-harmonic analysis on SPHEREPACK's equally spaced grid (theta_i = i pi / (nlat-1)), triangular
+ * truncation n <= T, synthesis.  f, out: [nbatch][nlat][nlon] in `dtype`, latitude ASCENDING; computed in
+ * float64.  Operators are built on the host once per (nlat, nlon, T) and cached on the context.  T <= 31.
+ * Restates the published algorithm (Swarztrauber 1979); not pinned against pyspharm. */
+int lc_spectral_truncate(lc_ctx *ctx, const void *f_dev, int dtype, int nbatch, int nlat, int nlon,
+                         int truncation, void *out_dev);
+
 /* ---- K1: parcel advection ------------------------------------------------
  * Replaces trajectory.parcel_propagation (LCS/trajectory.py:8-144) together
  * with every tools.xr_map_coordinates call it makes (LCS/tools.py:11-41):
@@ -270,6 +290,22 @@ int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, int dtype,
                 int t0, int nsteps, double gauss_sigma /* <=0: none */,
                 int fd_fp32_cast, int tensor_layout,
                 void *sigma_out, void *x_out, void *y_out, void *traj_x, void *traj_y);
+
+/* ---- the reference's default global call form in one call, torch-free -------
+ * LCS(...)(ds, isglobal=True) (LCS/LCS.py:105-157, examples/ideal_vortex.py:280-287) on host arrays:
+ * [interp_to_common_grid: lc_regrid_common_grid of u and v onto lc_common_grid's grid, float64]
+ * -> [truncation >= 0: lc_spectral_truncate at that wavenumber; the latitudes must pass windspharm's
+ * equally-spaced-global inspection] -> lc_field_pack -> lc_advect (cyclic, seeds = grid nodes, all nt-1 steps)
+ * -> [gauss_sigma > 0: lc_gaussian_filter] -> lc_sigma.
+ * Outputs [ny_o * nx_o] on the host, any may be NULL: ny_o x nx_o = 360 x 721 and float64 when
+ * interp_to_common_grid, else ny_f x nx_f in `dtype`.  Synchronous. */
+int lc_common_grid(int *ny_out, int *nx_out, double *lats_out /* NULL or [360] */, double *lons_out /* NULL or [721] */);
+int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v_host, int dtype,
+                       int nt, int ny_f, int nx_f, const double *lat_f_host, const double *lon_f_host,
+                       int interp_to_common_grid, int truncation /* < 0: none */,
+                       double timestep, int settls_order, int interp_order,
+                       double gauss_sigma /* <= 0: none */, int fd_fp32_cast, int tensor_layout,
+                       void *sigma_out, void *x_out, void *y_out);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,8 @@ PROTOTYPES = {
     "lc_packed_elems": (_sz, [_i, _i, _i]),
     "lc_field_pack": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lc_field_extrapolate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "lc_regrid_common_grid": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "lc_spectral_truncate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lc_advect": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i,
                        _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lc_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -48,6 +50,8 @@ PROTOTYPES = {
     "lc_comm_create": (_i, [_vp, _i, _i, _vp, _sz, C.POINTER(_vp)]),
     "lc_comm_destroy": (_i, [_vp]),
     "lc_halo_exchange": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "lc_common_grid": (_i, [C.POINTER(_i), C.POINTER(_i), _vp, _vp]),
+    "lc_lcs_global_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _d, _i, _i, _d, _i, _i, _vp, _vp, _vp]),
     "lc_lcs_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i,
                          _d, _i, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _vp]),
 }

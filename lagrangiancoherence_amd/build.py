@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblcs_hip.so")
-SOURCES = ["api.hip", "pack.hip", "advect.hip", "sigma.hip", "ridges.hip", "halo.hip"]
+SOURCES = ["api.hip", "pack.hip", "advect.hip", "sigma.hip", "ridges.hip", "halo.hip", "preprocess.hip"]
 ARCH = "gfx950"
 
 

@@ -43,6 +43,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->lds_tiles = 1;
     if (const char *ev = getenv("LCS_LDS_TILES")) c->lds_tiles = ev[0] == '0' ? 0 : 1;  // read once, here
     c->last_advect_kernel = "";
+    c->trunc = nullptr;
     *out = c;
     return LC_OK;
 }
@@ -60,6 +61,7 @@ extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
     if (!ctx) return LC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    lc_trunc_cache_free(ctx->trunc);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return LC_OK;
@@ -360,4 +362,141 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     }
     LC_HIP_CHECK(hipStreamSynchronize(st));
     return LC_OK;  // DevBuf destructors free after the sync
+}
+
+// ---------------------------------------------------------------------------
+// One-call host entry point for the reference's DEFAULT global call form,
+// LCS(...)(ds, isglobal=True) (LCS/LCS.py:105-157; examples/ideal_vortex.py:280-287):
+// regrid to the common 0.5 degree grid -> T-truncation -> advect (cyclic) -> sigma.
+// ---------------------------------------------------------------------------
+extern "C" int lc_common_grid(int *ny_out, int *nx_out, double *lats_out, double *lons_out) {
+    // LCS.py:107-108: np.linspace(-89.75, 89.75, 360), np.linspace(-180, 179.5, 721)  (numpy's formula: start + i*step)
+    const int ny = 360, nx = 721;
+    if (ny_out) *ny_out = ny;
+    if (nx_out) *nx_out = nx;
+    if (lats_out) {
+        const double step = (89.75 - -89.75) / (ny - 1);
+        for (int i = 0; i < ny; ++i) lats_out[i] = -89.75 + i * step;
+        lats_out[ny - 1] = 89.75;
+    }
+    if (lons_out) {
+        const double step = (179.5 - -180.0) / (nx - 1);
+        for (int i = 0; i < nx; ++i) lons_out[i] = -180.0 + i * step;
+        lons_out[nx - 1] = 179.5;
+    }
+    return LC_OK;
+}
+
+extern "C" int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v_host, int dtype, int nt, int ny_f, int nx_f,
+                                  const double *lat_f_host, const double *lon_f_host, int interp_to_common_grid,
+                                  int truncation, double timestep, int settls_order, int interp_order,
+                                  double gauss_sigma, int fd_fp32_cast, int tensor_layout, void *sigma_out, void *x_out,
+                                  void *y_out) {
+    LC_REQUIRE(ctx, "lc_lcs_global_host: null context");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_lcs_global_host: bad dtype %d", dtype);
+    LC_REQUIRE(u_host && v_host && lat_f_host && lon_f_host, "lc_lcs_global_host: null input pointer");
+    LC_REQUIRE(nt >= 2 && ny_f >= 4 && nx_f >= 4, "lc_lcs_global_host: bad sizes");
+    LC_REQUIRE(settls_order >= 0, "lc_lcs_global_host: SETTLS_order must be >= 0");
+    if (interp_order != 1 && interp_order != 3) {
+        lc_set_error("lc_lcs_global_host: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
+        return LC_EUNSUPPORTED;
+    }
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t es_in = dtype == LC_F32 ? 4 : 8;
+    const size_t nin = (size_t)nt * ny_f * nx_f;
+    // grid and dtype the wind ends up on: regridding gives float64 (xarray's interp result)
+    int ny = ny_f, nx = nx_f, wdtype = dtype;
+    std::vector<double> lat(lat_f_host, lat_f_host + ny_f), lon(lon_f_host, lon_f_host + nx_f);
+    if (interp_to_common_grid) {
+        lc_common_grid(&ny, &nx, nullptr, nullptr);
+        lat.resize(ny);
+        lon.resize(nx);
+        lc_common_grid(nullptr, nullptr, lat.data(), lon.data());
+        wdtype = LC_F64;
+    }
+    if (truncation >= 0) {
+        // windspharm's grid inspection (equally spaced, global): LCS.py:116 via VectorWind
+        const double d0 = lat[1] - lat[0];
+        const double first = ny % 2 ? -90.0 : -90.0 + 90.0 / ny;
+        for (int i = 0; i < ny; ++i) {
+            const double want = ny % 2 ? -90.0 + 180.0 * i / (ny - 1) : first + (180.0 - 180.0 / ny) * i / (ny - 1);
+            if ((i && std::fabs((lat[i] - lat[i - 1]) - d0) > 5e-4) || std::fabs(lat[i] - want) > 5e-4) {
+                lc_set_error("lc_lcs_global_host: truncation needs equally spaced global latitudes (row %d is %g, expected %g)",
+                             i, lat[i], want);
+                return LC_EINVAL;
+            }
+        }
+    }
+    const size_t es = wdtype == LC_F32 ? 4 : 8;
+    const size_t nw = (size_t)nt * ny * nx, sbytes = (size_t)ny * nx * es;
+    DevBuf uin, vin, ur, vr, ut, vt, lin, cub, ext, slat, slon, x, y, sig, gx, gy, gtmp;
+    LC_TRY(uin.alloc(nin * es_in));
+    LC_TRY(vin.alloc(nin * es_in));
+    LC_HIP_CHECK(hipMemcpyAsync(uin.p, u_host, nin * es_in, hipMemcpyHostToDevice, st));
+    LC_HIP_CHECK(hipMemcpyAsync(vin.p, v_host, nin * es_in, hipMemcpyHostToDevice, st));
+    void *uw = uin.p, *vw = vin.p;
+    if (interp_to_common_grid) {
+        LC_TRY(ur.alloc(nw * 8));
+        LC_TRY(vr.alloc(nw * 8));
+        LC_TRY(lc_regrid_common_grid(ctx, uin.p, dtype, nt, ny_f, nx_f, lat_f_host, lon_f_host, lat.data(), ny, lon.data(), nx,
+                                     (double *)ur.p));
+        LC_TRY(lc_regrid_common_grid(ctx, vin.p, dtype, nt, ny_f, nx_f, lat_f_host, lon_f_host, lat.data(), ny, lon.data(), nx,
+                                     (double *)vr.p));
+        uw = ur.p;
+        vw = vr.p;
+    }
+    if (truncation >= 0) {
+        LC_TRY(ut.alloc(nw * es));
+        LC_TRY(vt.alloc(nw * es));
+        LC_TRY(lc_spectral_truncate(ctx, uw, wdtype, nt, ny, nx, truncation, ut.p));
+        LC_TRY(lc_spectral_truncate(ctx, vw, wdtype, nt, ny, nx, truncation, vt.p));
+        uw = ut.p;
+        vw = vt.p;
+    }
+    // seeds = the (new) grid nodes, in the wind's dtype (trajectory.py:68-70)
+    std::vector<char> hl(ny * es), ho(nx * es);
+    for (int i = 0; i < ny; ++i)
+        if (wdtype == LC_F32) ((float *)hl.data())[i] = (float)lat[i]; else ((double *)hl.data())[i] = lat[i];
+    for (int i = 0; i < nx; ++i)
+        if (wdtype == LC_F32) ((float *)ho.data())[i] = (float)lon[i]; else ((double *)ho.data())[i] = lon[i];
+    LC_TRY(slat.alloc(ny * es));
+    LC_TRY(slon.alloc(nx * es));
+    LC_HIP_CHECK(hipMemcpyAsync(slat.p, hl.data(), ny * es, hipMemcpyHostToDevice, st));
+    LC_HIP_CHECK(hipMemcpyAsync(slon.p, ho.data(), nx * es, hipMemcpyHostToDevice, st));
+    LC_HIP_CHECK(hipStreamSynchronize(st));  // hl / ho are pageable locals
+    const size_t pbytes = lc_packed_elems(nt, ny, nx) * es;
+    LC_TRY(lin.alloc(pbytes));
+    if (interp_order == 3) LC_TRY(cub.alloc(pbytes));
+    if (wdtype == LC_F32 && settls_order > 0) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny, nx) * es));
+    LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
+    if (interp_order == 3) LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, 3, cub.p, ext.p));
+    LC_TRY(x.alloc(sbytes));
+    LC_TRY(y.alloc(sbytes));
+    const double lat_min = wdtype == LC_F32 ? (double)(float)lat[0] : lat[0], lat_max = wdtype == LC_F32 ? (double)(float)lat[ny - 1] : lat[ny - 1];
+    const double lon_min = wdtype == LC_F32 ? (double)(float)lon[0] : lon[0], lon_max = wdtype == LC_F32 ? (double)(float)lon[nx - 1] : lon[nx - 1];
+    LC_TRY(lc_advect(ctx, lin.p, cub.p, ext.p, wdtype, nt, ny, nx, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p, nx, 0,
+                     ny, timestep, settls_order, interp_order, LC_X_CYCLIC /* LCS.py:119 */, 0, nt - 1, x.p, y.p, nullptr, nullptr));
+    if (sigma_out) {
+        LC_REQUIRE(ny >= 5 && nx >= 5, "lc_lcs_global_host: sigma needs at least a 5x5 grid");
+        LC_TRY(sig.alloc(sbytes));
+        const void *xs = x.p, *ys = y.p;
+        if (gauss_sigma > 1e-15) {
+            LC_TRY(gx.alloc(sbytes));
+            LC_TRY(gy.alloc(sbytes));
+            LC_TRY(gtmp.alloc(sbytes));
+            LC_TRY(lc_gaussian_filter(ctx, x.p, wdtype, ny, nx, gauss_sigma, gtmp.p, gx.p));
+            LC_TRY(lc_gaussian_filter(ctx, y.p, wdtype, ny, nx, gauss_sigma, gtmp.p, gy.p));
+            xs = gx.p;
+            ys = gy.p;
+        }
+        const double dlat = wdtype == LC_F32 ? (double)((float)lat[1] - (float)lat[0]) : lat[1] - lat[0];
+        const double dlon = wdtype == LC_F32 ? (double)((float)lon[1] - (float)lon[0]) : lon[1] - lon[0];
+        LC_TRY(lc_sigma(ctx, xs, ys, wdtype, 0, ny, nx, ny, slat.p, dlat, dlon, fd_fp32_cast, tensor_layout, 0, ny, sig.p));
+        LC_HIP_CHECK(hipMemcpyAsync(sigma_out, sig.p, sbytes, hipMemcpyDeviceToHost, st));
+    }
+    if (x_out) LC_HIP_CHECK(hipMemcpyAsync(x_out, x.p, sbytes, hipMemcpyDeviceToHost, st));
+    if (y_out) LC_HIP_CHECK(hipMemcpyAsync(y_out, y.p, sbytes, hipMemcpyDeviceToHost, st));
+    LC_HIP_CHECK(hipStreamSynchronize(st));
+    return LC_OK;
 }

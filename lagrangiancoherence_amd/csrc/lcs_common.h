@@ -7,12 +7,16 @@
 
 #include "../../include/lcs_hip.h"
 
+struct lc_trunc_cache;                       // preprocess.hip: spectral-truncation operators of the last (nlat, nlon, T)
+void lc_trunc_cache_free(lc_trunc_cache *c);
+
 struct lc_ctx {
     int device;
     hipStream_t own_stream;
     hipStream_t stream;  // the one work is enqueued on (own or borrowed)
     int lds_tiles;       // lc_advect float32 kernel choice: 1 LDS tiles, 0 direct gathers (LCS_LDS_TILES at creation)
     const char *last_advect_kernel;
+    lc_trunc_cache *trunc;
 };
 
 void lc_set_error(const char *fmt, ...);

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _capi
 
-__all__ = ["Engine", "PackedField", "lcs_host", "common_dtype", "x_boundary_mode"]
+__all__ = ["Engine", "PackedField", "lcs_host", "lcs_global_host", "common_dtype", "x_boundary_mode"]
 
 _NP2LC = {np.dtype(np.float32): _capi.LC_F32, np.dtype(np.float64): _capi.LC_F64}
 _LAYOUTS = {"reference": _capi.LC_LAYOUT_REFERENCE, "physical": _capi.LC_LAYOUT_PHYSICAL}
@@ -170,6 +170,37 @@ class Engine:
         lo = lon_f.astype(dtype)
         return PackedField(lin, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
                            wind_f32)
+
+    # ------------------------------------------------------------------ global pre-processing (LCS.py:105-118)
+    def regrid(self, u, lat, lon, lats, lons):
+        """``u.interp(linear)`` onto (lats, lons) with nearest fill outside the source range (LCS/LCS.py:107-114).
+        u: (nt, nlat, nlon) array or device tensor.  Returns a float64 device tensor (nt, len(lats), len(lons))."""
+        dtype = common_dtype(u)
+        ud = self.to_device(u, dtype)
+        nt, ny_s, nx_s = (int(s) for s in ud.shape)
+        c = [np.ascontiguousarray(a, dtype=np.float64) for a in (lat, lon, lats, lons)]
+        if c[0].size != ny_s or c[1].size != nx_s:
+            raise ValueError("coordinate lengths do not match the field")
+        out = self._empty((nt, c[2].size, c[3].size), np.float64)
+        self._use_current_stream()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _capi.check(self.lib.lc_regrid_common_grid(self.ctx, self._ptr(ud), _NP2LC[dtype], nt, ny_s, nx_s, p(c[0]), p(c[1]),
+                                                   p(c[2]), int(c[2].size), p(c[3]), int(c[3].size), self._ptr(out)), self.lib)
+        return out
+
+    def spectral_truncate(self, f, T=20):
+        """Triangular truncation at total wavenumber T of fields (..., nlat, nlon), latitude ascending, on
+        SPHEREPACK's equally spaced grid (LCS/LCS.py:115-118).  Same shape and dtype back (device tensor)."""
+        dtype = common_dtype(f)
+        fd = self.to_device(f, dtype)
+        shape = tuple(int(s) for s in fd.shape)
+        nlat, nlon = shape[-2], shape[-1]
+        nb = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+        out = self._empty(shape, dtype)
+        self._use_current_stream()
+        _capi.check(self.lib.lc_spectral_truncate(self.ctx, self._ptr(fd), _NP2LC[dtype], nb, nlat, nlon, int(T),
+                                                  self._ptr(out)), self.lib)
+        return out
 
     # ------------------------------------------------------------------ K1
     def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
@@ -416,4 +447,42 @@ def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cycli
             p(out.get("traj_x")), p(out.get("traj_y"))), lib)
     finally:
         lib.lc_ctx_destroy(ctx)
+    return out
+
+
+def lcs_global_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, interp_to_common_grid=True,
+                    truncation=20, gauss_sigma=None, fd_fp32_cast=True, tensor_layout="reference", device=0):
+    """The reference's default global call form ``LCS(...)(ds, isglobal=True)`` (LCS/LCS.py:105-157) on numpy
+    arrays, torch-free, through ``lc_lcs_global_host``: regrid to the common 0.5 degree grid, T-truncation,
+    cyclic advection from the grid nodes, sigma.  Returns a dict with ``sigma, x_dep, y_dep, latitude, longitude``."""
+    lib = _capi.load()
+    dtype = common_dtype(u, v)
+    u = np.ascontiguousarray(u, dtype=dtype)
+    v = np.ascontiguousarray(v, dtype=dtype)
+    if u.shape != v.shape or u.ndim != 3:
+        raise ValueError("u and v must both be (time, latitude, longitude)")
+    lat_f = np.ascontiguousarray(lat_f, dtype=np.float64)
+    lon_f = np.ascontiguousarray(lon_f, dtype=np.float64)
+    nt, ny_f, nx_f = u.shape
+    if interp_to_common_grid:
+        ny, nx = C.c_int(), C.c_int()
+        lib.lc_common_grid(C.byref(ny), C.byref(nx), None, None)
+        lat, lon = np.empty(ny.value), np.empty(nx.value)
+        lib.lc_common_grid(None, None, lat.ctypes.data_as(C.c_void_p), lon.ctypes.data_as(C.c_void_p))
+        odt = np.dtype(np.float64)
+    else:
+        lat, lon, odt = lat_f, lon_f, dtype
+    out = {k: np.empty((lat.size, lon.size), odt) for k in ("sigma", "x_dep", "y_dep")}
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    gs = float(gauss_sigma) if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool) else 0.0
+    ctx = C.c_void_p()
+    _capi.check(lib.lc_ctx_create(int(device), C.byref(ctx)), lib)
+    try:
+        _capi.check(lib.lc_lcs_global_host(
+            ctx, p(u), p(v), _NP2LC[dtype], nt, ny_f, nx_f, p(lat_f), p(lon_f), int(bool(interp_to_common_grid)),
+            -1 if truncation is None else int(truncation), float(timestep), int(SETTLS_order), int(interp_order), gs,
+            int(bool(fd_fp32_cast)), _LAYOUTS[tensor_layout], p(out["sigma"]), p(out["x_dep"]), p(out["y_dep"])), lib)
+    finally:
+        lib.lc_ctx_destroy(ctx)
+    out["latitude"], out["longitude"] = lat, lon
     return out

@@ -84,3 +84,14 @@ def test_local_rccl_declarations_match_the_installed_header():
 def test_context_options_reject_bad_arguments(lib):
     assert lib.lc_ctx_set_lds_tiles(None, 1) == _capi.LC_EINVAL
     assert lib.lc_ctx_last_advect_kernel(None) == b""
+
+
+def test_common_grid_is_numpy_linspace(lib):
+    """LCS/LCS.py:107-108: lats = np.linspace(-89.75, 89.75, 360), lons = np.linspace(-180, 179.5, 721), bit for bit."""
+    import ctypes as C
+    import numpy as np
+    ny, nx = C.c_int(), C.c_int()
+    assert lib.lc_common_grid(C.byref(ny), C.byref(nx), None, None) == 0 and (ny.value, nx.value) == (360, 721)
+    lat, lon = np.empty(360), np.empty(721)
+    lib.lc_common_grid(None, None, lat.ctypes.data_as(C.c_void_p), lon.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(lat, np.linspace(-89.75, 89.75, 180 * 2)) and np.array_equal(lon, np.linspace(-180, 179.5, 360 * 2 + 1))

@@ -1,26 +1,11 @@
-"""Global pre-processing (LCS.py:105-118): the oracle's known answers, and the product's
-torch implementation (device-agnostic tensor ops + rocBLAS GEMMs on the GPU; plain CPU tensors here)
-against the oracle."""
+"""Global pre-processing (LCS.py:105-118), CPU side: the oracle's known answers and the
+host logic of the product (windspharm's grid inspection).  The product's kernels (lc_regrid_common_grid,
+lc_spectral_truncate) are compared with this oracle on the GPU in tests/test_preprocess_gpu.py."""
 import numpy as np
 import pytest
-import torch
 
 from lagrangiancoherence_amd import preprocess as PP
 from oracle import preprocess_oracle as PO
-
-
-class CpuTensorHost:
-    """What preprocess.py needs from an Engine, on CPU tensors (no kernels of ours are involved)."""
-    torch = torch
-    device = torch.device("cpu")
-
-    def to_device(self, a, dtype):
-        if isinstance(a, torch.Tensor):
-            return a.to(getattr(torch, np.dtype(dtype).name))
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
-
-
-HOST = CpuTensorHost()
 
 
 # ------------------------------------------------------------------ regrid
@@ -53,23 +38,6 @@ def test_regrid_oracle_known_answers():
     assert np.array_equal(o2[:, 0], o2[:, 5]) and not np.isnan(o2).any()
 
 
-def test_regrid_product_matches_oracle():
-    for kw in ({}, dict(lat0=-80.0, lat1=80.0), dict(ny=19, nx=40)):
-        u, lat, lon = _field(**kw)
-        ref, lats, lons = PO.regrid_common_grid(u, lat, lon)
-        got, glats, glons = PP.regrid_common_grid(HOST, u, lat, lon)
-        assert np.array_equal(glats, lats) and np.array_equal(glons, lons)
-        np.testing.assert_allclose(got.numpy(), ref, rtol=0, atol=1e-14)
-    # float32 input comes back float64, as xarray's interp does
-    got, _, _ = PP.regrid_common_grid(HOST, u.astype(np.float32), lat, lon)
-    assert got.dtype == torch.float64
-
-
-def test_nearest_tie_goes_to_the_larger_index_like_pandas():
-    lo, t, dx, inside, near = PP._axis_plan(np.array([0.0, 1.0, 2.0]), np.array([0.5, 1.5, -1.0, 3.0, 0.49, 0.51]))
-    assert list(near) == [1, 2, 0, 2, 0, 1] and list(inside) == [True, True, False, False, True, True]
-
-
 # ------------------------------------------------------------------ spectral truncation
 def _harmonic(m, n, nlat, nlon, phase=0.3):
     theta = np.arange(nlat) * np.pi / (nlat - 1)
@@ -78,11 +46,9 @@ def _harmonic(m, n, nlat, nlon, phase=0.3):
     return (P[:, None] * np.cos(m * lam + phase)[None, :])[::-1]       # ascending latitude
 
 
-@pytest.mark.parametrize("impl", ["oracle", "product"])
-def test_truncation_is_the_exact_projector_on_band_limited_fields(impl):
+def test_truncation_is_the_exact_projector_on_band_limited_fields():
     nlat, nlon, T = 60, 121, 8
-    trunc = (lambda f: PO.spectral_truncate(f, T)) if impl == "oracle" else \
-        (lambda f: PP.spectral_truncate(HOST, f, T).numpy())
+    trunc = lambda f: PO.spectral_truncate(f, T)
     for m, n in [(0, 0), (0, 5), (1, 1), (1, 8), (2, 8), (8, 8), (3, 7)]:
         f = _harmonic(m, n, nlat, nlon)
         np.testing.assert_allclose(trunc(f), f, atol=2e-12)            # degree <= T: unchanged
@@ -96,17 +62,6 @@ def test_truncation_is_the_exact_projector_on_band_limited_fields(impl):
     assert np.abs(once).max() < np.abs(g).max()
 
 
-def test_truncation_product_matches_oracle_on_the_reference_grid():
-    rng = np.random.default_rng(2)
-    f = rng.standard_normal((2, 360, 721))
-    ref = PO.spectral_truncate(f, 20)
-    got = PP.spectral_truncate(HOST, f, 20)
-    np.testing.assert_allclose(got.numpy(), ref, rtol=0, atol=5e-13)
-    got32 = PP.spectral_truncate(HOST, f.astype(np.float32), 20)
-    assert got32.dtype == torch.float32
-    np.testing.assert_allclose(got32.numpy(), ref, atol=5e-6)
-
-
 def test_grid_inspection_like_windspharm():
     PP.check_regular_global_lat(PP.COMMON_LATS)                        # 360 rows at +-(90 - 0.25): accepted
     PP.check_regular_global_lat(np.linspace(-90, 90, 181))             # odd count: poles + equator
@@ -115,4 +70,4 @@ def test_grid_inspection_like_windspharm():
     with pytest.raises(ValueError, match="equally-spaced"):
         PP.check_regular_global_lat(np.array([-60.0, -10.0, 0.0, 70.0]))
     with pytest.raises(ValueError, match="too high"):
-        PP.spectral_truncate(HOST, np.zeros((10, 30)), 20)
+        PP.spectral_truncate(None, np.zeros((10, 30)), 20)             # refused before any engine call
