@@ -50,7 +50,7 @@ enum lc_dtype {
 enum lc_status {
     LC_OK = 0,
     LC_EINVAL = -1,       /* bad argument (null pointer, bad size, bad enum) */
-    LC_EUNSUPPORTED = -2, /* e.g. interp_order not in {1,3}                  */
+    LC_EUNSUPPORTED = -2, /* e.g. interp_order outside 1..5                  */
     LC_EHIP = -3,         /* a HIP runtime call failed                       */
     LC_ENOMEM = -4,
     LC_ERCCL = -5         /* RCCL missing or an RCCL call failed             */
@@ -110,9 +110,10 @@ int lc_memcpy_d2h(lc_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes
  * Builds the gather-ready image of a wind time series: per time level a
  * (ny_f+3) x (nx_f+3) array of interleaved (u,v) nodes -- 1 mirrored node in
  * front and 2 behind on each axis, so the 2x2 / 4x4 tap windows never need
- * index logic.  order 1: raw values.  order 3: cubic B-spline coefficients
- * (mirror-boundary prefilter, gain 6 per axis, exact-sum initialisation ==
- * scipy.ndimage.spline_filter(mode='mirror')).
+ * index logic.  order 1: raw values.  orders 2..5: B-spline coefficients of that order
+ * (mirror-boundary prefilter with scipy's pole lists, exact-sum initialisation ==
+ * scipy.ndimage.spline_filter(order, mode='mirror'); orders 4, 5 agree with scipy to 1e-12: the pole
+ * constants differ in the last bit).
  *
  * lc_packed_elems() = number of dtype elements the image needs.            */
 size_t lc_packed_elems(int nt, int ny_f, int nx_f);
@@ -157,7 +158,10 @@ int lc_spectral_truncate(lc_ctx *ctx, const void *f_dev, int dtype, int nbatch, 
  *
  *   packed_lin   image from lc_field_pack(order=1)   (always required: the
  *                first/last interp_order seed rows use order 1 + 'constant')
- *   packed_cub   image from lc_field_pack(order=3), or NULL when interp_order==1
+ *   packed_cub   image from lc_field_pack(order=interp_order), or NULL when interp_order==1.  interp_order may be
+ *                any of scipy's spline orders 1..5 (LCS/trajectory.py:16, LCS/tools.py:26-30 hand it to
+ *                map_coordinates); 1 and 3 have the fused / LDS-tile kernels, 2, 4 and 5 a generic direct one
+ *                (no packed_ext).  0 fails in the reference itself (empty interior slice).
  *   packed_ext   image from lc_field_extrapolate, or NULL.  NULL = two samples per
  *                SETTLS iteration in the reference's operation order (the float64
  *                default, results identical to numpy/scipy's); non-NULL = one sample

@@ -107,8 +107,9 @@ __device__ __forceinline__ T pymod180(T x) {
 // pays its loads and its tap sum (fetch).  The arithmetic is exactly what scipy does per call.
 template <typename T>
 struct Tap {
-    unsigned off;     // element offset of the window origin inside one time level
-    T wy[4], wx[4];   // scipy's per-axis weights (order 1 uses [0], [1])
+    unsigned off;     // element offset of the window origin inside one time level (orders 1, 3)
+    int sy, sx;       // first tap's node index, before mirroring (orders 2, 4, 5)
+    T wy[6], wx[6];   // scipy's per-axis weights (order+1 of them)
     T ty, tx;         // fractional parts (float order-1 lerp form)
     bool zero;        // 'constant' mode, coordinate outside [0, n-1]: the sample is exactly 0
 };
@@ -122,6 +123,72 @@ __device__ __forceinline__ void cubic_weights(T t, T w[4]) {
     w[2] = (z * z * (z - T(2)) * T(3) + T(4)) / T(6);
     w[0] = z * z * z / T(6);
     w[3] = T(1) - w[0] - w[1] - w[2];
+}
+
+
+// ---- orders 2, 4, 5 (LCS/trajectory.py:16 and LCS/tools.py:26-30 pass any order to scipy) -----------------
+// Generic form, direct kernels only: centred B-spline weights from the closed form
+//   beta_n(t) = 1/n! sum_k (-1)^k C(n+1, k) (t + (n+1)/2 - k)_+^n,
+// first tap floor(c) - n/2 (odd n) or floor(c + 1/2) - n/2 (even n) as in scipy's map_coordinates, every tap
+// index mirrored into [0, n-1] (the pads of the image are not relied on), sums in double whatever T is (scipy
+// evaluates in double and rounds to the field's dtype).  Agreement with scipy: 1e-14 (order 2), 1e-12 (orders
+// 4, 5: the prefilter's pole constants differ from scipy's in the last bit and the gain amplifies it).
+__device__ __forceinline__ int mirror_node(int i, int n) {
+    const int s2 = 2 * n - 2;
+    i = i < 0 ? -i : i;
+    i %= s2;
+    return i > n - 1 ? s2 - i : i;
+}
+
+template <int N>
+__device__ __forceinline__ double bspline_centred(double t) {
+    constexpr double half = 0.5 * (N + 1);
+    constexpr int binom[6][7] = {{1, 1}, {1, 2, 1}, {1, 3, 3, 1}, {1, 4, 6, 4, 1}, {1, 5, 10, 10, 5, 1}, {1, 6, 15, 20, 15, 6, 1}};
+    constexpr double fact[6] = {1, 1, 2, 6, 24, 120};
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k <= N + 1; ++k) {
+        const double a = t + half - k;
+        if (a > 0.0) {
+            double p = a;
+#pragma unroll
+            for (int q = 1; q < N; ++q) p *= a;
+            s += ((k & 1) ? -1.0 : 1.0) * binom[N][k] * p;
+        }
+    }
+    return s / fact[N];
+}
+
+template <typename T, int ORDER>
+__device__ __forceinline__ void locate_general(Tap<T> &t, T cy, T cx) {
+    const double y = (double)cy, x = (double)cx;
+    t.sy = (ORDER & 1) ? (int)floor(y) - ORDER / 2 : (int)floor(y + 0.5) - ORDER / 2;
+    t.sx = (ORDER & 1) ? (int)floor(x) - ORDER / 2 : (int)floor(x + 0.5) - ORDER / 2;
+#pragma unroll
+    for (int k = 0; k <= ORDER; ++k) {
+        t.wy[k] = (T)bspline_centred<ORDER>(y - (double)(t.sy + k));
+        t.wx[k] = (T)bspline_centred<ORDER>(x - (double)(t.sx + k));
+    }
+}
+
+template <typename T, int ORDER>
+__device__ __forceinline__ Pair<T> fetch_general(const T *__restrict__ lvl, const AdvectArgs<T> &A, const Tap<T> &t) {
+#pragma clang fp contract(off)
+    double su = 0.0, sv = 0.0;
+#pragma unroll
+    for (int a = 0; a <= ORDER; ++a) {
+        const T *row = lvl + ((size_t)(mirror_node(t.sy + a, A.ny_f) + LC_PAD_LO) * A.pitch + LC_PAD_LO) * 2;
+#pragma unroll
+        for (int b = 0; b <= ORDER; ++b) {
+            const T *p = row + (size_t)mirror_node(t.sx + b, A.nx_f) * 2;
+            su += ((double)p[0] * (double)t.wy[a]) * (double)t.wx[b];
+            sv += ((double)p[1] * (double)t.wy[a]) * (double)t.wx[b];
+        }
+    }
+    Pair<T> r;
+    r.u = (T)su;
+    r.v = (T)sv;
+    return r;
 }
 
 template <typename T, int ORDER, bool WRAP>
@@ -144,6 +211,13 @@ __device__ __forceinline__ Tap<T> locate(const AdvectArgs<T> &A, T x, T y) {
         cx = wrap_coord<T>(cx, T(A.nx_f - 1));
     } else if (cy < T(0) || cy > T(A.ny_f - 1) || cx < T(0) || cx > T(A.nx_f - 1)) {
         t.zero = true;  // 'constant': exactly cval=0 outside [0, n-1] (no interpolation towards cval)
+    }
+    if (ORDER != 1 && ORDER != 3) {
+        t.ty = t.tx = T(0);
+        t.off = 0;
+        if (!(cy >= T(0) && cy <= T(A.ny_f - 1) && cx >= T(0) && cx <= T(A.nx_f - 1))) cy = cx = T(0);  // NaN / inf: memory safety
+        locate_general<T, ORDER>(t, cy, cx);
+        return t;
     }
     const T fy = floor(cy), fx = floor(cx);
     const int y0 = clampi((int)fy, 0, A.ny_f - 1);  // clamp: memory safety for NaN/inf/rounding
@@ -173,6 +247,7 @@ __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const Advect
         r.v = T(0);
         return r;
     }
+    if (ORDER != 1 && ORDER != 3) return fetch_general<T, ORDER>(lvl, A, t);
     const T *p = lvl + t.off;
     if (ORDER == 3) {
         T su = T(0), sv = T(0);
@@ -437,6 +512,8 @@ __device__ __forceinline__ void clamp_position_f(const AdvectArgs<float> &A, flo
 template <int ORDER>
 __device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
 #pragma clang fp contract(fast)
+    static_assert(ORDER >= 1 && ORDER <= 5, "interp_order");
+    if (ORDER != 1 && ORDER != 3) return;  // general orders go through advect_seed (InteriorPath)
     float x = A.seed_lon[ix];
     float y = A.seed_lat[iy];
     const float cx_conv =
@@ -983,7 +1060,10 @@ struct InteriorPath {
 template <int ORDER, bool FUSED>
 struct InteriorPath<float, ORDER, FUSED> {
     static __device__ __forceinline__ void run(const AdvectArgs<float> &A, int iy, int ix) {
-        advect_seed_f32<ORDER>(A, iy, ix);  // looks at A.ext itself
+        if (ORDER == 1 || ORDER == 3)
+            advect_seed_f32<ORDER>(A, iy, ix);  // looks at A.ext itself
+        else
+            advect_seed<float, ORDER, true, false>(A, A.img, iy, ix);
     }
 };
 
@@ -1150,10 +1230,15 @@ int advect_outer_impl(lc_ctx *ctx, AdvectArgs<T> A) {
             O.p_clo = prev + A.ny;
             O.p_rhi = O.p_clo + A.nx;
             O.p_chi = O.p_rhi + A.ny;
-            if (A.order == 3)
-                hipLaunchKernelGGL((outer_substep_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, A, O, A.t0 + s, k > 0);
-            else
-                hipLaunchKernelGGL((outer_substep_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, A, O, A.t0 + s, k > 0);
+#define LC_OUTER(ORD) hipLaunchKernelGGL((outer_substep_kernel<T, ORD>), dim3(blocks), dim3(256), 0, st, A, O, A.t0 + s, k > 0)
+            switch (A.order) {
+                case 2: LC_OUTER(2); break;
+                case 3: LC_OUTER(3); break;
+                case 4: LC_OUTER(4); break;
+                case 5: LC_OUTER(5); break;
+                default: LC_OUTER(1); break;
+            }
+#undef LC_OUTER
             hipLaunchKernelGGL((outer_hi_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O);
         }
         if (A.traj_x)
@@ -1178,8 +1263,8 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     AdvectArgs<T> A;
     A.wind_f32 = wind_f32;
     A.lin = (const T *)packed_lin;
-    A.img = (order == 3) ? (const T *)packed_cub : (const T *)packed_lin;
-    A.ext = (const T *)packed_ext;
+    A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
+    A.ext = (order == 1 || order == 3) ? (const T *)packed_ext : nullptr;  // general orders: two-sample form
     A.level_elems = lc_level_elems(ny_f, nx_f);
     A.pitch = nx_f + LC_PAD;
     A.ny_f = ny_f;
@@ -1239,7 +1324,12 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     const bool fused64 = sizeof(T) == 8 && A.ext != nullptr;  // opt-in single-sample iterations in float64
     const bool f64 = sizeof(T) == 8;
     const char *name = nullptr;
-    if (order == 3) {
+    if (order == 2 || order == 4 || order == 5) {  // generic direct kernel, any dtype
+        if (order == 2) hipLaunchKernelGGL((advect_kernel<T, 2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+        if (order == 4) hipLaunchKernelGGL((advect_kernel<T, 4>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+        if (order == 5) hipLaunchKernelGGL((advect_kernel<T, 5>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+        name = order == 2 ? "advect_kernel<T, 2, false>" : order == 4 ? "advect_kernel<T, 4, false>" : "advect_kernel<T, 5, false>";
+    } else if (order == 3) {
         if (fused64) {
             hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
             name = "advect_kernel<double, 3, true>";
@@ -1299,7 +1389,7 @@ int sample_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int
                 int nx, int row0, int ny_global, int order, void *out_u, void *out_v) {
     AdvectArgs<T> A = {};
     A.lin = (const T *)packed_lin;
-    A.img = (order == 3) ? (const T *)packed_cub : (const T *)packed_lin;
+    A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
     A.level_elems = lc_level_elems(ny_f, nx_f);
     A.pitch = nx_f + LC_PAD;
     A.ny_f = ny_f;
@@ -1316,12 +1406,17 @@ int sample_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int
     A.order = order;
     const size_t n = (size_t)ny * nx;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    if (order == 3)
-        hipLaunchKernelGGL((sample_kernel<T, 3>), dim3(blocks), dim3(256), 0, ctx->stream, A, (const T *)px,
-                           (const T *)py, level, (T *)out_u, (T *)out_v);
-    else
-        hipLaunchKernelGGL((sample_kernel<T, 1>), dim3(blocks), dim3(256), 0, ctx->stream, A, (const T *)px,
-                           (const T *)py, level, (T *)out_u, (T *)out_v);
+#define LC_SAMPLE(ORD)                                                                                                 \
+    hipLaunchKernelGGL((sample_kernel<T, ORD>), dim3(blocks), dim3(256), 0, ctx->stream, A, (const T *)px, (const T *)py, \
+                       level, (T *)out_u, (T *)out_v)
+    switch (order) {
+        case 2: LC_SAMPLE(2); break;
+        case 3: LC_SAMPLE(3); break;
+        case 4: LC_SAMPLE(4); break;
+        case 5: LC_SAMPLE(5); break;
+        default: LC_SAMPLE(1); break;
+    }
+#undef LC_SAMPLE
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }
@@ -1334,8 +1429,8 @@ extern "C" int lc_sample(lc_ctx *ctx, const void *packed_lin, const void *packed
                          int interp_order, void *out_u, void *out_v) {
     LC_REQUIRE(ctx, "lc_sample: null context");
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_sample: bad dtype %d", dtype);
-    if (interp_order != 1 && interp_order != 3) {
-        lc_set_error("lc_sample: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
+    if (interp_order < 1 || interp_order > 5) {
+        lc_set_error("lc_sample: interp_order %d unsupported (scipy's spline orders 1..5; 0 fails in the reference)", interp_order);
         return LC_EUNSUPPORTED;
     }
     LC_REQUIRE(packed_lin && (interp_order == 1 || packed_cub), "lc_sample: missing field image");
@@ -1359,13 +1454,14 @@ extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed
     LC_REQUIRE(ctx, "lc_advect: null context");
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64 || dtype == LC_F64_WIND_F32, "lc_advect: bad dtype %d", dtype);
     LC_REQUIRE(dtype != LC_F64_WIND_F32 || !packed_ext, "lc_advect: LC_F64_WIND_F32 keeps the two-sample form (no ext)");
-    if (interp_order != 1 && interp_order != 3) {
-        lc_set_error("lc_advect: interp_order %d unsupported (1 and 3 are implemented; 0 fails in the reference too)",
+    if (interp_order < 1 || interp_order > 5) {
+        lc_set_error("lc_advect: interp_order %d unsupported (scipy's spline orders 1..5; 0 fails in the reference too)",
                      interp_order);
         return LC_EUNSUPPORTED;
     }
     LC_REQUIRE(packed_lin, "lc_advect: packed_lin is required (pole rows use order 1)");
-    LC_REQUIRE(interp_order == 1 || packed_cub, "lc_advect: interp_order 3 needs packed_cub");
+    LC_REQUIRE(interp_order == 1 || packed_cub, "lc_advect: interp_order > 1 needs packed_cub (lc_field_pack of that order)");
+    LC_REQUIRE(interp_order == 1 || interp_order == 3 || !packed_ext, "lc_advect: orders 2, 4, 5 take no packed_ext");
     LC_REQUIRE(nt >= 2 && ny_f >= 4 && nx_f >= 4, "lc_advect: field too small (nt=%d ny_f=%d nx_f=%d)", nt, ny_f, nx_f);
     LC_REQUIRE(ny >= 1 && nx >= 1 && seed_lat_dev && seed_lon_dev, "lc_advect: bad seed grid");
     LC_REQUIRE(row0 >= 0 && row0 + ny <= ny_global, "lc_advect: rows [%d,%d) outside global grid of %d rows", row0,

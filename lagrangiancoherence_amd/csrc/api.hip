@@ -135,8 +135,8 @@ extern "C" int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, 
     LC_REQUIRE(u_dev && v_dev && packed_dev, "lc_field_pack: null pointer");
     LC_REQUIRE(nt >= 1 && ny_f >= 4 && nx_f >= 4, "lc_field_pack: field too small (nt=%d ny_f=%d nx_f=%d)", nt, ny_f,
                nx_f);
-    if (interp_order != 1 && interp_order != 3) {
-        lc_set_error("lc_field_pack: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
+    if (interp_order < 1 || interp_order > 5) {
+        lc_set_error("lc_field_pack: interp_order %d unsupported (scipy's spline orders 1..5)", interp_order);
         return LC_EUNSUPPORTED;
     }
     LC_HIP_CHECK(hipSetDevice(ctx->device));
@@ -285,8 +285,8 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     LC_REQUIRE(t0 >= 0 && nsteps >= 0 && t0 + nsteps <= nt - 1, "lc_lcs_host: steps [%d,%d) need levels up to %d, have %d",
                t0, t0 + nsteps, t0 + nsteps, nt);
     LC_REQUIRE(gauss_sigma >= 0.0 || gauss_sigma != gauss_sigma, "lc_lcs_host: gauss_sigma must be >= 0 (0 = no smoothing)");
-    if (interp_order != 1 && interp_order != 3) {
-        lc_set_error("lc_lcs_host: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
+    if (interp_order < 1 || interp_order > 5) {
+        lc_set_error("lc_lcs_host: interp_order %d unsupported (scipy's spline orders 1..5)", interp_order);
         return LC_EUNSUPPORTED;
     }
     LC_HIP_CHECK(hipSetDevice(ctx->device));
@@ -318,7 +318,7 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     LC_TRY(u.alloc(fbytes));
     LC_TRY(v.alloc(fbytes));
     LC_TRY(lin.alloc(pbytes));
-    if (interp_order == 3) LC_TRY(cub.alloc(pbytes));
+    if (interp_order != 1) LC_TRY(cub.alloc(pbytes));
     LC_TRY(slat.alloc(ny * es));
     LC_TRY(slon.alloc(nx * es));
     LC_TRY(x.alloc(sbytes));
@@ -333,9 +333,10 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     LC_HIP_CHECK(hipMemcpyAsync(slat.p, seed_lat_host, ny * es, hipMemcpyHostToDevice, st));
     LC_HIP_CHECK(hipMemcpyAsync(slon.p, seed_lon_host, nx * es, hipMemcpyHostToDevice, st));
     // float path: one combined sample per SETTLS iteration (ext image of the matching order)
-    if (dtype == LC_F32 && settls_order > 0) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
+    const bool fusable = interp_order == 1 || interp_order == 3;
+    if (dtype == LC_F32 && settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
     LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
-    if (interp_order == 3) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 3, cub.p, ext.p));
+    if (interp_order != 1) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, interp_order, cub.p, ext.p));
     LC_TRY(lc_advect(ctx, lin.p, cub.p, ext.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p,
                      nx, 0, ny, timestep, settls_order, interp_order, cyclic_x, t0, nsteps, x.p, y.p, tx.p, ty.p));
     if (sigma_out) {
@@ -397,8 +398,8 @@ extern "C" int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v
     LC_REQUIRE(u_host && v_host && lat_f_host && lon_f_host, "lc_lcs_global_host: null input pointer");
     LC_REQUIRE(nt >= 2 && ny_f >= 4 && nx_f >= 4, "lc_lcs_global_host: bad sizes");
     LC_REQUIRE(settls_order >= 0, "lc_lcs_global_host: SETTLS_order must be >= 0");
-    if (interp_order != 1 && interp_order != 3) {
-        lc_set_error("lc_lcs_global_host: interp_order %d unsupported (1 and 3 are implemented)", interp_order);
+    if (interp_order < 1 || interp_order > 5) {
+        lc_set_error("lc_lcs_global_host: interp_order %d unsupported (scipy's spline orders 1..5)", interp_order);
         return LC_EUNSUPPORTED;
     }
     LC_HIP_CHECK(hipSetDevice(ctx->device));
@@ -467,10 +468,11 @@ extern "C" int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v
     LC_HIP_CHECK(hipStreamSynchronize(st));  // hl / ho are pageable locals
     const size_t pbytes = lc_packed_elems(nt, ny, nx) * es;
     LC_TRY(lin.alloc(pbytes));
-    if (interp_order == 3) LC_TRY(cub.alloc(pbytes));
-    if (wdtype == LC_F32 && settls_order > 0) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny, nx) * es));
+    if (interp_order != 1) LC_TRY(cub.alloc(pbytes));
+    const bool fusable = interp_order == 1 || interp_order == 3;
+    if (wdtype == LC_F32 && settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny, nx) * es));
     LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
-    if (interp_order == 3) LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, 3, cub.p, ext.p));
+    if (interp_order != 1) LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, interp_order, cub.p, ext.p));
     LC_TRY(x.alloc(sbytes));
     LC_TRY(y.alloc(sbytes));
     const double lat_min = wdtype == LC_F32 ? (double)(float)lat[0] : lat[0], lat_max = wdtype == LC_F32 ? (double)(float)lat[ny - 1] : lat[ny - 1];

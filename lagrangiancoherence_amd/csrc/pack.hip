@@ -166,6 +166,83 @@ __device__ void prefilter_line_blocked(T *c, size_t stride, int n) {
     }
 }
 
+// Orders 2, 4, 5: the same recursion with scipy's pole lists (ni_splines.c get_filter_poles); the total gain
+// prod (1 - z)(1 - 1/z) is applied while the first pole's causal pass reads the line, as _apply_filter_gain does
+// before any pole.  Thread per line (these orders take the generic direct advect kernel; speed is not the point).
+struct PoleList {
+    double z[2];
+    int n;
+    double gain;
+};
+
+inline PoleList spline_poles(int order) {
+    PoleList p = {};
+    if (order == 2) {
+        p.n = 1;
+        p.z[0] = sqrt(8.0) - 3.0;
+    } else if (order == 3) {
+        p.n = 1;
+        p.z[0] = sqrt(3.0) - 2.0;
+    } else if (order == 4) {
+        p.n = 2;
+        p.z[0] = sqrt(664.0 - sqrt(438976.0)) + sqrt(304.0) - 19.0;
+        p.z[1] = sqrt(664.0 + sqrt(438976.0)) - sqrt(304.0) - 19.0;
+    } else {
+        p.n = 2;
+        p.z[0] = sqrt(67.5 - sqrt(4436.25)) + sqrt(26.25) - 6.5;
+        p.z[1] = sqrt(67.5 + sqrt(4436.25)) - sqrt(26.25) - 6.5;
+    }
+    p.gain = 1.0;
+    for (int i = 0; i < p.n; ++i) p.gain *= (1.0 - p.z[i]) * (1.0 - 1.0 / p.z[i]);
+    return p;
+}
+
+template <typename T>
+__device__ void prefilter_line_poles(T *c, size_t stride, int n, const PoleList P) {
+    if (n < 2) return;
+    for (int k = 0; k < P.n; ++k) {
+        const double z = P.z[k], gain = k == 0 ? P.gain : 1.0;
+        const double zn1 = pow(z, (double)(n - 1));
+        double c0 = gain * (double)c[0] + zn1 * (gain * (double)c[(size_t)(n - 1) * stride]);
+        double zi = z;
+        for (int i = 1; i < n - 1; ++i) {
+            if (zi == 0.0) break;
+            c0 += zi * (gain * (double)c[(size_t)i * stride] + zn1 * (gain * (double)c[(size_t)(n - 1 - i) * stride]));
+            zi *= z;
+        }
+        c0 /= (1.0 - zn1 * zn1);
+        double prev = c0;
+        c[0] = (T)prev;
+        for (int i = 1; i < n; ++i) {
+            prev = gain * (double)c[(size_t)i * stride] + z * prev;
+            c[(size_t)i * stride] = (T)prev;
+        }
+        const double cn1 = (double)c[(size_t)(n - 1) * stride], cn2 = (double)c[(size_t)(n - 2) * stride];
+        double next = (z * cn2 + cn1) * z / (z * z - 1.0);
+        c[(size_t)(n - 1) * stride] = (T)next;
+        for (int i = n - 2; i >= 0; --i) {
+            next = z * (next - (double)c[(size_t)i * stride]);
+            c[(size_t)i * stride] = (T)next;
+        }
+    }
+}
+
+template <typename T>
+__global__ void prefilter_general_kernel(T *__restrict__ packed, int nt, int ny, int nx, int axis, const PoleList P) {
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
+    const size_t per_level = (size_t)(axis == 0 ? nx : ny) * 2;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= per_level * nt) return;
+    const size_t t = i / per_level, r = i - t * per_level;
+    const int k = (int)(r >> 1), comp = (int)(r & 1);
+    T *base = packed + t * level + ((size_t)LC_PAD_LO * pitch + LC_PAD_LO) * 2 + comp;
+    if (axis == 0)
+        prefilter_line_poles<T>(base + (size_t)k * 2, (size_t)pitch * 2, ny, P);
+    else
+        prefilter_line_poles<T>(base + (size_t)k * pitch * 2, 2, nx, P);
+}
+
 // axis 0 (latitude): one thread per (level, column, component); consecutive
 // threads touch consecutive elements, so every step of the march is coalesced.
 template <typename T>
@@ -357,6 +434,14 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
             hipLaunchKernelGGL(prefilter_rows_kernel<T>, dim3((unsigned)((lines + 63) / 64)), dim3(64), 0,
                                ctx->stream, packed, nt, ny, nx);
         }
+    }
+    if (order == 2 || order == 4 || order == 5) {  // scipy filters axis 0 first, then axis 1
+        const PoleList P = spline_poles(order);
+        const size_t l0 = (size_t)nt * nx * 2, l1 = (size_t)nt * ny * 2;
+        hipLaunchKernelGGL(prefilter_general_kernel<T>, dim3((unsigned)((l0 + 63) / 64)), dim3(64), 0, ctx->stream, packed, nt,
+                           ny, nx, 0, P);
+        hipLaunchKernelGGL(prefilter_general_kernel<T>, dim3((unsigned)((l1 + 63) / 64)), dim3(64), 0, ctx->stream, packed, nt,
+                           ny, nx, 1, P);
     }
     hipLaunchKernelGGL(fill_pads_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
     if (ext && nt >= 2) {

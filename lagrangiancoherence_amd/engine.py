@@ -54,7 +54,7 @@ def common_dtype(*arrays) -> np.dtype:
 class PackedField:
     """Gather-ready image(s) of a wind time series, resident on the device."""
     lin: "torch.Tensor"            # order-1 image, always present
-    cub: "torch.Tensor | None"     # order-3 coefficient image
+    cub: "torch.Tensor | None"     # B-spline coefficient image of order ``order`` (2..5), None for order 1
     ext: "torch.Tensor | None"     # 2*img[t]-img[t+1] of the image matching interp_order (fused SETTLS sample)
     nt: int
     ny_f: int
@@ -65,6 +65,7 @@ class PackedField:
     lon_max: float
     dtype: np.dtype
     wind_f32: bool = False          # float32 wind on float64 coordinates: numpy's promotion rules in lc_advect
+    order: int = 1                  # interpolation order the field was prepared for (order 1 is always available)
 
 
 class Engine:
@@ -131,8 +132,8 @@ class Engine:
         float32 (which cannot be bit-identical to scipy's double evaluation anyway), off for float64
         (keeps the reference's operation order and numpy/scipy's exact results; ``True`` there trades
         that for speed -- positions move by ~1e-13 degrees)."""
-        if interp_order not in (1, 3):
-            raise ValueError(f"interp_order {interp_order} unsupported (1 and 3 are implemented; "
+        if interp_order not in (1, 2, 3, 4, 5):
+            raise ValueError(f"interp_order {interp_order} unsupported (scipy's spline orders 1..5; "
                              "0 fails in the reference too, LCS/tools.py:24-30)")
         lat_f = np.asarray(lat_f)
         lon_f = np.asarray(lon_f)
@@ -152,7 +153,7 @@ class Engine:
         self._use_current_stream()
         if fuse_levels is None:
             fuse_levels = dtype == np.dtype(np.float32)
-        if wind_f32:
+        if wind_f32 or interp_order in (2, 4, 5):   # general orders: generic direct kernel, two-sample form
             fuse_levels = False
         ext = None
         if fuse_levels and nt >= 2:
@@ -161,15 +162,15 @@ class Engine:
         _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f, 1,
                                            self._ptr(lin), self._ptr(ext if interp_order == 1 else None)), self.lib)
         cub = None
-        if interp_order == 3:
+        if interp_order != 1:
             cub = self._empty((n,), dtype)
             _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f,
-                                               3, self._ptr(cub), self._ptr(ext)), self.lib)
+                                               int(interp_order), self._ptr(cub), self._ptr(ext)), self.lib)
         # coordinate extremes in the arithmetic dtype (what .min()/.max() give numpy)
         la = lat_f.astype(dtype)
         lo = lon_f.astype(dtype)
         return PackedField(lin, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
-                           wind_f32)
+                           wind_f32, int(interp_order))
 
     # ------------------------------------------------------------------ global pre-processing (LCS.py:105-118)
     def regrid(self, u, lat, lon, lats, lons):
@@ -212,8 +213,8 @@ class Engine:
 
         ``halo=(n_lo, n_hi)``: return ``(n_lo + ny + n_hi, nx)`` buffers with the results in the middle
         rows, so a row-sharded caller can receive its neighbours' rows in place (sharded.py)."""
-        if interp_order == 3 and field.cub is None:
-            raise ValueError("field was prepared for interp_order=1")
+        if interp_order != 1 and field.order != interp_order:
+            raise ValueError(f"field was prepared for interp_order={field.order}")
         dtype = field.dtype
         slat = self.to_device(seed_lat, dtype)
         slon = self.to_device(seed_lon, dtype)
@@ -234,8 +235,8 @@ class Engine:
             ty = self._empty((nsteps + 1, ny, nx), dtype)
         self._use_current_stream()
         _capi.check(self.lib.lc_advect(
-            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order == 3 else None),
-            self._ptr(field.ext if (field.cub is not None) == (interp_order == 3) else None),
+            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order != 1 else None),
+            self._ptr(field.ext if field.order == interp_order else None),
             _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[dtype], field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max,
             self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, float(timestep), int(SETTLS_order),
             int(interp_order), x_boundary_mode(cyclic_xboundary, noncyclic_clamp, int(row0) == 0 and ny == ny_global),
@@ -246,8 +247,8 @@ class Engine:
 
     def sample(self, field: PackedField, pos_x, pos_y, level=0, interp_order=1, row0=0, ny_global=None):
         """tools.xr_map_coordinates for (u, v) of one time level at positions (ny, nx) in degrees."""
-        if interp_order == 3 and field.cub is None:
-            raise ValueError("field was prepared for interp_order=1")
+        if interp_order != 1 and field.order != interp_order:
+            raise ValueError(f"field was prepared for interp_order={field.order}")
         dtype = field.dtype
         px = self.to_device(pos_x, dtype)
         py = self.to_device(pos_y, dtype)
@@ -257,7 +258,7 @@ class Engine:
         ov = self._empty((ny, nx), dtype)
         self._use_current_stream()
         _capi.check(self.lib.lc_sample(
-            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order == 3 else None), _NP2LC[dtype],
+            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order != 1 else None), _NP2LC[dtype],
             field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max, int(level),
             self._ptr(px), self._ptr(py), ny, nx, int(row0), ny_global, int(interp_order), self._ptr(ou),
             self._ptr(ov)), self.lib)

@@ -424,32 +424,55 @@ def _mirror_index(i, n):
     return np.where(i > n - 1, s2 - i, i)
 
 
-def spline_prefilter_mirror(field):
-    """Cubic B-spline coefficients, mirror boundary, both axes.
+def _spline_poles(order):
+    """scipy ni_splines.c get_filter_poles."""
+    sq = np.sqrt
+    return {2: [sq(8.0) - 3.0], 3: [sq(3.0) - 2.0],
+            4: [sq(664.0 - sq(438976.0)) + sq(304.0) - 19.0, sq(664.0 + sq(438976.0)) - sq(304.0) - 19.0],
+            5: [sq(67.5 - sq(4436.25)) + sq(26.25) - 6.5, sq(67.5 + sq(4436.25)) - sq(26.25) - 6.5]}[order]
 
-    Equals ``scipy.ndimage.spline_filter(field, 3, mode='mirror')`` -- the
-    prefilter scipy runs inside ``map_coordinates(order=3, mode='wrap')``.
+
+def spline_prefilter_mirror(field, order=3):
+    """B-spline coefficients of ``order`` (2..5), mirror boundary, both axes.
+
+    Equals ``scipy.ndimage.spline_filter(field, order, mode='mirror')`` -- the
+    prefilter scipy runs inside ``map_coordinates(order, mode='wrap')`` -- to 4e-15 for
+    orders 2 and 3, to 1e-12 for orders 4 and 5 (scipy's pole constants differ in the last bit).
     """
-    z = np.sqrt(3.0) - 2.0
+    poles = _spline_poles(order)
+    gain = 1.0
+    for z in poles:
+        gain *= (1 - z) * (1 - 1 / z)
     c = np.array(field, dtype=np.float64)
     for axis in (0, 1):
         c = np.moveaxis(c, axis, 0).copy()
         n = c.shape[0]
-        c *= 6.0
-        zn1 = z ** (n - 1)
-        c0 = c[0] + zn1 * c[n - 1]
-        zi = z
-        for i in range(1, n - 1):
-            c0 = c0 + zi * (c[i] + zn1 * c[n - 1 - i])
-            zi *= z
-        c[0] = c0 / (1 - zn1 * zn1)
-        for i in range(1, n):
-            c[i] += z * c[i - 1]
-        c[n - 1] = (z / (z * z - 1)) * (c[n - 1] + z * c[n - 2])
-        for i in range(n - 2, -1, -1):
-            c[i] = z * (c[i + 1] - c[i])
+        c *= gain
+        for z in poles:
+            zn1 = z ** (n - 1)
+            c0 = c[0] + zn1 * c[n - 1]
+            zi = z
+            for i in range(1, n - 1):
+                c0 = c0 + zi * (c[i] + zn1 * c[n - 1 - i])
+                zi *= z
+            c[0] = c0 / (1 - zn1 * zn1)
+            for i in range(1, n):
+                c[i] += z * c[i - 1]
+            c[n - 1] = (z / (z * z - 1)) * (c[n - 1] + z * c[n - 2])
+            for i in range(n - 2, -1, -1):
+                c[i] = z * (c[i + 1] - c[i])
         c = np.moveaxis(c, 0, axis)
     return c
+
+
+def _bspline_centred(n, t):
+    """beta_n(t) = 1/n! sum_k (-1)^k C(n+1, k) (t + (n+1)/2 - k)_+^n."""
+    from math import comb, factorial
+    s = 0.0
+    for k in range(n + 2):
+        a = t + (n + 1) / 2.0 - k
+        s = s + (-1) ** k * comb(n + 1, k) * np.where(a > 0, a, 0.0) ** n
+    return s / factorial(n)
 
 
 def interp_restated(field, cy, cx, order, mode):
@@ -493,6 +516,15 @@ def interp_restated(field, cy, cx, order, mode):
         wx = w(tx)
         off = -1
         coeff = spline_prefilter_mirror(field)
+    elif order in (2, 4, 5):
+        # first tap: floor(c) - order//2 (odd) or floor(c + 1/2) - order//2 (even); centred B-spline weights
+        if order % 2 == 0:
+            y0 = np.floor(cy + 0.5).astype(np.int64)
+            x0 = np.floor(cx + 0.5).astype(np.int64)
+        off = -(order // 2)
+        wy = [_bspline_centred(order, cy - (y0 + off + a)) for a in range(order + 1)]
+        wx = [_bspline_centred(order, cx - (x0 + off + b)) for b in range(order + 1)]
+        coeff = spline_prefilter_mirror(field, order)
     else:
         raise ValueError(order)
     out = np.zeros(cy.shape)

@@ -82,6 +82,46 @@ def test_prefilter_matches_scipy(eng, O, dtype, tol):
     assert np.array_equal(img[0, ny + 2, 1:nx + 1, 1], img[0, ny - 2, 1:nx + 1, 1])
 
 
+# ------------------------------------------------------------------ orders 2, 4, 5 (generic direct kernels)
+@pytest.mark.parametrize("order", [2, 4, 5])
+def test_general_spline_orders_vs_scipy_and_oracle(eng, O, order):
+    """LCS/trajectory.py:16 + LCS/tools.py:26-30 hand any interp_order to scipy.  Prefilter vs
+    scipy.ndimage.spline_filter itself, one interpolation pass vs scipy.ndimage.map_coordinates through the
+    oracle's xr_map_coordinates (index scale, pole rows, wrap), then whole advections vs the oracle."""
+    from scipy.ndimage import spline_filter
+    tol = 1e-12 if order == 2 else 5e-11       # orders 4, 5: scipy's pole constants differ in the last bit
+    u, v, lat, lon = _rand_field(40 + order, nt=4, ny=21, nx=37)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    nt, ny, nx = u.shape
+    img = _np(f.cub).reshape(nt, ny + 3, nx + 3, 2)
+    np.testing.assert_allclose(img[1, 1:ny + 1, 1:nx + 1, 0], spline_filter(u[1], order=order, mode="mirror"), atol=tol)
+    rng = np.random.default_rng(order)
+    py = rng.uniform(lat[0] - 5, lat[-1] + 5, (ny, nx))
+    px = rng.uniform(lon[0] - 30, lon[-1] + 30, (ny, nx))
+    su, sv = eng.sample(f, px, py, level=2, interp_order=order)
+    np.testing.assert_allclose(_np(su), O.xr_map_coordinates(u[2], lat, lon, px, py, order=order), rtol=0, atol=20 * tol)
+    np.testing.assert_allclose(_np(sv), O.xr_map_coordinates(v[2], lat, lon, px, py, order=order), rtol=0, atol=20 * tol)
+    for K, cyc in ((0, True), (2, True), (1, False)):
+        kw = dict(timestep=-3600.0, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyc)
+        x, y = eng.advect(f, lat, lon, -3600.0, K, order, cyc)
+        xr_, yr_ = O.parcel_propagation(u, v, lat, lon, **kw)
+        np.testing.assert_allclose(_np(x), xr_, rtol=0, atol=POS_ATOL64)
+        np.testing.assert_allclose(_np(y), yr_, rtol=0, atol=POS_ATOL64)
+    # float32 fields: scipy evaluates in double and rounds to the field dtype; so does the generic kernel
+    u32, v32, la32, lo32 = (a.astype(np.float32) for a in (u, v, lat, lon))
+    f32 = eng.prepare_field(u32, v32, la32, lo32, order)
+    x, y = eng.advect(f32, la32, lo32, -3600.0, 2, order, True)
+    x32, y32 = O.parcel_propagation(u32, v32, la32, lo32, timestep=-3600.0, SETTLS_order=2, interp_order=order, cyclic_xboundary=True)
+    d = np.abs(_np(x).astype(np.float64) - x32)
+    d = np.maximum(np.minimum(d, np.abs(d - 360)), np.abs(_np(y) - y32))
+    # (the float32 coefficient image and float32 positions meet a spatially uncorrelated random wind)
+    assert np.percentile(d, 99) < 2e-4 and d.max() < 5e-3
+    with pytest.raises(ValueError):
+        eng.advect(f, lat, lon, -3600.0, 1, 3, True)           # prepared for another order
+    with pytest.raises(ValueError):
+        eng.prepare_field(u, v, lat, lon, 6)
+
+
 # ------------------------------------------------------------------ advection
 @pytest.mark.parametrize("order", [1, 3])
 @pytest.mark.parametrize("K", [0, 1, 4])

@@ -67,7 +67,7 @@ def test_kat2_uniform_zonal_wind(K):
 
 
 # ---------------------------------------------------------------- KAT-3
-@pytest.mark.parametrize("order,mode", [(1, "wrap"), (3, "wrap"), (1, "constant")])
+@pytest.mark.parametrize("order,mode", [(1, "wrap"), (3, "wrap"), (1, "constant"), (2, "wrap"), (4, "wrap"), (5, "wrap")])
 def test_kat3_interp_restated_vs_scipy(order, mode):
     rng = np.random.default_rng(3)
     f = rng.standard_normal((17, 23))
@@ -78,16 +78,19 @@ def test_kat3_interp_restated_vs_scipy(order, mode):
                          [0, nx - 1, nx, 5.0, -0.0, nx - 1.0, 0.0, 2 * (nx - 1.0)]])
     ref = map_coordinates(f, np.array([cy, cx]), order=order, mode=mode)
     got = O.interp_restated(f, cy, cx, order, mode)
-    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-14)
+    # orders 4 and 5: scipy's prefilter pole constants differ from sqrt-expression ones in the last bit and
+    # the filter gain (~400) carries that into the coefficients
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-14 if order <= 3 else 2e-12)
 
 
 # ---------------------------------------------------------------- KAT-4
-def test_kat4_prefilter_vs_scipy():
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_kat4_prefilter_vs_scipy(order):
     rng = np.random.default_rng(4)
     f = rng.standard_normal((19, 31))
-    np.testing.assert_allclose(O.spline_prefilter_mirror(f),
-                               spline_filter(f, order=3, mode="mirror"),
-                               rtol=0, atol=5e-14)
+    np.testing.assert_allclose(O.spline_prefilter_mirror(f, order),
+                               spline_filter(f, order=order, mode="mirror"),
+                               rtol=0, atol=5e-14 if order <= 3 else 5e-12)
 
 
 # ---------------------------------------------------------------- KAT-5
