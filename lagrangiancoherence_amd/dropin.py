@@ -192,10 +192,12 @@ class LCS:
             u = ds.u.copy()
             v = ds.v.copy()
         if isinstance(resample, str):                                      # LCS.py:88-91
-            if not _is_xarray(u):
-                raise NotImplementedError("resample= needs xarray inputs")
-            u = u.resample({timedim: resample}).interpolate('linear')
-            v = v.resample({timedim: resample}).interpolate('linear')
+            if _is_xarray(u):
+                u = u.resample({timedim: resample}).interpolate('linear')
+                v = v.resample({timedim: resample}).interpolate('linear')
+            else:
+                u = labelled.resample_linear(u, timedim, resample)
+                v = labelled.resample_linear(v, timedim, resample)
             timestep = np.sign(timestep) * (u[timedim].values[1] - u[timedim].values[0]) \
                 .astype('timedelta64[s]').astype('float')
         assert set(u.dims) == set(v.dims), "u and v dims are different"                     # LCS.py:95

@@ -82,6 +82,25 @@ class DataArray:
         return f"<labelled.DataArray {self.name!r} dims={self.dims} shape={self.shape} dtype={self.dtype}>"
 
 
+def resample_linear(da, dim, freq):
+    """``da.resample({dim: freq}).interpolate('linear')`` (LCS/LCS.py:89-90) for a labelled array: the new time
+    axis is pandas' resampling index of the old one (what xarray's grouper calls ``full_index``), the values go
+    through ``scipy.interpolate.interp1d(kind='linear', bounds_error=False)`` on the times as float64 nanoseconds
+    since the first one -- the two kernels xarray itself delegates to."""
+    import pandas as pd
+    from scipy.interpolate import interp1d
+    t = pd.DatetimeIndex(np.asarray(da.coords[dim]))
+    full = pd.Series(np.arange(t.size), index=t).resample(freq).asfreq().index
+    t0 = t.values.astype("datetime64[ns]").min()
+    x = (t.values.astype("datetime64[ns]") - t0).astype("int64").astype(np.float64)
+    xn = (full.values.astype("datetime64[ns]") - t0).astype("int64").astype(np.float64)
+    ax = da.dims.index(dim)
+    vals = interp1d(x, da.values, kind="linear", axis=ax, bounds_error=False, assume_sorted=True)(xn)
+    coords = dict(da.coords)
+    coords[dim] = full.values
+    return DataArray(vals, da.dims, coords, da.name)
+
+
 class Dataset:
     """Just enough for ``ds.u`` / ``ds.v`` / ``ds.copy()`` (LCS/LCS.py:81-83)."""
 

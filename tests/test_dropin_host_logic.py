@@ -112,6 +112,23 @@ def test_lcs_return_variants_and_time_stamp():
     assert np.array_equal(e2.values, eig.values)
 
 
+def test_resample_keyword_without_xarray():
+    """LCS.py:88-91: `resample='3h'` interpolates the 6-hourly series linearly to 3-hourly and re-derives |timestep|
+    from the new axis (its sign is kept)."""
+    from LagrangianCoherence.LCS.LCS import LCS
+    ds, times, lat, lon = _dataset()
+    kw = dict(isglobal=True, interp_to_common_grid=False, truncation=None, verbose=False, traj_interp_order=1)
+    e = LCS(timestep=-999.0, SETTLS_order=2)(ds, resample='3h', **kw)
+    u, v, _, _ = flows.config1()
+    x = np.arange(u.shape[0]) * 6.0
+    from scipy.interpolate import interp1d
+    xn = np.arange(0, x[-1] + 1e-9, 3.0)
+    u3, v3 = interp1d(x, u, axis=0)(xn), interp1d(x, v, axis=0)(xn)
+    s, _, _ = O.lcs(u3, v3, lat, lon, timestep=-3 * 3600.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=True)
+    np.testing.assert_allclose(e.values[0], s, rtol=1e-9)
+    assert e['time'].values[0] == times[0]
+
+
 def test_unsorted_inputs_are_sorted_and_dims_are_checked():
     from LagrangianCoherence.LCS import trajectory
     from LagrangianCoherence.LCS.LCS import LCS

@@ -36,3 +36,21 @@ def test_dataset_and_errors():
         labelled.DataArray(np.zeros((2, 2)), ['a', 'b'], {'a': np.zeros(3)})
     with pytest.raises(AttributeError):
         ds.w
+
+
+def test_resample_linear_is_pandas_index_plus_scipy_interp1d():
+    """LCS/LCS.py:89-90 `u.resample(time='2h').interpolate('linear')` without xarray: 6-hourly -> 2-hourly."""
+    import pandas as pd
+    times = pd.date_range('2000-01-01', periods=4, freq='6h').values
+    vals = np.random.default_rng(0).standard_normal((3, 4, 5))                 # (latitude, time, longitude)
+    da = labelled.DataArray(vals, ['latitude', 'time', 'longitude'],
+                            {'latitude': np.arange(3.0), 'time': times, 'longitude': np.arange(5.0)}, name='u')
+    r = labelled.resample_linear(da, 'time', '2h')
+    assert r.dims == da.dims and r.shape == (3, 10, 5) and r.name == 'u'
+    assert np.array_equal(r['time'].values, pd.date_range('2000-01-01', periods=10, freq='2h').values)
+    np.testing.assert_allclose(r.values[:, ::3], vals, rtol=1e-14, atol=1e-15)   # original instants (interp1d rounds: slope*dx + y_lo)
+    np.testing.assert_allclose(r.values[:, 1], vals[:, 0] + (vals[:, 1] - vals[:, 0]) / 3, rtol=1e-14)
+    np.testing.assert_allclose(r.values[:, 5], vals[:, 1] + 2 * (vals[:, 2] - vals[:, 1]) / 3, rtol=1e-14)
+    # the timestep the reference derives from the new axis (LCS.py:91)
+    dt = (r['time'].values[1] - r['time'].values[0]).astype('timedelta64[s]').astype('float')
+    assert dt == 7200.0
