@@ -88,7 +88,8 @@ int lc_ctx_set_stream(lc_ctx *ctx, void *hip_stream /* hipStream_t; NULL = the d
 int lc_ctx_use_own_stream(lc_ctx *ctx); /* back to the context's private stream */
 int lc_sync(lc_ctx *ctx);
 
-/* Kernel choice of lc_advect for float32 + packed_ext: 1 = per-wave LDS tiles (default), 0 = direct gathers.
+/* Kernel choice of lc_advect for float32 + packed_ext: 1 = per-wave LDS tiles (default; at order 1 the
+ * two-seeds-per-lane kernel), 2 = LDS tiles with the one-seed-per-lane kernel at every order, 0 = direct gathers.
  * -1 restores the default.  The environment variable LCS_LDS_TILES (0/1) sets the initial value, read ONCE in
  * lc_ctx_create (profiling A/B; results are bit-identical either way).  No reference counterpart. */
 int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode);

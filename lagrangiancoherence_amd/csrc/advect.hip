@@ -817,8 +817,15 @@ __device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 
 #ifndef LCS_O3_MINWAVES
 #define LCS_O3_MINWAVES 1
 #endif
+#ifndef LCS_LDS_NUM_SGPR
+#define LCS_LDS_NUM_SGPR 0
+#endif
 template <int ORDER, int KFIX, bool CYCLIC>
-__global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1) advect_lds_kernel(const AdvectArgs<float> A) {
+__global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
+#if LCS_LDS_NUM_SGPR > 0
+    __attribute__((amdgpu_num_sgpr(LCS_LDS_NUM_SGPR)))
+#endif
+    advect_lds_kernel(const AdvectArgs<float> A) {
 #pragma clang fp contract(fast)
     const int K = KFIX >= 0 ? KFIX : A.K;  // KFIX: SETTLS_order known at compile time (the iteration loop unrolls)
     typedef TileGeom<ORDER> G;
@@ -888,10 +895,11 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1) advec
     constexpr int NPASS = LT_ROWS / G::ROWS_PER_PASS;
     // With the Euler sample gathered directly (order 3 without its Euler tile) the tile loads stay behind it:
     // 16 more live VGPRs across the 8 gathers cost two waves per SIMD (measured: 21.7 vs 21.0-21.2 ms)
-#ifdef LCS_O3_NO_PREFETCH
-    constexpr bool PREFETCH = ORDER == 1;
-#else
+    // (order 3 with its Euler tile: prefetching costs 14 VGPRs = one wave per SIMD, 18.1 vs 17.84 ms without)
+#ifdef LCS_O3_PREFETCH
     constexpr bool PREFETCH = ORDER == 1 || E::ON;
+#else
+    constexpr bool PREFETCH = ORDER == 1;
 #endif
     constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
     for (int s = 0; s < A.nsteps; ++s) {
@@ -993,6 +1001,22 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1) advec
             // absolute index coordinate: its rounding must not depend on where the tile sits (row-sharded runs
             // place tiles differently and must stay bit-identical to unsharded ones)
             TapL t = tap_of(to_index(p));
+#ifdef LCS_EXP_SALU  // sensitivity experiment: LCS_EXP_SALU dummy scalar instructions per sample
+            {
+                unsigned dummy = (unsigned)k;
+#pragma unroll
+                for (int q = 0; q < LCS_EXP_SALU; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy) : : "scc");
+                asm volatile("" : : "s"(dummy));
+            }
+#endif
+#ifdef LCS_EXP_VALU  // ... and LCS_EXP_VALU dummy 4-cycle vector instructions per sample
+            {
+                float dummy = t.tx;
+#pragma unroll
+                for (int q = 0; q < LCS_EXP_VALU; ++q) asm volatile("v_fract_f32 %0, %0" : "+v"(dummy));
+                asm volatile("" : : "v"(dummy));
+            }
+#endif
             const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;  // the subtrahends are wave-uniform (SGPRs)
             bool bad = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
             const f2 ew = window_lds<ORDER, LT_PITCH>(base_addr, pitch_bytes, rx, ry, t, e);  // e + sample of ext[t]
@@ -1021,14 +1045,266 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1) advec
     }
 }
 
+
+// ======================================================================================
+// Order 1, TWO seeds per lane (the default for float32 + fused levels at order 1).
+//
+// The one-seed kernel above is neither VALU- nor scalar-throughput bound: adding 14 % more (independent) vector
+// instructions to its loop costs 5 % of time, 37 % more scalar instructions 3 % (tools/ab.sh, LCS_EXP_*): what
+// bounds it is the dependent chain position -> index -> LDS window -> lerps -> position of each sample, with at
+// most 8 waves per SIMD to cover it.  A second, independent seed per lane doubles the work in flight per
+// wave at the same occupancy (44 -> ~70 VGPRs), and the per-wave bookkeeping (tile anchor, staging, loop,
+// level pointers, one rare branch per sample) is shared by 128 seeds instead of 64.
+// A wave's patch is 8 x 16 seeds (lane = column + 8 * row, seeds (row, col) and (row + 8, col)); on C3 that is
+// 2.8 x 2.8 field cells, which the same 16 x 8-node tile covers.  Arithmetic per seed is exactly the one-seed
+// kernel's (results are bit-identical to it and to the direct-gather kernel).
+// ======================================================================================
+constexpr int SPL = 2;  // seeds per lane
+
+#ifdef LCS_STAMPS  // diagnostic build only: where a wave's cycles go (s_memtime), summed over waves and levels
+__device__ unsigned long long g_stamps[8];
+#define LCS_STAMP(i)                                           \
+    {                                                          \
+        const long long _t = __builtin_amdgcn_s_memtime();     \
+        acc_t[i] += _t - last_t;                               \
+        last_t = _t;                                           \
+    }
+#else
+#define LCS_STAMP(i)
+#endif
+
+// 98 SGPRs as compiled admit 6 workgroups per CU (MI355X_MICROARCH.md: 97-112 -> 6); capped at 96 -> 7
+// (7.55 -> 7.31 ms on C3; 80 -> 8 workgroups measures the same as 96).
+#ifndef LCS_LDS2_NUM_SGPR
+#define LCS_LDS2_NUM_SGPR 96
+#endif
+template <int KFIX, bool CYCLIC>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2_NUM_SGPR)))
+    advect_lds2_kernel(const AdvectArgs<float> A) {
+#pragma clang fp contract(fast)
+    constexpr int ORDER = 1;
+    const int K = KFIX >= 0 ? KFIX : A.K;
+    typedef TileGeom<ORDER> G;
+    constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
+    constexpr int WIN = 2, WOFF = LC_PAD_LO;
+    __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
+    const int per_xcd = (A.ntiles + 7) / 8;
+    const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile_id >= A.ntiles) return;  // whole block
+    const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ix = txi * TILE_W + (lane % TILE_W);
+    const int iy0 = tyi * (TILE_H * SPL) + wave * (8 * SPL) + lane / TILE_W;  // seed q sits 8 rows further down
+    f2 *tile = s_tiles[wave];
+
+    bool live[SPL];
+    f2 p[SPL], dd[SPL], hd[SPL];
+    size_t idx[SPL];
+    const size_t plane = (size_t)A.ny * A.nx;
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+        const int iy = iy0 + 8 * q;
+        live[q] = ix < A.nx && iy < A.ny;
+        if (live[q]) {
+            const int grow = A.row0 + iy;
+            if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path, whole integration (Q3)
+                advect_seed<float, 1, false>(A, A.lin, iy, ix);
+                live[q] = false;
+            }
+        }
+        any |= live[q];
+        // lanes without a seed shadow a neighbouring one so that they follow the same path; only their stores are masked
+        p[q] = (f2){A.seed_lon[min(ix, A.nx - 1)], A.seed_lat[min(iy, A.ny - 1)]};
+        const float cx_conv =
+            180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((p[q].y * (float)3.141592653589793) / 180.0f)));
+        dd[q] = (f2){A.dt * cx_conv, A.dtcy};        // trajectory.py:55-57,86-87
+        hd[q] = (f2){A.half_dt * cx_conv, A.hdtcy};  // trajectory.py:110-112
+        idx[q] = live[q] ? (size_t)iy * A.nx + ix : 0;
+        if (live[q] && A.traj_x) {
+            A.traj_x[idx[q]] = p[q].x;
+            A.traj_y[idx[q]] = p[q].y;
+        }
+    }
+    if (__ballot(any) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
+    float ymax_v = A.y_max;
+    asm volatile("" : "+v"(ymax_v));
+    const unsigned tile_addr = lds_address(tile);
+    unsigned pitch_bytes = (unsigned)LT_PITCH * 8u;
+    asm volatile("" : "+s"(pitch_bytes));
+    const f2 pmin = {A.lon_min, A.lat_min}, sc = {A.sx, A.sy};
+    auto to_index = [&](f2 v) { return (v - pmin) * sc; };  // subtract first: exact 0 at the grid origin
+    const float xlo = A.x_min, xhi = A.x_max;
+    auto x_needs_care = [&](float x) { return CYCLIC ? !(fabsf(x) < 180.0f) : !((x > xlo) & (x < xhi)); };
+    const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    const float kpred = 0.5f * (float)(K > 0 ? K - 1 : 0);
+    const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
+    const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 8u;
+    constexpr int NPASS = LT_ROWS / G::ROWS_PER_PASS;
+    constexpr int CENTRE = TILE_W / 2 + TILE_W * 7;  // seed 0 of the lane in the patch's 8th row: its middle
+    const f2 zero = {0.0f, 0.0f};
+    f2 dprev = {0.0f, 0.0f};
+#ifdef LCS_STAMPS
+    long long acc_t[5] = {0, 0, 0, 0, 0}, last_t = __builtin_amdgcn_s_memtime();
+#endif
+    for (int s = 0; s < A.nsteps; ++s) {
+        f2 c0[SPL];
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) c0[q] = to_index(p[q]);
+        // ---- 1. anchor the tile on the centre lane's predicted travel and issue its loads ------------
+        int ox = 0, oy = 0;
+        f4 stage[NPASS];
+        if (K > 0) {
+            const f2 ca = dprev * (1.0f + kpred) + c0[0];
+            const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
+            const int rym = __builtin_amdgcn_readlane((int)floor_to_uint(ca.y), CENTRE) + 1;  // row 7.5 of 16
+            ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
+            oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
+            const char *src = (const char *)elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)ox) * 8;
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r)
+                __builtin_memcpy(&stage[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_off, 16);
+        }
+        LCS_STAMP(0)  // anchor + tile load issue
+        // ---- 2. Euler samples (global gathers) ----------------------------------------------------
+        f2 e[SPL], pn[SPL];
+        bool bad[SPL], anybad = false;
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+            const TapL t = tap_of(c0[q]);
+            bad[q] = ((unsigned)t.x0 > (unsigned)(A.nx_f - 2)) | ((unsigned)t.y0 > (unsigned)(A.ny_f - 2));
+            e[q] = window_global<ORDER>(lvl, A, t, zero);
+            pn[q] = dd[q] * e[q] + p[q];
+            bad[q] |= x_needs_care(pn[q].x);
+            anybad |= bad[q];
+        }
+        if (anybad) {  // exact sequence for the lanes / seeds that need it
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                if (bad[q]) {
+                    const TapL t = tap_of(index_coords(A, p[q]));
+                    e[q] = window_global<ORDER>(lvl, A, t, zero);
+                    pn[q] = dd[q] * e[q] + p[q];
+                    clamp_position_p(A, pn[q], ymax_v);
+                }
+            }
+        }
+        dprev = (pn[0] - p[0]) * sc;  // Euler displacement in index space (predicts the next level's travel)
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) p[q] = pn[q];
+#ifdef LCS_STAMPS
+        asm volatile("" : : "v"(p[0].x), "v"(p[1].x));
+#endif
+        LCS_STAMP(1)  // Euler sample
+        // ---- 3. tile into LDS ------------------------------------------------------------------------
+        int lo_x = 0x40000000, lo_y = 0x40000000, lim_x = 0, lim_y = 0;  // no tile: nothing is "inside"
+        unsigned base_addr = tile_addr;
+        if (K > 0) {
+            __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r) *(f4 *)(tile + (r * G::ROWS_PER_PASS + st_row) * LT_PITCH + st_col) = stage[r];
+            __builtin_amdgcn_wave_barrier();
+            const int sox = ox - WOFF, soy = oy - WOFF;
+            const int hx = min(sox + LT_COLS - WIN, A.nx_f - 2), hy = min(soy + LT_ROWS - WIN, A.ny_f - 2);
+            const int lx = max(sox, 0), ly = max(soy, 0);
+            if (hx >= lx && hy >= ly) {
+                lo_x = lx;
+                lo_y = ly;
+                lim_x = hx - lx;
+                lim_y = hy - ly;
+                base_addr = tile_addr + (unsigned)(lx - sox) * 8u + (unsigned)(ly - soy) * ((unsigned)LT_PITCH * 8u);
+            }
+        }
+#ifdef LCS_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        LCS_STAMP(2)  // wait for the tile + LDS write
+        // ---- 4. K iterations out of LDS (latitude clamp deferred to the redo path / the level's end) -----
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            anybad = false;
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                const TapL t = tap_of(to_index(p[q]));
+                const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;
+                bad[q] = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
+                const f2 ew = window_lds<ORDER, LT_PITCH>(base_addr, pitch_bytes, rx, ry, t, e[q]);
+                pn[q] = hd[q] * ew + p[q];
+                bad[q] |= x_needs_care(pn[q].x);
+                anybad |= bad[q];
+            }
+            if (anybad) {
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) {
+                    if (bad[q]) {  // exact sequence, global gather
+                        f2 pc = p[q];
+                        pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
+                        const TapL t = tap_of(index_coords(A, pc));
+                        pn[q] = hd[q] * window_global<ORDER>(elv, A, t, e[q]) + pc;
+                        clamp_position_p(A, pn[q], ymax_v);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) p[q] = pn[q];
+        }
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+            p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);  // the level's one latitude clamp
+            if (live[q] && A.traj_x) {
+                A.traj_x[(size_t)(s + 1) * plane + idx[q]] = p[q].x;
+                A.traj_y[(size_t)(s + 1) * plane + idx[q]] = p[q].y;
+            }
+        }
+#ifdef LCS_STAMPS
+        asm volatile("" : : "v"(p[0].x), "v"(p[1].x));
+#endif
+        LCS_STAMP(3)  // K iterations
+        lvl += A.level_elems;
+        elv += A.level_elems;
+    }
+#ifdef LCS_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_stamps[i], (unsigned long long)acc_t[i]);
+#endif
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+        if (live[q]) {
+            A.x_out[idx[q]] = p[q].x;
+            A.y_out[idx[q]] = p[q].y;
+        }
+    }
+}
+
 template <typename T, int ORDER>
 struct LdsLaunch {
-    static const char *launch(const AdvectArgs<T> &, int, hipStream_t) { return nullptr; }
+    static const char *launch(const AdvectArgs<T> &, int, hipStream_t, int) { return nullptr; }
 };
 template <int ORDER>
 struct LdsLaunch<float, ORDER> {
     // returns the launched kernel's name, or NULL when the LDS kernel does not apply
-    static const char *launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
+    static const char *launch(const AdvectArgs<float> &A0, int grid, hipStream_t st, int mode) {
+        AdvectArgs<float> A = A0;
+        if (ORDER == 1 && mode != 2 && A.ext && A.K > 0 && A.nx_f + LC_PAD >= TileGeom<1>::COLS && A.ny_f + LC_PAD >= TileGeom<1>::ROWS) {
+            // two seeds per lane: a block covers 8 x 64 seeds
+            const int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
+            A.ntiles = A.ntx * nty;
+            const int g2 = ((A.ntiles + 7) / 8) * 8;
+            if (A.K == 4 && A.cyclic) {
+                hipLaunchKernelGGL((advect_lds2_kernel<4, true>), dim3(g2), dim3(BLOCK), 0, st, A);
+                return "advect_lds2_kernel<4, true>";
+            } else if (A.K == 4) {
+                hipLaunchKernelGGL((advect_lds2_kernel<4, false>), dim3(g2), dim3(BLOCK), 0, st, A);
+                return "advect_lds2_kernel<4, false>";
+            } else if (A.cyclic) {
+                hipLaunchKernelGGL((advect_lds2_kernel<-1, true>), dim3(g2), dim3(BLOCK), 0, st, A);
+                return "advect_lds2_kernel<-1, true>";
+            }
+            hipLaunchKernelGGL((advect_lds2_kernel<-1, false>), dim3(g2), dim3(BLOCK), 0, st, A);
+            return "advect_lds2_kernel<-1, false>";
+        }
         // the fixed-size tile must fit inside one padded time level
         if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return nullptr;
         // SETTLS_order = 0 (the library default): one Euler sample per level and nothing to stage a tile
@@ -1333,7 +1609,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         if (fused64) {
             hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
             name = "advect_kernel<double, 3, true>";
-        } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream)))) {
+        } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
             hipLaunchKernelGGL((advect_kernel<T, 3>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
             name = f64 ? "advect_kernel<double, 3, false>" : "advect_kernel<float, 3, false>";
         }
@@ -1341,7 +1617,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         if (fused64) {
             hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
             name = "advect_kernel<double, 1, true>";
-        } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream)))) {
+        } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
             hipLaunchKernelGGL((advect_kernel<T, 1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
             name = f64 ? "advect_kernel<double, 1, false>" : "advect_kernel<float, 1, false>";
         }
@@ -1422,6 +1698,17 @@ int sample_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int
 }
 
 }  // namespace
+
+#ifdef LCS_STAMPS
+extern "C" int lc_debug_read_stamps(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int lc_sample(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype, int nt, int ny_f,
                          int nx_f, double lat_min, double lat_max, double lon_min, double lon_max, int level,

@@ -41,7 +41,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     }
     c->stream = c->own_stream;
     c->lds_tiles = 1;
-    if (const char *ev = getenv("LCS_LDS_TILES")) c->lds_tiles = ev[0] == '0' ? 0 : 1;  // read once, here
+    if (const char *ev = getenv("LCS_LDS_TILES")) c->lds_tiles = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);  // read once, here
     c->last_advect_kernel = "";
     c->trunc = nullptr;
     *out = c;
@@ -50,7 +50,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
 
 extern "C" int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode) {
     LC_REQUIRE(ctx, "lc_ctx_set_lds_tiles: null context");
-    LC_REQUIRE(mode >= -1 && mode <= 1, "lc_ctx_set_lds_tiles: mode must be -1, 0 or 1");
+    LC_REQUIRE(mode >= -1 && mode <= 2, "lc_ctx_set_lds_tiles: mode must be -1, 0, 1 or 2");
     ctx->lds_tiles = mode < 0 ? 1 : mode;
     return LC_OK;
 }

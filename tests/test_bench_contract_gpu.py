@@ -34,7 +34,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm", "algorithmic_GBps", "csrc_hash"):
         assert k in rf, k
     # the fused LDS-tile kernel is bound by vector-ALU instruction throughput; the fraction is a physical one
-    assert rf["bound"] == "valu" and rf["kernel"] == "advect_lds_kernel<1, 4, true>"
+    assert rf["bound"] == "valu" and rf["kernel"] == "advect_lds2_kernel<4, true>"
     assert rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert 0 < rf["frac"] <= 1 and 0 < rf["hbm"]["compulsory_frac"] <= 1
     # no committed counter summary matches a miniature variant: replayed fields are null, never stale numbers

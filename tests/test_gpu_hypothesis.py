@@ -78,7 +78,7 @@ def test_float32_kernels_agree_with_each_other_and_the_oracle(fny, fnx, nt, K, o
     f = eng.prepare_field(u, v, lat, lon, order)
     out = {}
     try:
-        for flag in ("0", "1"):
+        for flag in ("0", "1", "2"):     # direct gathers, LDS tiles (two seeds per lane at order 1), LDS tiles one seed per lane
             eng.set_lds_tiles(int(flag))
             x, y = eng.advect(f, slat, slon, dt, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic,
                               noncyclic_clamp="pointwise")     # the fused kernels' own per-point clamp
@@ -105,6 +105,8 @@ def test_float32_kernels_agree_with_each_other_and_the_oracle(fny, fnx, nt, K, o
     assert np.percentile(dxk, 99) < 2e-4 and np.percentile(dyk, 99) < 2e-4 and dxk.max() < 0.1 and dyk.max() < 0.1
     # kernel vs float64 oracle: float32 distance (the 'order' seed rows at each end use the constant-mode
     # order-1 rule on both sides and are included)
+    # the two LDS-tile kernels and the direct kernel share one arithmetic: bit-identical
+    assert np.array_equal(out["1"][0], out["2"][0]) and np.array_equal(out["1"][1], out["2"][1])
     for flag in ("0", "1"):
         dx, dy = dist(out[flag][0], xo, cyclic)[ok], np.abs(out[flag][1] - yo)[ok]
         assert np.percentile(dx, 99) < 2e-3 and np.percentile(dy, 99) < 2e-3, (flag, dx.max(), dy.max())

@@ -16,10 +16,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         REP8(REP8(asm volatile(asm_line : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)) \
     }
 
-enum Op { FMA, PKFMA, PKMUL, PKADD, CVTFLR, FRACT, MED3, MADU24, CMP, ADD, MIXPK, LDSB64, LDSREAD2, NOPS };
+enum Op { FMA, PKFMA, PKMUL, PKADD, CVTFLR, FRACT, MED3, MADU24, CMP, ADD, MIXPK, NOPS, VS, VN, SALU, VS2, LDSB64, LDSREAD2 };
 
 template <int OP>
-__global__ void __launch_bounds__(256) k(float *out, long long *cyc, int iters) {
+__global__ void __launch_bounds__(256) k(float *out, long long *cyc, int iters, long long *rt) {
     __shared__ f2 lds[2048];
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a1, a0}, p3 = {a3, a2};
@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(256) k(float *out, long long *cyc, int iters) 
     lds[threadIdx.x + 256] = p1;
     __syncthreads();
     const unsigned la = (threadIdx.x & 63) * 8;
+    const long long r0 = __builtin_amdgcn_s_memrealtime();
     const long long t0 = __builtin_amdgcn_s_memtime();
     if (OP == FMA) {
         for (int it = 0; it < iters; ++it) {
@@ -90,6 +91,32 @@ __global__ void __launch_bounds__(256) k(float *out, long long *cyc, int iters) 
         for (int it = 0; it < iters; ++it) {
             REP8(REP8(asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));))
         }
+    } else if (OP == VS) {  // 4 VALU (4-cycle class) + 4 SALU interleaved
+        unsigned s0 = 1, s1 = 2, s2 = 3, s3 = 4;
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_fract_f32 %0, %0\n s_add_u32 %4, %4, 1\n v_fract_f32 %1, %1\n s_add_u32 %5, %5, 1\n v_fract_f32 %2, %2\n s_add_u32 %6, %6, 1\n v_fract_f32 %3, %3\n s_add_u32 %7, %7, 1"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");))
+        }
+        u0 += s0 + s1 + s2 + s3;
+    } else if (OP == VS2) {  // 4 VALU + 8 SALU
+        unsigned s0 = 1, s1 = 2, s2 = 3, s3 = 4;
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_fract_f32 %0, %0\n s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n v_fract_f32 %1, %1\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n v_fract_f32 %2, %2\n s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n v_fract_f32 %3, %3\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");))
+        }
+        u0 += s0 + s1 + s2 + s3;
+    } else if (OP == VN) {  // 4 VALU + 4 s_nop
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_fract_f32 %0, %0\n s_nop 0\n v_fract_f32 %1, %1\n s_nop 0\n v_fract_f32 %2, %2\n s_nop 0\n v_fract_f32 %3, %3\n s_nop 0"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));))
+        }
+    } else if (OP == SALU) {
+        unsigned s0 = 1, s1 = 2, s2 = 3, s3 = 4;
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1"
+                                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");))
+        }
+        u0 += s0 + s1 + s2 + s3;
     } else if (OP == LDSB64) {
         for (int it = 0; it < iters; ++it) {
             REP8(REP8(asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:8\n ds_read_b64 %2, %4 offset:512\n ds_read_b64 %3, %4 offset:520\n s_waitcnt lgkmcnt(0)"
@@ -102,58 +129,67 @@ __global__ void __launch_bounds__(256) k(float *out, long long *cyc, int iters) 
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
+    const long long r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y + p2.x + p3.y + (float)(u0 + u1 + u2 + u3);
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) {
+        cyc[blockIdx.x] = t1 - t0;
+        rt[blockIdx.x] = r1 - r0;
+    }
 }
 
 template <int OP>
 void run(const char *name, int per_body) {
     float *out;
-    long long *cyc;
+    long long *cyc, *rt;
     hipMalloc(&out, sizeof(float) * 256 * 256 * 8 * 4);
     hipMalloc(&cyc, sizeof(long long) * 256 * 8 * 4);
-    const int iters = 200;
+    hipMalloc(&rt, sizeof(long long) * 256 * 8 * 4);
+    const int iters = OP >= LDSB64 ? 2000 : 8000;
     printf("%-10s", name);
     for (int wps : {1, 2, 4, 8}) {
-        const int blocks = 256 * wps;  // 256-thread blocks = 4 waves, one per SIMD
+        const int blocks = 256 * wps;  // 256-thread blocks = 4 waves, one per SIMD; all resident at once
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
         hipEventCreate(&e1);
-        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 100, rt);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters, rt);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        std::vector<long long> h(blocks);
+        std::vector<long long> h(blocks), hr(blocks);
         hipMemcpy(h.data(), cyc, sizeof(long long) * blocks, hipMemcpyDeviceToHost);
-        double avg = 0;
-        for (long long v : h) avg += (double)v;
+        hipMemcpy(hr.data(), rt, sizeof(long long) * blocks, hipMemcpyDeviceToHost);
+        double avg = 0, clk = 0;
+        for (int i = 0; i < blocks; ++i) {
+            avg += (double)h[i];
+            clk += (double)h[i] / (double)hr[i] * 0.1;  // GHz: memtime ticks per 100 MHz memrealtime tick
+        }
         avg /= blocks;
+        clk /= blocks;
         const double n_inst = (double)iters * 64 * per_body;  // per wave
-        // in-kernel cycles per instruction per wave, times waves sharing the SIMD
-        printf("  W=%d: %.2f cyc/inst/wave (%.2f SIMD-cyc/inst, %.3f ms)", wps, avg / n_inst, avg / n_inst / wps, ms);
+        // SIMD cycles per wave-instruction: (in-kernel cycles of one wave) / (instructions of the W waves sharing its SIMD)
+        printf("  W=%d: %.2f SIMD-cyc/inst (clock %.2f GHz, %.2f ms; wall-based %.2f)", wps, avg / n_inst / wps, clk, ms,
+               ms * 1e-3 * clk * 1e9 / n_inst / wps);
     }
     printf("\n");
     hipFree(out);
     hipFree(cyc);
+    hipFree(rt);
 }
 
 int main() {
     run<FMA>("v_fma", 4);
-    run<ADD>("v_add", 4);
     run<PKFMA>("v_pk_fma", 4);
-    run<PKMUL>("v_pk_mul", 4);
-    run<PKADD>("v_pk_add", 4);
-    run<MIXPK>("pk+plain", 4);
     run<CVTFLR>("cvt_flr", 4);
     run<FRACT>("v_fract", 4);
-    run<MED3>("v_med3", 4);
-    run<MADU24>("mad_u24", 4);
-    run<CMP>("v_cmp", 4);
     run<NOPS>("s_nop", 4);
+    run<SALU>("s_add", 4);
+    run<VS>("4v+4s", 4);    // per_body counts the VALU instructions only: compare with v_fract
+    run<VS2>("4v+8s", 4);
+    run<VN>("4v+4nop", 4);
     run<LDSB64>("ds_b64x4", 4);
     run<LDSREAD2>("ds_rd2x2", 2);
     return 0;
