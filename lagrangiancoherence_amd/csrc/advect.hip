@@ -1085,9 +1085,15 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     constexpr int ORDER = 1;
     const int K = KFIX >= 0 ? KFIX : A.K;
     typedef TileGeom<ORDER> G;
-    constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
+    constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS;
+    // LDS tile of 16-byte entries {u, v, u[x+1] - u, v[x+1] - v}: the x-differences of the two lerps are formed
+    // ONCE per node when the tile is staged (2 packed subtractions + one more 8-byte load per lane and level) instead of
+    // once per sample (2 per sample and seed), and a window is two 16-byte reads instead of four 8-byte ones.
+    // Same values as n00 + tx * (n01 - n00): results stay bit-identical to the other float kernels.
+    // Pitch 20 entries: rows shift 16 banks, no conflicts between neighbouring rows for ds_read_b128.
+    constexpr int LT_PITCH = LT_COLS + 4;
     constexpr int WIN = 2, WOFF = LC_PAD_LO;
-    __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
+    __shared__ __attribute__((aligned(16))) f4 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
     const int per_xcd = (A.ntiles + 7) / 8;
     const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile_id >= A.ntiles) return;  // whole block
@@ -1095,7 +1101,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ix = txi * TILE_W + (lane % TILE_W);
     const int iy0 = tyi * (TILE_H * SPL) + wave * (8 * SPL) + lane / TILE_W;  // seed q sits 8 rows further down
-    f2 *tile = s_tiles[wave];
+    f4 *tile = s_tiles[wave];
 
     bool live[SPL];
     f2 p[SPL], dd[SPL], hd[SPL];
@@ -1130,7 +1136,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     float ymax_v = A.y_max;
     asm volatile("" : "+v"(ymax_v));
     const unsigned tile_addr = lds_address(tile);
-    unsigned pitch_bytes = (unsigned)LT_PITCH * 8u;
+    unsigned pitch_bytes = (unsigned)LT_PITCH * 16u;
     asm volatile("" : "+s"(pitch_bytes));
     const f2 pmin = {A.lon_min, A.lat_min}, sc = {A.sx, A.sy};
     auto to_index = [&](f2 v) { return (v - pmin) * sc; };  // subtract first: exact 0 at the grid origin
@@ -1143,6 +1149,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
     const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 8u;
     constexpr int NPASS = LT_ROWS / G::ROWS_PER_PASS;
+    // node c+2 of the lane's tile row (the x-difference of node c+1 needs it): loaded with the tile, 8 more bytes
+    // per lane; the last lane of a row re-reads its own node instead (its entry c+1 is never a window origin)
+    const unsigned st_next = st_off + (st_col + 2 < LT_COLS ? 16u : 0u);
     constexpr int CENTRE = TILE_W / 2 + TILE_W * 7;  // seed 0 of the lane in the patch's 8th row: its middle
     const f2 zero = {0.0f, 0.0f};
     f2 dprev = {0.0f, 0.0f};
@@ -1156,6 +1165,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
         // ---- 1. anchor the tile on the centre lane's predicted travel and issue its loads ------------
         int ox = 0, oy = 0;
         f4 stage[NPASS];
+        f2 stage_next[NPASS];
         if (K > 0) {
             const f2 ca = dprev * (1.0f + kpred) + c0[0];
             const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
@@ -1164,8 +1174,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
             oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
             const char *src = (const char *)elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)ox) * 8;
 #pragma unroll
-            for (int r = 0; r < NPASS; ++r)
+            for (int r = 0; r < NPASS; ++r) {
                 __builtin_memcpy(&stage[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_off, 16);
+                __builtin_memcpy(&stage_next[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_next, 8);
+            }
         }
         LCS_STAMP(0)  // anchor + tile load issue
         // ---- 2. Euler samples (global gathers) ----------------------------------------------------
@@ -1204,7 +1216,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
         if (K > 0) {
             __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
 #pragma unroll
-            for (int r = 0; r < NPASS; ++r) *(f4 *)(tile + (r * G::ROWS_PER_PASS + st_row) * LT_PITCH + st_col) = stage[r];
+            for (int r = 0; r < NPASS; ++r) {
+                // this lane holds nodes (c, c+1) of a tile row and node c+2 in stage_next (loaded, not shuffled: two
+                // cross-lane moves of the .x and .y of one register pair -- v_mov_b32_dpp or ds_bpermute alike -- came
+                // out of hipcc 7.2 as ONE move feeding both halves; seen in the ISA and in wrong results)
+                const f2 nxt = stage_next[r];
+                f4 *dst = tile + (r * G::ROWS_PER_PASS + st_row) * LT_PITCH + st_col;
+                const f2 n0 = stage[r].xy, n1 = stage[r].zw, d0 = n1 - n0, d1 = nxt - n1;
+                dst[0] = (f4){n0.x, n0.y, d0.x, d0.y};
+                dst[1] = (f4){n1.x, n1.y, d1.x, d1.y};
+            }
             __builtin_amdgcn_wave_barrier();
             const int sox = ox - WOFF, soy = oy - WOFF;
             const int hx = min(sox + LT_COLS - WIN, A.nx_f - 2), hy = min(soy + LT_ROWS - WIN, A.ny_f - 2);
@@ -1214,7 +1235,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
                 lo_y = ly;
                 lim_x = hx - lx;
                 lim_y = hy - ly;
-                base_addr = tile_addr + (unsigned)(lx - sox) * 8u + (unsigned)(ly - soy) * ((unsigned)LT_PITCH * 8u);
+                base_addr = tile_addr + (unsigned)(lx - sox) * 16u + (unsigned)(ly - soy) * ((unsigned)LT_PITCH * 16u);
             }
         }
 #ifdef LCS_STAMPS
@@ -1230,7 +1251,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
                 const TapL t = tap_of(to_index(p[q]));
                 const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;
                 bad[q] = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
-                const f2 ew = window_lds<ORDER, LT_PITCH>(base_addr, pitch_bytes, rx, ry, t, e[q]);
+                unsigned row_addr;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(base_addr));
+                typedef __attribute__((address_space(3))) const f4 lds_f4;
+                lds_f4 *cell = (lds_f4 *)(size_t)(row_addr + ((unsigned)rx << 4));
+                const f4 c0 = cell[0], c1 = cell[LT_PITCH];
+                const f2 r0 = c0.xy + t.tx * c0.zw;   // n00 + tx (n01 - n00)
+                const f2 r1 = c1.xy + t.tx * c1.zw;   // n10 + tx (n11 - n10)
+                const f2 ew = e[q] + (r0 + t.ty * (r1 - r0));  // e + sample of ext[t]
                 pn[q] = hd[q] * ew + p[q];
                 bad[q] |= x_needs_care(pn[q].x);
                 anybad |= bad[q];

@@ -5,7 +5,7 @@
     python tools/isa_hist.py advect.s 'advect_lds_kernelILi1ELi4ELb1E' [--json out.json]
 
 The walk starts at the kernel's outermost hot loop header (--loop LABEL, default: the depth-1 loop with the
-most instructions between header and back edge) and
+most LDS reads, else the longest) and
 follows the path a wave takes when no lane needs a rare-case redo: `s_cbranch_execz` is taken (the
 exec-masked block is skipped), `s_cbranch_execnz` falls through, `s_branch` is followed, and a uniform
 branch (`vccz/vccnz/scc0/scc1`) takes the side given with --take LABEL (default: fall through; every such
@@ -43,9 +43,9 @@ def kernel_lines(path, key):
             on = True
             continue
         if on:
-            out.append(ln.rstrip("\n"))
-            if "s_endpgm" in ln:
+            if ln.startswith(".Lfunc_end"):   # (a kernel may hold several s_endpgm: early exits)
                 break
+            out.append(ln.rstrip("\n"))
     if not out:
         raise SystemExit(f"kernel matching {key!r} not found in {path}")
     return out
@@ -84,9 +84,11 @@ def main():
     headers = [m.group(1) for ln in lines for m in [re.match(r"^(\.LBB\w+):.*This Loop Header: Depth=1", ln)] if m]
     if not headers:
         raise SystemExit("no depth-1 loop found")
-    if loop is None:
+    if loop is None:   # the loop with the most LDS reads (the tile kernels' hot loop), else the longest
         pos = sorted(label_at[h] for h in headers) + [len(insts)]
-        loop = max(headers, key=lambda h: pos[pos.index(label_at[h]) + 1] - label_at[h])
+        ext = {h: (label_at[h], pos[pos.index(label_at[h]) + 1]) for h in headers}
+        nds = {h: sum(1 for k in range(*ext[h]) if insts[k][1].startswith("ds_read")) for h in headers}
+        loop = max(headers, key=lambda h: (nds[h], ext[h][1] - ext[h][0]))
     header, start = loop, label_at[loop]
     pc = start
     hist = collections.Counter()
