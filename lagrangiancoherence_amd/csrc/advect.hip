@@ -1373,8 +1373,8 @@ struct InteriorPath<float, ORDER, FUSED> {
 
 // double, order 1 sits at 69 VGPRs (7 waves per SIMD); asking for 8 costs nothing measurable per wave and
 // lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
-template <typename T, int ORDER, bool FUSED = false>
-__global__ void __launch_bounds__(BLOCK, (sizeof(T) == 8 && ORDER == 1) ? 8 : 1) advect_kernel(const AdvectArgs<T> A) {
+template <typename T, int ORDER, bool FUSED>
+__device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A) {
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give
     // XCD k the k-th contiguous eighth of the tile list -- its L2 then serves one latitude band.
     const int per_xcd = (A.ntiles + 7) / 8;
@@ -1392,6 +1392,37 @@ __global__ void __launch_bounds__(BLOCK, (sizeof(T) == 8 && ORDER == 1) ? 8 : 1)
         InteriorPath<T, ORDER, FUSED>::run(A, iy, ix);
 }
 
+// double, order 1 sits at 69 VGPRs (7 waves per SIMD); asking for 8 costs nothing measurable per wave and
+// lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
+template <typename T, int ORDER, bool FUSED = false>
+__global__ void __launch_bounds__(BLOCK, (sizeof(T) == 8 && ORDER == 1) ? 8 : 1) advect_kernel(const AdvectArgs<T> A) {
+    advect_kernel_body<T, ORDER, FUSED>(A);
+}
+
+// float: 98 SGPRs as compiled would admit 6 workgroups per CU instead of 7 (MI355X_MICROARCH.md: 97-112 -> 6);
+// capped at 96 (K = 0 on C3: 2.5 -> 2.2 ms).  (The attribute takes no template-dependent value: own kernel.)
+template <int ORDER>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) advect_kernel_f32(const AdvectArgs<float> A) {
+    advect_kernel_body<float, ORDER, false>(A);
+}
+
+template <typename T, int ORDER>
+struct DirectLaunch {
+    static const char *launch(const AdvectArgs<T> &A, int grid, hipStream_t st) {
+        hipLaunchKernelGGL((advect_kernel<T, ORDER>), dim3(grid), dim3(BLOCK), 0, st, A);
+        return ORDER == 1 ? "advect_kernel<double, 1, false>" : ORDER == 2 ? "advect_kernel<double, 2, false>"
+             : ORDER == 3 ? "advect_kernel<double, 3, false>" : ORDER == 4 ? "advect_kernel<double, 4, false>"
+                                                                           : "advect_kernel<double, 5, false>";
+    }
+};
+template <int ORDER>
+struct DirectLaunch<float, ORDER> {
+    static const char *launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
+        hipLaunchKernelGGL((advect_kernel_f32<ORDER>), dim3(grid), dim3(BLOCK), 0, st, A);
+        return ORDER == 1 ? "advect_kernel_f32<1>" : ORDER == 2 ? "advect_kernel_f32<2>" : ORDER == 3 ? "advect_kernel_f32<3>"
+             : ORDER == 4 ? "advect_kernel_f32<4>" : "advect_kernel_f32<5>";
+    }
+};
 
 // ======================================================================================
 // LC_X_CLAMP_REFERENCE_OUTER -- the reference's non-cyclic longitude clamp, as written (Q9):
@@ -1626,28 +1657,23 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // lc_ctx_set_lds_tiles / LCS_LDS_TILES (read once at context creation) override (profiling).
     const bool use_lds = ctx->lds_tiles != 0;
     const bool fused64 = sizeof(T) == 8 && A.ext != nullptr;  // opt-in single-sample iterations in float64
-    const bool f64 = sizeof(T) == 8;
     const char *name = nullptr;
     if (order == 2 || order == 4 || order == 5) {  // generic direct kernel, any dtype
-        if (order == 2) hipLaunchKernelGGL((advect_kernel<T, 2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-        if (order == 4) hipLaunchKernelGGL((advect_kernel<T, 4>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-        if (order == 5) hipLaunchKernelGGL((advect_kernel<T, 5>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-        name = order == 2 ? "advect_kernel<T, 2, false>" : order == 4 ? "advect_kernel<T, 4, false>" : "advect_kernel<T, 5, false>";
+        name = order == 2 ? DirectLaunch<T, 2>::launch(A, grid, ctx->stream)
+             : order == 4 ? DirectLaunch<T, 4>::launch(A, grid, ctx->stream) : DirectLaunch<T, 5>::launch(A, grid, ctx->stream);
     } else if (order == 3) {
         if (fused64) {
             hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
             name = "advect_kernel<double, 3, true>";
         } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
-            hipLaunchKernelGGL((advect_kernel<T, 3>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-            name = f64 ? "advect_kernel<double, 3, false>" : "advect_kernel<float, 3, false>";
+            name = DirectLaunch<T, 3>::launch(A, grid, ctx->stream);
         }
     } else {
         if (fused64) {
             hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
             name = "advect_kernel<double, 1, true>";
         } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
-            hipLaunchKernelGGL((advect_kernel<T, 1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-            name = f64 ? "advect_kernel<double, 1, false>" : "advect_kernel<float, 1, false>";
+            name = DirectLaunch<T, 1>::launch(A, grid, ctx->stream);
         }
     }
     ctx->last_advect_kernel = name;

@@ -48,9 +48,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 def test_bench_direct_kernel_is_named_as_such():
     d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--settls", "0", "--no-cpu-baseline")
-    assert d["roofline"]["kernel"] == "advect_kernel<float, 1, false>" and d["roofline"]["bound"] == "tcp"
+    assert d["roofline"]["kernel"] == "advect_kernel_f32<1>" and d["roofline"]["bound"] == "tcp"
     d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--no-cpu-baseline", env={"LCS_LDS_TILES": "0"})
-    assert d["roofline"]["kernel"] == "advect_kernel<float, 1, false>"
+    assert d["roofline"]["kernel"] == "advect_kernel_f32<1>"
 
 
 @pytest.mark.parametrize("wk,extra,units", [
