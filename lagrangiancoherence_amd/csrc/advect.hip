@@ -1085,7 +1085,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     constexpr int ORDER = 1;
     const int K = KFIX >= 0 ? KFIX : A.K;
     typedef TileGeom<ORDER> G;
-    constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS;
+#ifndef LCS_LDS2_ROWS
+#define LCS_LDS2_ROWS 8
+#endif
+    constexpr int LT_COLS = G::COLS, LT_ROWS = LCS_LDS2_ROWS;
     // LDS tile of 16-byte entries {u, v, u[x+1] - u, v[x+1] - v}: the x-differences of the two lerps are formed
     // ONCE per node when the tile is staged (2 packed subtractions + one more 8-byte load per lane and level) instead of
     // once per sample (2 per sample and seed), and a window is two 16-byte reads instead of four 8-byte ones.
@@ -1315,7 +1318,7 @@ struct LdsLaunch<float, ORDER> {
     // returns the launched kernel's name, or NULL when the LDS kernel does not apply
     static const char *launch(const AdvectArgs<float> &A0, int grid, hipStream_t st, int mode) {
         AdvectArgs<float> A = A0;
-        if (ORDER == 1 && mode != 2 && A.ext && A.K > 0 && A.nx_f + LC_PAD >= TileGeom<1>::COLS && A.ny_f + LC_PAD >= TileGeom<1>::ROWS) {
+        if (ORDER == 1 && mode != 2 && A.ext && A.K > 0 && A.nx_f + LC_PAD >= TileGeom<1>::COLS && A.ny_f + LC_PAD >= 16) {
             // two seeds per lane: a block covers 8 x 64 seeds
             const int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
             A.ntiles = A.ntx * nty;

@@ -100,11 +100,19 @@ __device__ void prefilter_line(T *c, size_t stride, int n) {
 
 // Same recursion, marching in blocks of 8 elements whose loads are issued together: the march
 // is a dependent chain per line, so memory latency (not bandwidth) is what must be overlapped.
+// ``src`` / ``sstride``: where the causal pass READS the line (the raw field, so that the interleave and the
+// latitude sweep are one pass over the data); NULL = in place.
 template <typename T>
-__device__ void prefilter_line_blocked(T *c, size_t stride, int n) {
+__device__ void prefilter_line_blocked(T *c, size_t stride, int n, const T *src = nullptr, size_t sstride = 0) {
     constexpr int B = 8;
     const double z = -0.26794919243112270647, gain = 6.0;
+    if (!src) {
+        src = c;
+        sstride = stride;
+    }
     if (n < 2 * B) {
+        if (src != c)
+            for (int i = 0; i < n; ++i) c[(size_t)i * stride] = src[(size_t)i * sstride];
         prefilter_line<T>(c, stride, n);
         return;
     }
@@ -114,8 +122,8 @@ __device__ void prefilter_line_blocked(T *c, size_t stride, int n) {
     constexpr int HORIZON = 64;
     const bool mirrored = n < HORIZON;
     const double zn1 = mirrored ? pow(z, (double)(n - 1)) : 0.0;
-    double c0 = gain * (double)c[0];
-    if (mirrored) c0 += zn1 * (gain * (double)c[(size_t)(n - 1) * stride]);
+    double c0 = gain * (double)src[0];
+    if (mirrored) c0 += zn1 * (gain * (double)src[(size_t)(n - 1) * sstride]);
     double zi = z;
     const int last = mirrored ? n - 1 : HORIZON;  // direct terms i = 1 .. last-1
     for (int i0 = 1; i0 < last; i0 += B) {
@@ -123,8 +131,8 @@ __device__ void prefilter_line_blocked(T *c, size_t stride, int n) {
 #pragma unroll
         for (int q = 0; q < B; ++q) {
             const int i = min(i0 + q, n - 2);
-            a[q] = (double)c[(size_t)i * stride];
-            b[q] = mirrored ? (double)c[(size_t)(n - 1 - i) * stride] : 0.0;
+            a[q] = (double)src[(size_t)i * sstride];
+            b[q] = mirrored ? (double)src[(size_t)(n - 1 - i) * sstride] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < B; ++q) {
@@ -140,7 +148,7 @@ __device__ void prefilter_line_blocked(T *c, size_t stride, int n) {
     for (int i0 = 1; i0 < n; i0 += B) {
         double a[B];
 #pragma unroll
-        for (int q = 0; q < B; ++q) a[q] = (double)c[(size_t)min(i0 + q, n - 1) * stride];
+        for (int q = 0; q < B; ++q) a[q] = (double)src[(size_t)min(i0 + q, n - 1) * sstride];
 #pragma unroll
         for (int q = 0; q < B; ++q) {
             if (i0 + q < n) {
@@ -245,8 +253,11 @@ __global__ void prefilter_general_kernel(T *__restrict__ packed, int nt, int ny,
 
 // axis 0 (latitude): one thread per (level, column, component); consecutive
 // threads touch consecutive elements, so every step of the march is coalesced.
+// The causal pass reads the RAW field (u / v planes) and writes the interleaved image: the separate interleave
+// pass (pack_interior_kernel, one write + one read of the whole image) is folded into the sweep.
 template <typename T>
-__global__ void prefilter_cols_kernel(T *__restrict__ packed, int nt, int ny, int nx) {
+__global__ void prefilter_cols_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ packed, int nt, int ny,
+                                      int nx) {
     const int pitch = nx + LC_PAD;
     const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
     const size_t lines = (size_t)nt * nx * 2;
@@ -255,7 +266,8 @@ __global__ void prefilter_cols_kernel(T *__restrict__ packed, int nt, int ny, in
     const size_t t = i / ((size_t)nx * 2);
     const size_t xc = i - t * (size_t)nx * 2;  // x*2 + component
     T *c = packed + t * level + ((size_t)LC_PAD_LO * pitch + LC_PAD_LO) * 2 + xc;
-    prefilter_line_blocked<T>(c, (size_t)pitch * 2, ny);
+    const T *src = ((xc & 1) ? v : u) + t * (size_t)ny * nx + (xc >> 1);
+    prefilter_line_blocked<T>(c, (size_t)pitch * 2, ny, src, (size_t)nx);
 }
 
 // axis 1 (longitude): one thread per (level, row, component).
@@ -401,6 +413,34 @@ __global__ void pack_fused_kernel(const T *__restrict__ u, const T *__restrict__
     }
 }
 
+// Pads of img and the whole of ext = 2*img[t] - img[t+1] in one pass over the padded levels: every padded node
+// reads its mirrored interior source at levels t and t+1 (interior nodes are final by now), writes its own pad
+// of img[t] if it is one, and its node of ext[t].  Replaces fill_pads_kernel + extrapolate_kernel.
+template <typename T>
+__global__ void pads_ext_kernel(T *__restrict__ img, T *__restrict__ ext, int nt, int ny, int nx) {
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch;
+    const size_t total = level * nt;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / level;
+        const size_t r = i - t * level;
+        const int py = (int)(r / pitch), px = (int)(r - (size_t)py * pitch);
+        const int y = py - LC_PAD_LO, x = px - LC_PAD_LO;
+        const bool pad = !(y >= 0 && y < ny && x >= 0 && x < nx);
+        const int sy = mirror_index(y, ny), sx = mirror_index(x, nx);
+        const size_t sidx = (t * level + (size_t)(sy + LC_PAD_LO) * pitch + (sx + LC_PAD_LO)) * 2;
+        const T a = img[sidx], b = img[sidx + 1];
+        if (pad) {
+            img[2 * i] = a;
+            img[2 * i + 1] = b;
+        }
+        if (t + 1 < (size_t)nt) {
+            ext[2 * i] = T(2) * a - img[sidx + level * 2];
+            ext[2 * i + 1] = T(2) * b - img[sidx + level * 2 + 1];
+        }
+    }
+}
+
 // ext[t] = 2*img[t] - img[t+1] over whole padded levels (linear, so pads stay mirrored)
 template <typename T>
 __global__ void extrapolate_kernel(const T *__restrict__ img, T *__restrict__ ext, size_t level_elems, size_t total) {
@@ -419,13 +459,12 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
         return LC_OK;
     }
     const int blocks = (int)((nodes + threads - 1) / threads < 8192 ? (nodes + threads - 1) / threads : 8192);
-    hipLaunchKernelGGL(pack_interior_kernel<T>, dim3(blocks), dim3(threads), 0, ctx->stream, u, v, packed, ny, nx,
-                       nodes);
     if (order == 3) {
-        // scipy filters axis 0 first, then axis 1 (spline_filter loops over axes in order)
+        // scipy filters axis 0 first, then axis 1 (spline_filter loops over axes in order); the latitude sweep
+        // reads the raw field and writes the interleaved image
         size_t lines = (size_t)nt * nx * 2;
         hipLaunchKernelGGL(prefilter_cols_kernel<T>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
-                           ctx->stream, packed, nt, ny, nx);
+                           ctx->stream, u, v, packed, nt, ny, nx);
         if (nx >= PR_CHUNK) {
             hipLaunchKernelGGL(prefilter_rows_lds_kernel<T>, dim3((ny + PR_ROWS - 1) / PR_ROWS, nt), dim3(64), 0,
                                ctx->stream, packed, ny, nx);
@@ -434,8 +473,9 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
             hipLaunchKernelGGL(prefilter_rows_kernel<T>, dim3((unsigned)((lines + 63) / 64)), dim3(64), 0,
                                ctx->stream, packed, nt, ny, nx);
         }
-    }
-    if (order == 2 || order == 4 || order == 5) {  // scipy filters axis 0 first, then axis 1
+    } else {  // orders 2, 4, 5: generic pole lists, thread per line
+        hipLaunchKernelGGL(pack_interior_kernel<T>, dim3(blocks), dim3(threads), 0, ctx->stream, u, v, packed, ny, nx,
+                           nodes);
         const PoleList P = spline_poles(order);
         const size_t l0 = (size_t)nt * nx * 2, l1 = (size_t)nt * ny * 2;
         hipLaunchKernelGGL(prefilter_general_kernel<T>, dim3((unsigned)((l0 + 63) / 64)), dim3(64), 0, ctx->stream, packed, nt,
@@ -443,12 +483,10 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
         hipLaunchKernelGGL(prefilter_general_kernel<T>, dim3((unsigned)((l1 + 63) / 64)), dim3(64), 0, ctx->stream, packed, nt,
                            ny, nx, 1, P);
     }
-    hipLaunchKernelGGL(fill_pads_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
-    if (ext && nt >= 2) {
-        const size_t le = lc_level_elems(ny, nx), total = le * (size_t)(nt - 1);
-        hipLaunchKernelGGL(extrapolate_kernel<T>, dim3(8192), dim3(256), 0, ctx->stream, (const T *)packed, ext, le,
-                           total);
-    }
+    if (ext && nt >= 2)   // pads + fused-level image in one pass
+        hipLaunchKernelGGL(pads_ext_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
+    else
+        hipLaunchKernelGGL(fill_pads_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }

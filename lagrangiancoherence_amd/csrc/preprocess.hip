@@ -429,6 +429,10 @@ extern "C" int lc_spectral_truncate(lc_ctx *ctx, const void *f_dev, int dtype, i
                      truncation, nlat, nlon);
         return truncation > 31 ? LC_EUNSUPPORTED : LC_EINVAL;
     }
+    if ((size_t)DFT_ROWS * nlon * sizeof(double) > 64 * 1024) {  // the forward DFT stages DFT_ROWS field rows in LDS
+        lc_set_error("lc_spectral_truncate: %d longitudes exceed this build's limit of %d", nlon, 64 * 1024 / (DFT_ROWS * 8));
+        return LC_EUNSUPPORTED;
+    }
     LC_HIP_CHECK(hipSetDevice(ctx->device));
     const int s = ensure_operators(ctx, nlat, nlon, truncation);
     if (s != LC_OK) return s;
