@@ -1241,6 +1241,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
                 base_addr = tile_addr + (unsigned)(lx - sox) * 16u + (unsigned)(ly - soy) * ((unsigned)LT_PITCH * 16u);
             }
         }
+        // per-level constants of the float window arithmetic (wave-uniform)
+        const f2 lo_f = {(float)lo_x, (float)lo_y};
+        const unsigned lim_bits_x = __float_as_uint((float)lim_x), lim_bits_y = __float_as_uint((float)lim_y);
+        const float base_f = (float)base_addr, pitch_f = (float)(LT_PITCH * 16);
+        (void)lo_f; (void)lim_bits_x; (void)lim_bits_y; (void)base_f; (void)pitch_f;
 #ifdef LCS_STAMPS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -1251,13 +1256,39 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
             anybad = false;
 #pragma unroll
             for (int q = 0; q < SPL; ++q) {
+                typedef __attribute__((address_space(3))) const f4 lds_f4;
+#ifndef LCS_LDS2_FLOAT_ADDR
                 const TapL t = tap_of(to_index(p[q]));
                 const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;
                 bad[q] = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
                 unsigned row_addr;
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(base_addr));
-                typedef __attribute__((address_space(3))) const f4 lds_f4;
                 lds_f4 *cell = (lds_f4 *)(size_t)(row_addr + ((unsigned)rx << 4));
+#else
+                // MEASURED AND NOT KEPT (-DLCS_LDS2_FLOAT_ADDR; bit-identical results, 7.21-7.29 ms against 7.17-7.18): on
+                // paper 8 cycles per sample cheaper, but hipcc adds two v_mov per sample to pair the fractions and
+                // 23 more hazard s_nop per level, which eat the gain.
+                // Window index and LDS address in FLOAT arithmetic: on gfx950 v_add / v_mul / v_fma_f32 issue in 2.25
+                // SIMD cycles, everything else (conversions, integer ops, compares, packed ops) in 4.13, so
+                //   floor(c) - lo = (c - lo) - fract(c)      two packed subtractions for both axes, EXACT (c, lo, fract(c)
+                //                                            are multiples of ulp(c); the result is a small integer)
+                //   address = base + ry * pitch + rx * 16    two plain fmas on small integers (exact) + ONE conversion
+                // replace 2 floor-conversions, 2 integer subtractions, a 24-bit mad and a shift-add.  The fractions are
+                // fract() of the ABSOLUTE coordinate, as in every other float kernel: same bits, wherever the tile sits.
+                // The range test is an unsigned compare on the float's bits (negative, NaN and too large all fail).
+                f2 c = to_index(p[q]);
+                asm volatile("" : "+v"(c));  // c must be the ROUNDED coordinate in both uses below: no fma(d, s, -lo)
+                f2 fr;
+                fr.x = __builtin_amdgcn_fractf(c.x);
+                fr.y = __builtin_amdgcn_fractf(c.y);
+                const f2 rf = (c - lo_f) - fr;
+                bad[q] = (unsigned)(__float_as_uint(rf.x) > lim_bits_x) | (unsigned)(__float_as_uint(rf.y) > lim_bits_y);
+                struct { float tx, ty; } t = {fr.x, fr.y};
+                const float addr_f = __builtin_fmaf(rf.y, pitch_f, __builtin_fmaf(rf.x, 16.0f, base_f));
+                unsigned cell_addr;
+                asm("v_cvt_u32_f32 %0, %1" : "=v"(cell_addr) : "v"(addr_f));  // negative / NaN -> 0, too large saturates: LDS reads cannot fault
+                lds_f4 *cell = (lds_f4 *)(size_t)cell_addr;
+#endif
                 const f4 c0 = cell[0], c1 = cell[LT_PITCH];
                 const f2 r0 = c0.xy + t.tx * c0.zw;   // n00 + tx (n01 - n00)
                 const f2 r1 = c1.xy + t.tx * c1.zw;   // n10 + tx (n11 - n10)

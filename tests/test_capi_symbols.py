@@ -95,3 +95,24 @@ def test_common_grid_is_numpy_linspace(lib):
     lat, lon = np.empty(360), np.empty(721)
     lib.lc_common_grid(None, None, lat.ctypes.data_as(C.c_void_p), lon.ctypes.data_as(C.c_void_p))
     assert np.array_equal(lat, np.linspace(-89.75, 89.75, 180 * 2)) and np.array_equal(lon, np.linspace(-180, 179.5, 360 * 2 + 1))
+
+
+def test_new_entry_points_validate_before_touching_a_device(lib):
+    import ctypes as C
+    assert lib.lc_regrid_common_grid(None, None, 0, 1, 2, 2, None, None, None, 1, None, 1, None) == _capi.LC_EINVAL
+    assert lib.lc_spectral_truncate(None, None, 0, 1, 8, 16, 4, None) == _capi.LC_EINVAL
+    assert lib.lc_lcs_global_host(None, None, None, 0, 2, 4, 4, None, None, 1, 20, -900.0, 4, 3, 0.0, 1, 0,
+                                  None, None, None) == _capi.LC_EINVAL
+    assert b"null context" in lib.lc_last_error()
+
+
+def test_x_boundary_mode_defaults():
+    """cyclic_xboundary=False means the reference's own outer-product clamp (Q9) whenever the call covers the whole
+    seed grid; a row-sharded call falls back to the per-point clamp; explicit choices are honoured."""
+    from lagrangiancoherence_amd.engine import x_boundary_mode
+    assert x_boundary_mode(True) == _capi.LC_X_CYCLIC == 1
+    assert x_boundary_mode(False) == _capi.LC_X_CLAMP_REFERENCE_OUTER == 2
+    assert x_boundary_mode(False, whole_grid=False) == _capi.LC_X_CLAMP_POINT == 0
+    assert x_boundary_mode(False, "pointwise") == 0 and x_boundary_mode(False, "reference_outer", whole_grid=False) == 2
+    with pytest.raises(ValueError):
+        x_boundary_mode(False, "nearest")
