@@ -64,20 +64,28 @@ def test_bench_c4_c5_workloads(wk, extra, units):
     assert d["config"]["workload"].startswith("variant of BASELINE configs[%d]" % (3 if wk == "c4" else 4))
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_two_ranks_rehearsal_carries_a_halo_check(scaling):
+@pytest.mark.parametrize("wk,extra,units,scaling", [
+    ("c3", ["--scaling", "weak", "--seeds", "256", "--nt", "5"], 512 * 256 * 4, "weak"),
+    ("c3", ["--scaling", "strong", "--seeds", "256", "--nt", "5"], 256 * 256 * 4, "strong"),
+    ("c4", ["--seeds", "512", "--nt", "9"], 512 * 512 * 8, "strong"),
+    ("c5", ["--seeds", "256", "--nt", "14", "--members", "4"], 4 * 256 * 256 * 10, "strong"),
+])
+def test_bench_two_ranks_rehearsal_carries_a_halo_check(wk, extra, units, scaling):
     """N=2 over gloo with both ranks on GPU 0 (RCCL refuses two ranks on one device): the JSON line carries
-    halo_check, and the exchanged rows equal the redundantly advected ones bit for bit."""
+    halo_check for the row-sharded workloads, and the exchanged rows equal the redundantly advected ones bit for
+    bit; the ensemble workload shards members and exchanges nothing."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    d = _bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--seeds", "256", "--nt", "5", "--scaling", scaling,
+    d = _bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", wk, *extra,
                launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                          "127.0.0.1", "--master-port", str(port)),
                env={"LCS_BENCH_BACKEND": "gloo", "LCS_BENCH_ONE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == scaling
-    hc = d["halo_check"]
-    assert hc["timed_path"] == "torch.distributed" and hc["timed_path_ok"] is True
-    rows = 512 if scaling == "weak" else 256
-    assert abs(d["value"] - rows * 256 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+    if wk == "c5":
+        assert "halo_check" not in d
+    else:
+        hc = d["halo_check"]
+        assert hc["timed_path"] == "torch.distributed" and hc["timed_path_ok"] is True
+    assert abs(d["value"] - units / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
