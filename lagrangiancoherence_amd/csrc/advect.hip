@@ -1061,6 +1061,19 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
 // ======================================================================================
 constexpr int SPL = 2;  // seeds per lane
 
+// Tile geometry of the two-seed kernel (nodes).  Measured (advect ms on C3 / on C5's 64 members): 16x8 7.15 / 462,
+// 16x16 7.44 / 477, 32x8 7.85 / 495, 32x16 - / 479.  C5 (seeds half as dense, 200 steps) is slower per particle
+// whatever the tile: its patches are pulled apart by the flow over the longer integration, not merely too wide.
+#ifndef LCS_LDS2_ROWS
+#define LCS_LDS2_ROWS 8
+#endif
+#ifndef LCS_LDS2_COLS
+#define LCS_LDS2_COLS 16
+#endif
+struct Lds2Geom {  // staging: a tile row = COLS/2 lanes x 16 bytes
+    static constexpr int COLS = LCS_LDS2_COLS, LANES_PER_ROW = COLS / 2, ROWS_PER_PASS = 64 / LANES_PER_ROW;
+};
+
 #ifdef LCS_STAMPS  // diagnostic build only: where a wave's cycles go (s_memtime), summed over waves and levels
 __device__ unsigned long long g_stamps[8];
 #define LCS_STAMP(i)                                           \
@@ -1084,10 +1097,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
 #pragma clang fp contract(fast)
     constexpr int ORDER = 1;
     const int K = KFIX >= 0 ? KFIX : A.K;
-    typedef TileGeom<ORDER> G;
-#ifndef LCS_LDS2_ROWS
-#define LCS_LDS2_ROWS 8
-#endif
+    typedef Lds2Geom G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = LCS_LDS2_ROWS;
     // LDS tile of 16-byte entries {u, v, u[x+1] - u, v[x+1] - v}: the x-differences of the two lerps are formed
     // ONCE per node when the tile is staged (2 packed subtractions + one more 8-byte load per lane and level) instead of
@@ -1349,7 +1359,7 @@ struct LdsLaunch<float, ORDER> {
     // returns the launched kernel's name, or NULL when the LDS kernel does not apply
     static const char *launch(const AdvectArgs<float> &A0, int grid, hipStream_t st, int mode) {
         AdvectArgs<float> A = A0;
-        if (ORDER == 1 && mode != 2 && A.ext && A.K > 0 && A.nx_f + LC_PAD >= TileGeom<1>::COLS && A.ny_f + LC_PAD >= 16) {
+        if (ORDER == 1 && mode != 2 && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16) {
             // two seeds per lane: a block covers 8 x 64 seeds
             const int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
             A.ntiles = A.ntx * nty;
