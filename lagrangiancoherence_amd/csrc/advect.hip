@@ -1062,7 +1062,10 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
 constexpr int SPL = 2;  // seeds per lane
 
 // Tile geometry of the two-seed kernel (nodes).  Measured (advect ms on C3 / on C5's 64 members): 16x8 7.15 / 462,
-// 16x16 7.44 / 477, 32x8 7.85 / 495, 32x16 - / 479.  C5 (seeds half as dense, 200 steps) is slower per particle
+// 16x16 7.44 / 477, 32x8 7.85 / 495, 32x16 - / 479.  Where the windows leave the tile (-DLCS_STAMPS counters, C3):
+// 2.3 % of the seed-samples in x, 4.6 % in y, evenly above and below -- patches the flow has deformed; a 16-row
+// tile brings y down to 1.5 % and the wave-samples with a redo from 19 % to 11 %, but its second staging pass
+// costs what the redos saved (7.19 against 7.04 ms).  C5 (seeds half as dense, 200 steps) is slower per particle
 // whatever the tile: its patches are pulled apart by the flow over the longer integration, not merely too wide.
 #ifndef LCS_LDS2_ROWS
 #define LCS_LDS2_ROWS 8
@@ -1076,6 +1079,8 @@ struct Lds2Geom {  // staging: a tile row = COLS/2 lanes x 16 bytes
 
 #ifdef LCS_STAMPS  // diagnostic build only: where a wave's cycles go (s_memtime), summed over waves and levels
 __device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_cause[4];  // seed-samples outside the tile in x, in y, of those below (x < lo), (y < lo)
+__device__ unsigned long long g_redo[3][3][3];  // [latitude band 0-30 / 30-60 / 60-90][third of the levels][samples, with redo, seeds redone]
 #define LCS_STAMP(i)                                           \
     {                                                          \
         const long long _t = __builtin_amdgcn_s_memtime();     \
@@ -1170,6 +1175,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     f2 dprev = {0.0f, 0.0f};
 #ifdef LCS_STAMPS
     long long acc_t[5] = {0, 0, 0, 0, 0}, last_t = __builtin_amdgcn_s_memtime();
+    unsigned long long acc_n[3] = {0, 0, 0};
 #endif
     for (int s = 0; s < A.nsteps; ++s) {
         f2 c0[SPL];
@@ -1182,7 +1188,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
         if (K > 0) {
             const f2 ca = dprev * (1.0f + kpred) + c0[0];
             const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
-            const int rym = __builtin_amdgcn_readlane((int)floor_to_uint(ca.y), CENTRE) + 1;  // row 7.5 of 16
+            // (the patch's middle lies 0.09 cells above this lane on C3: no shift.  A tile anchored one row higher
+            // measured 23 % instead of 19 % of wave-samples with a redo, 7.19 against 7.04 ms)
+            const int rym = __builtin_amdgcn_readlane((int)floor_to_uint(ca.y), CENTRE);
             ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
             oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
             const char *src = (const char *)elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)ox) * 8;
@@ -1271,6 +1279,18 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
                 const TapL t = tap_of(to_index(p[q]));
                 const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;
                 bad[q] = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
+#ifdef LCS_STAMPS
+                {
+                    const unsigned long long bx = __ballot((unsigned)rx > (unsigned)lim_x), by = __ballot((unsigned)ry > (unsigned)lim_y);
+                    const unsigned long long bxl = __ballot(rx < 0), byl = __ballot(ry < 0);
+                    if (lane == 0) {
+                        atomicAdd(&g_cause[0], (unsigned long long)__popcll(bx));
+                        atomicAdd(&g_cause[1], (unsigned long long)__popcll(by));
+                        atomicAdd(&g_cause[2], (unsigned long long)__popcll(bxl));
+                        atomicAdd(&g_cause[3], (unsigned long long)__popcll(byl));
+                    }
+                }
+#endif
                 unsigned row_addr;
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(base_addr));
                 lds_f4 *cell = (lds_f4 *)(size_t)(row_addr + ((unsigned)rx << 4));
@@ -1307,6 +1327,20 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
                 bad[q] |= x_needs_care(pn[q].x);
                 anybad |= bad[q];
             }
+#ifdef LCS_STAMPS
+            {   // g_stamps[4]: wave-samples, [5]: wave-samples with a redo, [6]: lane-seed-samples redone
+                const unsigned long long m0 = __ballot(bad[0]), m1 = __ballot(bad[1]);
+                if (lane == 0) {
+                    acc_n[0] += 1;
+                    acc_n[1] += (m0 | m1) ? 1 : 0;
+                    acc_n[2] += __popcll(m0) + __popcll(m1);
+                    const int band = min(2, (int)(fabsf(A.seed_lat[min(iy0, A.ny - 1)]) / 30.0f)), third = min(2, 3 * s / A.nsteps);
+                    atomicAdd(&g_redo[band][third][0], 1ull);
+                    atomicAdd(&g_redo[band][third][1], (m0 | m1) ? 1ull : 0ull);
+                    atomicAdd(&g_redo[band][third][2], (unsigned long long)(__popcll(m0) + __popcll(m1)));
+                }
+            }
+#endif
             if (anybad) {
 #pragma unroll
                 for (int q = 0; q < SPL; ++q) {
@@ -1338,8 +1372,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
         elv += A.level_elems;
     }
 #ifdef LCS_STAMPS
-    if (lane == 0)
+    if (lane == 0) {
         for (int i = 0; i < 4; ++i) atomicAdd(&g_stamps[i], (unsigned long long)acc_t[i]);
+        for (int i = 0; i < 3; ++i) atomicAdd(&g_stamps[4 + i], acc_n[i]);
+    }
 #endif
 #pragma unroll
     for (int q = 0; q < SPL; ++q) {
@@ -1798,6 +1834,22 @@ int sample_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int
 }  // namespace
 
 #ifdef LCS_STAMPS
+extern "C" int lc_debug_read_cause(unsigned long long *out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_cause), sizeof(g_cause)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[4] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_cause), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+extern "C" int lc_debug_read_redo(unsigned long long *out27, int reset) {
+    if (hipMemcpyFromSymbol(out27, HIP_SYMBOL(g_redo), sizeof(g_redo)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[27] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_redo), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int lc_debug_read_stamps(unsigned long long *out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
     if (reset) {
