@@ -16,7 +16,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         REP8(REP8(asm volatile(asm_line : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)) \
     }
 
-enum Op { FMA, PKFMA, PKMUL, PKADD, CVTFLR, FRACT, MED3, MADU24, CMP, ADD, MIXPK, NOPS, VS, VN, SALU, VS2, LDSB64, LDSREAD2 };
+enum Op { FMA, PKFMA, PKMUL, PKADD, CVTFLR, FRACT, MED3, MADU24, CMP, ADD, MIXPK, NOPS, VS, VN, SALU, VS2, LDSB64, LDSREAD2, FMA64, MUL64, ADD64, RCP64, FLOOR64, CVTI64, DIVSC64, DIVFIX64, CNDMASK };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(float *out, long long *cyc, int iters, long long *rt) {
@@ -128,9 +128,37 @@ __global__ void __launch_bounds__(256) k(float *out, long long *cyc, int iters, 
                                    : "+v"(*(float __attribute__((ext_vector_type(4))) *)&p0), "+v"(*(float __attribute__((ext_vector_type(4))) *)&p2) : "v"(la));))
         }
     }
+    double d0 = threadIdx.x, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3;
+    const double db = 1.0001, dc = 0.5;
+#define D64(line)                                                                                            \
+    for (int it = 0; it < iters; ++it) {                                                                     \
+        REP8(REP8(asm volatile(line : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));))          \
+    }
+    if (OP == FMA64) {
+        D64("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5")
+    } else if (OP == MUL64) {
+        D64("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4")
+    } else if (OP == ADD64) {
+        D64("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4")
+    } else if (OP == RCP64) {
+        D64("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3")
+    } else if (OP == FLOOR64) {
+        D64("v_floor_f64 %0, %0\n v_floor_f64 %1, %1\n v_floor_f64 %2, %2\n v_floor_f64 %3, %3")
+    } else if (OP == CVTI64) {
+        for (int it = 0; it < iters; ++it) {
+            REP8(REP8(asm volatile("v_cvt_i32_f64 %0, %4\n v_cvt_i32_f64 %1, %5\n v_cvt_i32_f64 %2, %4\n v_cvt_i32_f64 %3, %5"
+                                   : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(db), "v"(dc));))
+        }
+    } else if (OP == DIVSC64) {
+        D64("v_div_scale_f64 %0, vcc, %0, %4, %5\n v_div_scale_f64 %1, vcc, %1, %4, %5\n v_div_scale_f64 %2, vcc, %2, %4, %5\n v_div_scale_f64 %3, vcc, %3, %4, %5")
+    } else if (OP == DIVFIX64) {
+        D64("v_div_fixup_f64 %0, %0, %4, %5\n v_div_fixup_f64 %1, %1, %4, %5\n v_div_fixup_f64 %2, %2, %4, %5\n v_div_fixup_f64 %3, %3, %4, %5")
+    } else if (OP == CNDMASK) {
+        BODY("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc")
+    }
     const long long t1 = __builtin_amdgcn_s_memtime();
     const long long r1 = __builtin_amdgcn_s_memrealtime();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y + p2.x + p3.y + (float)(u0 + u1 + u2 + u3);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(d0 + d1 + d2 + d3) + a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y + p2.x + p3.y + (float)(u0 + u1 + u2 + u3);
     if (threadIdx.x == 0) {
         cyc[blockIdx.x] = t1 - t0;
         rt[blockIdx.x] = r1 - r0;
@@ -144,7 +172,7 @@ void run(const char *name, int per_body) {
     hipMalloc(&out, sizeof(float) * 256 * 256 * 8 * 4);
     hipMalloc(&cyc, sizeof(long long) * 256 * 8 * 4);
     hipMalloc(&rt, sizeof(long long) * 256 * 8 * 4);
-    const int iters = OP >= LDSB64 ? 2000 : 8000;
+    const int iters = OP >= LDSB64 ? 2000 : 8000;  // (the float64 cases share the short count)
     printf("%-10s", name);
     for (int wps : {1, 2, 4, 8}) {
         const int blocks = 256 * wps;  // 256-thread blocks = 4 waves, one per SIMD; all resident at once
@@ -192,5 +220,14 @@ int main() {
     run<VN>("4v+4nop", 4);
     run<LDSB64>("ds_b64x4", 4);
     run<LDSREAD2>("ds_rd2x2", 2);
+    run<FMA64>("v_fma_f64", 4);
+    run<MUL64>("v_mul_f64", 4);
+    run<ADD64>("v_add_f64", 4);
+    run<RCP64>("v_rcp_f64", 4);
+    run<FLOOR64>("v_floor64", 4);
+    run<CVTI64>("cvt_i32f64", 4);
+    run<DIVSC64>("divscale64", 4);
+    run<DIVFIX64>("divfixup64", 4);
+    run<CNDMASK>("v_cndmask", 4);
     return 0;
 }
