@@ -467,9 +467,11 @@ def main():
                                 s_p, s_f, True, comp, wl, csrc),
                      "measured_copy_peak_GBps": copy_gbps},
         "roofline_sigma": {
-            "bound": "hbm", "kernel": "sigma_kernel_f32", "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
+            "bound": "hbm", "kernel": eng.last_sigma_kernel(), "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": sigma_gbps / copy_gbps,
             "algorithmic_bytes_per_cell": 3 * s_p,
+            "note": "SURVEY 8d's bound (read x_dep, y_dep, write sigma); the kernel itself is limited by the VALU work of "
+                    "two sincos + stencils + two square roots per cell (DESIGN 4)",
         },
     }
     if halo_check is not None:

@@ -28,7 +28,9 @@ PROTOTYPES = {
     "lc_ctx_use_own_stream": (_i, [_vp]),
     "lc_sync": (_i, [_vp]),
     "lc_ctx_set_lds_tiles": (_i, [_vp, _i]),
+    "lc_ctx_set_sigma_march": (_i, [_vp, _i]),
     "lc_ctx_last_advect_kernel": (C.c_char_p, [_vp]),
+    "lc_ctx_last_sigma_kernel": (C.c_char_p, [_vp]),
     "lc_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "lc_free": (_i, [_vp, _vp]),
     "lc_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),

@@ -42,7 +42,10 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->stream = c->own_stream;
     c->lds_tiles = 1;
     if (const char *ev = getenv("LCS_LDS_TILES")) c->lds_tiles = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);  // read once, here
+    c->sigma_march = 1;
+    if (const char *ev = getenv("LCS_SIGMA_MARCH")) c->sigma_march = ev[0] != '0';  // read once, here
     c->last_advect_kernel = "";
+    c->last_sigma_kernel = "";
     c->trunc = nullptr;
     *out = c;
     return LC_OK;
@@ -55,7 +58,15 @@ extern "C" int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode) {
     return LC_OK;
 }
 
+extern "C" int lc_ctx_set_sigma_march(lc_ctx *ctx, int on) {
+    LC_REQUIRE(ctx, "lc_ctx_set_sigma_march: null context");
+    LC_REQUIRE(on >= -1 && on <= 1, "lc_ctx_set_sigma_march: on must be -1, 0 or 1");
+    ctx->sigma_march = on != 0;
+    return LC_OK;
+}
+
 extern "C" const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_advect_kernel : ""; }
+extern "C" const char *lc_ctx_last_sigma_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_sigma_kernel : ""; }
 
 extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
     if (!ctx) return LC_OK;

@@ -146,14 +146,13 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel(const SigmaArgs<T> A) {
 // 64x32 0.105, 128x16 0.112, 64x16 0.0905, 64x12 0.096, 32x32 0.094, 32x16 0.101, 128x8 0.099, 64x8 0.108 --
 // occupancy (LDS per workgroup) matters more than halo redundancy.
 // ======================================================================================
+#ifndef LCS_SIGMA_MROWS
+#define LCS_SIGMA_MROWS 20
+#endif
 constexpr int FW = 64, FH = 16;
 constexpr int FLW = FW + 2 * HALO, FLH = FH + 2 * HALO;
 
-__device__ __forceinline__ void fast_sincosf(float a, float *sn, float *cs) {
-    if (!(fabsf(a) < 64.0f)) {  // out of the bounded range (or NaN): library path
-        sincosf(a, sn, cs);
-        return;
-    }
+__device__ __forceinline__ void bounded_sincosf(float a, float *sn, float *cs) {  // |a| < 64
     const float n = rintf(a * 0.636619772367581343f);  // 2/pi
     float r = fmaf(n, -1.5703125f, a);
     r = fmaf(n, -4.837512969970703125e-4f, r);
@@ -163,11 +162,74 @@ __device__ __forceinline__ void fast_sincosf(float a, float *sn, float *cs) {
     const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
                           z * z, fmaf(-0.5f, z, 1.0f));
     const int q = (int)n;
-    const float s1 = (q & 1) ? cp : sp, c1 = (q & 1) ? sp : cp;
-    *sn = (q & 2) ? -s1 : s1;
-    *cs = ((q + 1) & 2) ? -c1 : c1;
+    const bool odd = q & 1;  // odd quadrant: sine and cosine swap
+    const unsigned s1 = __builtin_bit_cast(unsigned, odd ? cp : sp), c1 = __builtin_bit_cast(unsigned, odd ? sp : cp);
+    // signs as bit operations: sine flips in quadrants 2, 3 (bit 1 of q), cosine in quadrants 1, 2 (bit 1 of q + 1)
+    *sn = __builtin_bit_cast(float, s1 ^ (((unsigned)q << 30) & 0x80000000u));
+    *cs = __builtin_bit_cast(float, c1 ^ (((unsigned)(q + 1) << 30) & 0x80000000u));
 }
 
+// X, Y, Z of one departure point (LCS.py:195-199), float
+__device__ __forceinline__ void sphere_xyz_f32(float xd, float yd, float &vx, float &vy, float &vz) {
+#pragma clang fp contract(off)
+    const float D2R = 3.141592653589793f / 180.0f;
+    const float R = 6371000.0f;
+    const float lon = xd * D2R;            // LCS.py:195
+    const float lat = (yd - 90.0f) * D2R;  // LCS.py:196
+    float sl, cl, so, co;
+    if (fabsf(lat) < 64.0f && fabsf(lon) < 64.0f) {
+        bounded_sincosf(lat, &sl, &cl);
+        bounded_sincosf(lon, &so, &co);
+    } else {  // out of the polynomial's range, or NaN: library path
+        sincosf(lat, &sl, &cl);
+        sincosf(lon, &so, &co);
+    }
+    const float rs = R * sl;
+    vx = rs * co;  // LCS.py:197
+    vy = rs * so;  // LCS.py:198
+    vz = R * cl;   // LCS.py:199
+}
+
+// 1 / dx of a seed row (tools.py:254-255), float
+__device__ __forceinline__ float inv_dx_f32(float seed_lat, float dlon) {
+#pragma clang fp contract(off)
+    const float latr = (seed_lat * 3.141592653589793f) / 180.0f;                           // tools.py:254
+    return 1.0f / ((((3.141592653589793f / 180.0f) * dlon) * 6371000.0f) * cosf(latr));  // tools.py:255
+}
+
+// the two stencils with the 4th-order weights folded: (4/3)/2 and -(1/3)/4 of tools.py:204-207
+__device__ __forceinline__ float centred_f32(float p1, float m1, float p2, float m2) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(2.0f / 3.0f, p1 - m1, (-1.0f / 12.0f) * (p2 - m2));
+}
+__device__ __forceinline__ float ddy_f32(int gy, int ny_global, float m2, float m1, float c0, float p1, float p2) {
+#pragma clang fp contract(off)
+    if (gy < 2) return 0.5f * (p1 - c0);              // tools.py:210-213
+    if (gy >= ny_global - 2) return 0.5f * (c0 - m1);  // tools.py:214-217
+    return centred_f32(p1, m1, p2, m2);
+}
+
+// largest singular value from the six derivatives (closed-form 2x2 Gram eigenvalue), float
+__device__ __forceinline__ float sigma_from_derivatives_f32(int layout, float a_, float b_, float c_, float d_, float e_,
+                                                            float f_) {
+#pragma clang fp contract(off)
+    float p, q, r;
+    if (layout == LC_LAYOUT_REFERENCE) {  // LCS.py:153 (Q13)
+        p = __builtin_fmaf(c_, c_, __builtin_fmaf(b_, b_, a_ * a_));
+        q = __builtin_fmaf(f_, f_, __builtin_fmaf(e_, e_, d_ * d_));
+        r = __builtin_fmaf(c_, f_, __builtin_fmaf(b_, e_, a_ * d_));
+    } else {
+        p = __builtin_fmaf(e_, e_, __builtin_fmaf(c_, c_, a_ * a_));
+        q = __builtin_fmaf(f_, f_, __builtin_fmaf(d_, d_, b_ * b_));
+        r = __builtin_fmaf(e_, f_, __builtin_fmaf(c_, d_, a_ * b_));
+    }
+    const float dpq = p - q;
+    // v_sqrt_f32 (1 ulp) instead of the correctly rounded expansion: 14 fewer instructions per root
+    const float disc = __builtin_amdgcn_sqrtf(__builtin_fmaf(dpq, dpq, (4.0f * r) * r));
+    return __builtin_amdgcn_sqrtf(0.5f * ((p + q) + disc));
+}
+
+// general float kernel (any width, any alignment): X, Y, Z of a 64 x 16 tile + halo through LDS
 __global__ void __launch_bounds__(SBLOCK) sigma_kernel_f32(const SigmaArgs<float> A) {
     __shared__ float sX[FLH][FLW + 1];
     __shared__ float sY[FLH][FLW + 1];
@@ -177,17 +239,10 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel_f32(const SigmaArgs<float
     const int tyi = blockIdx.x / ntx, txi = blockIdx.x - tyi * ntx;
     const int gy0 = A.out_row0 + tyi * FH;
     const int gx0 = txi * FW;
-    const float D2R = 3.141592653589793f / 180.0f;
-    const float R = 6371000.0f;
 
     if (threadIdx.x < FH) {
         const int gy = gy0 + (int)threadIdx.x;
-        float v = 0.0f;
-        if (gy < A.out_row0 + A.n_out_rows) {
-            const float latr = (A.seed_lat[gy - A.in_row0] * 3.141592653589793f) / 180.0f;  // tools.py:254
-            v = 1.0f / ((((3.141592653589793f / 180.0f) * A.dlon) * R) * cosf(latr));      // tools.py:255
-        }
-        s_inv_dx[threadIdx.x] = v;
+        s_inv_dx[threadIdx.x] = gy < A.out_row0 + A.n_out_rows ? inv_dx_f32(A.seed_lat[gy - A.in_row0], A.dlon) : 0.0f;
     }
     for (int i = threadIdx.x; i < FLW * FLH; i += SBLOCK) {
         const int ly = i / FLW, lx = i - ly * FLW;
@@ -202,15 +257,7 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel_f32(const SigmaArgs<float
         float vx = 0.0f, vy = 0.0f, vz = 0.0f;
         if (gy >= 0 && gy < A.ny_global && ry >= 0 && ry < A.n_in_rows) {
             const size_t o = (size_t)ry * A.nx + gx;
-            const float lon = A.x_dep[o] * D2R;             // LCS.py:195
-            const float lat = (A.y_dep[o] - 90.0f) * D2R;   // LCS.py:196
-            float sl, cl, so, co;
-            fast_sincosf(lat, &sl, &cl);
-            fast_sincosf(lon, &so, &co);
-            const float rs = R * sl;
-            vx = rs * co;  // LCS.py:197
-            vy = rs * so;  // LCS.py:198
-            vz = R * cl;   // LCS.py:199
+            sphere_xyz_f32(A.x_dep[o], A.y_dep[o], vx, vy, vz);
         }
         sX[ly][lx] = vx;
         sY[ly][lx] = vy;
@@ -218,8 +265,7 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel_f32(const SigmaArgs<float
     }
     __syncthreads();
 
-    const float inv_dy = 1.0f / (((3.141592653589793f / 180.0f) * A.dlat) * R);  // tools.py:256
-    const float W1 = 2.0f / 3.0f, W2 = -1.0f / 12.0f;  // (4/3)/2 and -(1/3)/4 of tools.py:204-207
+    const float inv_dy = 1.0f / (((3.141592653589793f / 180.0f) * A.dlat) * 6371000.0f);  // tools.py:256
     for (int i = threadIdx.x; i < FW * FH; i += SBLOCK) {
         const int oy = i / FW, ox = i - oy * FW;
         const int gy = gy0 + oy, gx = gx0 + ox;
@@ -227,33 +273,119 @@ __global__ void __launch_bounds__(SBLOCK) sigma_kernel_f32(const SigmaArgs<float
         const int ly = oy + HALO, lx = ox + HALO;
         const float inv_dx = s_inv_dx[oy];
         auto ddx = [&](float(*a)[FLW + 1]) -> float {
-            return fmaf(W1, a[ly][lx + 1] - a[ly][lx - 1], W2 * (a[ly][lx + 2] - a[ly][lx - 2])) * inv_dx;
+            return centred_f32(a[ly][lx + 1], a[ly][lx - 1], a[ly][lx + 2], a[ly][lx - 2]) * inv_dx;
         };
         auto ddy = [&](float(*a)[FLW + 1]) -> float {
-            float d;
-            if (gy < 2)
-                d = 0.5f * (a[ly + 1][lx] - a[ly][lx]);  // tools.py:210-213
-            else if (gy >= A.ny_global - 2)
-                d = 0.5f * (a[ly][lx] - a[ly - 1][lx]);  // tools.py:214-217
-            else
-                d = fmaf(W1, a[ly + 1][lx] - a[ly - 1][lx], W2 * (a[ly + 2][lx] - a[ly - 2][lx]));
-            return d * inv_dy;
+            return ddy_f32(gy, A.ny_global, a[ly - 2][lx], a[ly - 1][lx], a[ly][lx], a[ly + 1][lx], a[ly + 2][lx]) * inv_dy;
         };
         const float a_ = ddx(sX), b_ = ddy(sX), c_ = ddx(sY), d_ = ddy(sY), e_ = ddx(sZ), f_ = ddy(sZ);
-        const size_t oidx = (size_t)(gy - A.out_row0) * A.nx + gx;
-        float p, q, r;
-        if (A.layout == LC_LAYOUT_REFERENCE) {  // LCS.py:153 (Q13)
-            p = a_ * a_ + b_ * b_ + c_ * c_;
-            q = d_ * d_ + e_ * e_ + f_ * f_;
-            r = a_ * d_ + b_ * e_ + c_ * f_;
-        } else {
-            p = a_ * a_ + c_ * c_ + e_ * e_;
-            q = b_ * b_ + d_ * d_ + f_ * f_;
-            r = a_ * b_ + c_ * d_ + e_ * f_;
+        A.sigma[(size_t)(gy - A.out_row0) * A.nx + gx] = sigma_from_derivatives_f32(A.layout, a_, b_, c_, d_, e_, f_);
+    }
+}
+
+// ======================================================================================
+// float, sigma only, even width: the marching kernel.  A WAVE owns a span of 128 columns (two per lane, one 8-byte
+// load per field and row) and walks down MROWS output rows with the X, Y, Z of five rows in registers: d/dy comes
+// from the registers, d/dx from the two neighbouring lanes by wavefront shuffle (`ds_bpermute_b32`: 12 per row, no
+// LDS memory, no barrier).  Lanes 0 and 63 are halo lanes (124 columns written per wave), rows -2..+2 around the
+// strip are loaded as halo: the sincos work per output cell is 1.03 x (1 + 4/MROWS) instead of the LDS tile's 1.33.
+// Five rows of loads are in flight per wave (a register ring indexed like the window).  Same arithmetic as sigma_kernel_f32, bit for bit.
+// ======================================================================================
+#ifndef LCS_SIGMA_MBLOCK
+#define LCS_SIGMA_MBLOCK 256
+#endif
+constexpr int MBLOCK = LCS_SIGMA_MBLOCK;  // threads per workgroup of the marching kernel (waves are independent)
+constexpr int MCOLS = 2;                 // columns per lane
+constexpr int MSPAN_OUT = 62 * MCOLS;    // columns written per wave
+
+template <int MROWS, int LAYOUT>
+__global__ void __launch_bounds__(MBLOCK) sigma_march_kernel_f32(const SigmaArgs<float> A, int nspans, int nstrips) {
+    static_assert(MROWS <= 64, "row metrics live one per lane");
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (MBLOCK / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
+    const int strip = w / nspans, span = w - strip * nspans;
+    if (strip >= nstrips) return;
+    const int gy0 = A.out_row0 + strip * MROWS;
+    const int nrows = min(MROWS, A.out_row0 + A.n_out_rows - gy0);
+    const int col = span * MSPAN_OUT + (lane - 1) * MCOLS;
+    const bool writes = lane >= 1 && lane <= 62 && col < A.nx;
+    int c = col < 0 ? col + A.nx : col;  // cyclic column of this lane's pair (tools.py:225-228); nx is even
+    if (c >= A.nx) {
+        c -= A.nx;
+        if (c >= A.nx) c %= A.nx;
+    }
+    const int from_prev = ((lane + 63) & 63) * 4, from_next = ((lane + 1) & 63) * 4;  // bpermute byte addresses
+    // 1/dx of this strip's rows, one per lane, broadcast by readlane in the loop
+    float my_inv_dx = 0.0f;
+    if (lane < nrows) my_inv_dx = inv_dx_f32(A.seed_lat[gy0 + lane - A.in_row0], A.dlon);
+    const float inv_dy = 1.0f / (((3.141592653589793f / 180.0f) * A.dlat) * 6371000.0f);  // tools.py:256
+
+    auto row_ok = [&](int gy) {  // wave-uniform
+        const int ry = gy - A.in_row0;
+        return gy >= 0 && gy < A.ny_global && ry >= 0 && ry < A.n_in_rows;
+    };
+    auto load_row = [&](int gy, float2 &xd, float2 &yd) {  // always issued (a row outside the window reads the nearest
+        const int ry = min(max(gy - A.in_row0, 0), A.n_in_rows - 1);  // one and is zeroed below): no branch around loads
+        const float *px = A.x_dep + (size_t)ry * A.nx, *py = A.y_dep + (size_t)ry * A.nx;
+        xd = *reinterpret_cast<const float2 *>(px + c);
+        yd = *reinterpret_cast<const float2 *>(py + c);
+    };
+    auto shuf = [&](int addr, float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+    };
+    float X[5][MCOLS], Y[5][MCOLS], Z[5][MCOLS];  // rows gy-2 .. gy+2; slot = (row - first row) mod 5
+    float2 RX[5], RY[5];                          // the next five rows as loaded: five rows of loads in flight per wave
+    const int base = gy0 - 2;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        load_row(base + j, RX[j], RY[j]);
+    }
+    // rows enter in slot order, so with the loop unrolled by five every register index below is static and the
+    // compiler counts the loads in flight itself (vmcnt)
+    for (int o = 0; o * 5 - 4 < nrows; ++o) {
+#pragma unroll
+        for (int S4 = 0; S4 < 5; ++S4) {         // S4: slot of the entering row
+            const int i = o * 5 + S4 - 4;        // output row gy0 + i once rows up to gy0 + i + 2 are in
+            if (i < nrows) {                     // wave-uniform
+                const int S0 = (S4 + 1) % 5, S1 = (S4 + 2) % 5, S2 = (S4 + 3) % 5, S3 = (S4 + 4) % 5;
+                const int gyn = gy0 + i + 2;     // the row entering the window
+                const float2 cx = RX[S4], cy = RY[S4];
+                load_row(gyn + 5, RX[S4], RY[S4]);  // its ring slot goes to the row five further down
+                if (row_ok(gyn)) {
+                    sphere_xyz_f32(cx.x, cy.x, X[S4][0], Y[S4][0], Z[S4][0]);
+                    sphere_xyz_f32(cx.y, cy.y, X[S4][1], Y[S4][1], Z[S4][1]);
+                } else {
+                    X[S4][0] = X[S4][1] = Y[S4][0] = Y[S4][1] = Z[S4][0] = Z[S4][1] = 0.0f;
+                }
+                if (i >= 0) {
+                    const int gy = gy0 + i;
+                    const float inv_dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_inv_dx), i));
+                    const bool edge = gy < 2 || gy >= A.ny_global - 2;  // one-sided rows (Q12): wave-uniform, rare
+                    float dxs[3][MCOLS], dys[3][MCOLS];
+                    auto field = [&](float (&F)[5][MCOLS], int n) {
+                        const float pk0 = shuf(from_prev, F[S2][0]), pk1 = shuf(from_prev, F[S2][1]);
+                        const float nk0 = shuf(from_next, F[S2][0]), nk1 = shuf(from_next, F[S2][1]);
+                        dxs[n][0] = centred_f32(F[S2][1], pk1, nk0, pk0) * inv_dx;
+                        dxs[n][1] = centred_f32(nk0, F[S2][0], nk1, pk1) * inv_dx;
+#pragma unroll
+                        for (int k = 0; k < MCOLS; ++k) {
+                            float d = centred_f32(F[S3][k], F[S1][k], F[S4][k], F[S0][k]);
+                            if (edge) d = ddy_f32(gy, A.ny_global, F[S0][k], F[S1][k], F[S2][k], F[S3][k], F[S4][k]);
+                            dys[n][k] = d * inv_dy;
+                        }
+                    };
+                    field(X, 0);
+                    field(Y, 1);
+                    field(Z, 2);
+                    float sig[MCOLS];
+#pragma unroll
+                    for (int k = 0; k < MCOLS; ++k)
+                        sig[k] = sigma_from_derivatives_f32(LAYOUT, dxs[0][k], dys[0][k], dxs[1][k], dys[1][k], dxs[2][k], dys[2][k]);
+                    if (writes)
+                        *reinterpret_cast<float2 *>(A.sigma + (size_t)(gy - A.out_row0) * A.nx + col) = make_float2(sig[0], sig[1]);
+                }
+            }
         }
-        const float dpq = p - q;
-        const float disc = sqrtf(fmaf(dpq, dpq, 4.0f * r * r));
-        A.sigma[oidx] = sqrtf(0.5f * ((p + q) + disc));
     }
 }
 
@@ -277,14 +409,33 @@ int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, i
     A.sigma = (T *)sigma_out;
     A.tensor = (T *)tensor_out;
     if constexpr (sizeof(T) == 4) {
-        if (!tensor_out) {  // float, sigma only: the fast kernel
+        if (!tensor_out && nx % MCOLS == 0 && nx >= 2 * MCOLS && ctx->sigma_march &&
+            (((uintptr_t)x_dep | (uintptr_t)y_dep | (uintptr_t)sigma_out) & 7) == 0) {  // float, sigma only, even width
+            constexpr int MROWS = LCS_SIGMA_MROWS;
+            const int nspans = (nx + MSPAN_OUT - 1) / MSPAN_OUT, nstrips = (n_out_rows + MROWS - 1) / MROWS;
+            const int waves = nspans * nstrips;
+            const dim3 grid((waves + MBLOCK / 64 - 1) / (MBLOCK / 64));
+            ctx->last_sigma_kernel = "sigma_march_kernel_f32";
+            if (layout == LC_LAYOUT_REFERENCE)
+                hipLaunchKernelGGL((sigma_march_kernel_f32<MROWS, LC_LAYOUT_REFERENCE>), grid, dim3(MBLOCK), 0, ctx->stream, A,
+                                   nspans, nstrips);
+            else
+                hipLaunchKernelGGL((sigma_march_kernel_f32<MROWS, LC_LAYOUT_PHYSICAL>), grid, dim3(MBLOCK), 0, ctx->stream, A,
+                                   nspans, nstrips);
+            LC_HIP_CHECK(hipGetLastError());
+            return LC_OK;
+        }
+        if (!tensor_out) {  // float, sigma only, any width: the LDS-tile kernel
             const int fx = (nx + FW - 1) / FW, fy = (n_out_rows + FH - 1) / FH;
+            ctx->last_sigma_kernel = "sigma_kernel_f32";
             hipLaunchKernelGGL(sigma_kernel_f32, dim3(fx * fy), dim3(SBLOCK), 0, ctx->stream, A);
             LC_HIP_CHECK(hipGetLastError());
             return LC_OK;
         }
     }
     const int ntx = (nx + SW - 1) / SW, nty = (n_out_rows + SH - 1) / SH;
+    ctx->last_sigma_kernel = sizeof(T) == 4 ? "sigma_kernel<float, float>"
+                             : (fd_fp32_cast ? "sigma_kernel<double, float>" : "sigma_kernel<double, double>");
     if (fd_fp32_cast || sizeof(T) == 4)
         hipLaunchKernelGGL((sigma_kernel<T, float>), dim3(ntx * nty), dim3(SBLOCK), 0, ctx->stream, A);
     else

@@ -99,9 +99,17 @@ class Engine:
         """lc_advect float32 kernel choice: 1 per-wave LDS tiles (default), 0 direct gathers, -1 default."""
         _capi.check(self.lib.lc_ctx_set_lds_tiles(self.ctx, int(mode)), self.lib)
 
+    def set_sigma_march(self, on: int):
+        """lc_sigma float32 kernel choice: 1 marching kernel with wavefront shuffles (default), 0 LDS tiles, -1 default."""
+        _capi.check(self.lib.lc_ctx_set_sigma_march(self.ctx, int(on)), self.lib)
+
     def last_advect_kernel(self) -> str:
         """Name of the kernel the last :meth:`advect` call launched (as a profiler shows it)."""
         return self.lib.lc_ctx_last_advect_kernel(self.ctx).decode()
+
+    def last_sigma_kernel(self) -> str:
+        """Name of the kernel the last :meth:`sigma` / :meth:`flowmap_gradient` call launched."""
+        return self.lib.lc_ctx_last_sigma_kernel(self.ctx).decode()
 
     # ------------------------------------------------------------------ plumbing
     def _use_current_stream(self):

@@ -307,6 +307,45 @@ def test_sigma_row_window_with_halo(eng):
         eng.sigma(xd[15:30], yd[15:30], lat[15:30], dlat, dlon, ny_global=41, in_row0=15, out_row0=15, n_out_rows=15)
 
 
+@pytest.mark.parametrize("ny,nx", [(5, 8), (41, 72), (37, 124), (70, 126), (33, 250), (64, 1440), (131, 2050)])
+@pytest.mark.parametrize("layout", ["reference", "physical"])
+def test_sigma_marching_and_lds_tile_kernels_agree_bitwise(eng, O, ny, nx, layout):
+    """float32 sigma: the marching kernel (registers + wavefront shuffles, the default on even widths) and the LDS-tile
+    kernel are one arithmetic -- every width class (one span, span edge at 124/126/250, many spans), pole rows,
+    NaNs, row windows with halo; and both sit in the float32 oracle's band."""
+    rng = np.random.default_rng(ny * 10007 + nx)
+    lat = np.linspace(-89.5, 89.5, ny)
+    lon = -180 + (360.0 / nx) * np.arange(nx)
+    X, Y = np.meshgrid(lon, lat)
+    xd = (X + rng.uniform(-1, 1, X.shape) * (360.0 / nx)).astype(np.float32)
+    yd = np.clip(Y + rng.uniform(-1, 1, X.shape) * (179.0 / ny), -90, 90).astype(np.float32)
+    if ny > 8:
+        xd[ny // 2, nx // 3] = np.nan
+    dlat, dlon = float(lat[1] - lat[0]), float(lon[1] - lon[0])
+    lat32 = lat.astype(np.float32)
+    try:
+        eng.set_sigma_march(1)
+        a = _np(eng.sigma(xd, yd, lat32, dlat, dlon, tensor_layout=layout))
+        eng.set_sigma_march(0)
+        b = _np(eng.sigma(xd, yd, lat32, dlat, dlon, tensor_layout=layout))
+        assert np.array_equal(a, b, equal_nan=True)
+        if ny >= 41:   # a row window with halo, through both kernels
+            kw = dict(ny_global=ny, in_row0=9, out_row0=11, n_out_rows=17)
+            eng.set_sigma_march(1)
+            wa = _np(eng.sigma(xd[9:30], yd[9:30], lat32[9:30], dlat, dlon, tensor_layout=layout, **kw))
+            eng.set_sigma_march(0)
+            wb = _np(eng.sigma(xd[9:30], yd[9:30], lat32[9:30], dlat, dlon, tensor_layout=layout, **kw))
+            assert np.array_equal(wa, wb, equal_nan=True) and np.array_equal(wa, a[11:28], equal_nan=True)
+    finally:
+        eng.set_sigma_march(-1)
+    ok = np.isfinite(a)
+    assert (~ok).sum() == (8 if ny > 8 else 0)
+    # against the float64 oracle on the same float32 inputs: float32 X, Y, Z differences carry the Q11 noise
+    ref = O.sigma_max(O.flowmap_gradient(xd.astype(np.float64), yd.astype(np.float64), lat, lon), layout)
+    rel = np.abs(a[ok] - ref[ok]) / np.maximum(ref[ok], 1e-30)
+    assert np.median(rel) < 2e-3
+
+
 def test_gaussian_filter_vs_scipy(eng):
     from scipy.ndimage import gaussian_filter
     rng = np.random.default_rng(8)
