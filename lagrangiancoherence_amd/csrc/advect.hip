@@ -53,8 +53,26 @@ struct AdvectArgs {
     int wind_f32;  // double instantiation only: the wind is float32-valued -> numpy's promotion rules (Q10)
     T *x_out, *y_out, *traj_x, *traj_y;
     int ntx, ntiles;
+    int xcd_chunk;  // tiles per chunk of the XCD-cyclic tile order; 0: one contiguous band of tiles per XCD
     unsigned *clamp_flag;  // NULL, or set to 1 when the non-cyclic longitude clamp moves any parcel (Q9)
 };
+
+// Tile of a workgroup.  Hardware deals workgroups to the 8 XCDs round-robin (blockIdx % 8), each with its own L2.
+// xcd_chunk = 0: XCD x takes the x-th contiguous eighth of the tiles (neighbouring tiles share an L2).
+// xcd_chunk = C: chunks of C tiles (whole tile rows) go to the XCDs cyclically, so every XCD sees every latitude
+// band and they finish together even when the bands cost differently (redo rate, pole rows).
+template <typename T>
+__device__ __forceinline__ int xcd_tile_id(const AdvectArgs<T> &A) {
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+    if (A.xcd_chunk <= 0) return xcd * ((A.ntiles + 7) / 8) + j;
+    const int cj = j / A.xcd_chunk, r = j - cj * A.xcd_chunk;
+    return (cj * 8 + xcd) * A.xcd_chunk + r;
+}
+static inline int xcd_grid(int ntiles, int chunk) {
+    if (chunk <= 0) return ((ntiles + 7) / 8) * 8;
+    const int nch = (ntiles + chunk - 1) / chunk;
+    return ((nch + 7) / 8) * 8 * chunk;
+}
 
 template <typename T>
 struct Pair {
@@ -834,8 +852,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     constexpr int WOFF = ORDER == 3 ? 0 : LC_PAD_LO;  // padded window origin = (y0 + WOFF, x0 + WOFF)
     typedef EulerGeom<ORDER> E;
     __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH + E::ELEMS];
-    const int per_xcd = (A.ntiles + 7) / 8;
-    const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
     const int ix = txi * TILE_W + (threadIdx.x % TILE_W);
@@ -1112,8 +1129,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     constexpr int LT_PITCH = LT_COLS + 4;
     constexpr int WIN = 2, WOFF = LC_PAD_LO;
     __shared__ __attribute__((aligned(16))) f4 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
-    const int per_xcd = (A.ntiles + 7) / 8;
-    const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1399,7 +1415,7 @@ struct LdsLaunch<float, ORDER> {
             // two seeds per lane: a block covers 8 x 64 seeds
             const int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
             A.ntiles = A.ntx * nty;
-            const int g2 = ((A.ntiles + 7) / 8) * 8;
+            const int g2 = xcd_grid(A.ntiles, A.xcd_chunk);
             if (A.K == 4 && A.cyclic) {
                 hipLaunchKernelGGL((advect_lds2_kernel<4, true>), dim3(g2), dim3(BLOCK), 0, st, A);
                 return "advect_lds2_kernel<4, true>";
@@ -1457,8 +1473,7 @@ template <typename T, int ORDER, bool FUSED>
 __device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A) {
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give
     // XCD k the k-th contiguous eighth of the tile list -- its L2 then serves one latitude band.
-    const int per_xcd = (A.ntiles + 7) / 8;
-    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int tile = xcd_tile_id(A);
     if (tile >= A.ntiles) return;
     const int tyi = tile / A.ntx, txi = tile - tyi * A.ntx;
     const int ix = txi * TILE_W + (threadIdx.x % TILE_W);
@@ -1726,7 +1741,8 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.ntx = (nx + TILE_W - 1) / TILE_W;
     const int nty = (ny + TILE_H - 1) / TILE_H;
     A.ntiles = A.ntx * nty;
-    const int grid = ((A.ntiles + 7) / 8) * 8;
+    A.xcd_chunk = ctx->xcd_chunk_rows * A.ntx;
+    const int grid = xcd_grid(A.ntiles, A.xcd_chunk);
     // Kernel choice (float + fused levels only; measured on MI355X, 4096^2 seeds, 96 steps, K=4, 8x8-seed waves):
     //   order 1: direct gather 10.9 ms (vector-L1 lookup bound), LDS tiles 10.2 ms (VALU-issue bound);
     //   order 3: direct gather 37.8 ms, LDS tiles 20.4 ms.

@@ -16,6 +16,7 @@ struct lc_ctx {
     hipStream_t stream;  // the one work is enqueued on (own or borrowed)
     int lds_tiles;       // lc_advect float32 kernel choice: 1 LDS tiles, 0 direct gathers (LCS_LDS_TILES at creation)
     int sigma_march;     // lc_sigma float32 kernel choice: 1 marching kernel with wavefront shuffles, 0 LDS tiles (LCS_SIGMA_MARCH at creation)
+    int xcd_chunk_rows;  // lc_advect tile order: tile rows per chunk dealt to the XCDs cyclically; default 1; 0 = one contiguous band per XCD (LCS_XCD_CHUNK_ROWS at creation)
     const char *last_advect_kernel;
     const char *last_sigma_kernel;
     lc_trunc_cache *trunc;
