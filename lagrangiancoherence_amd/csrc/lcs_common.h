@@ -17,6 +17,7 @@ struct lc_ctx {
     int lds_tiles;       // lc_advect float32 kernel choice: 1 LDS tiles, 0 direct gathers (LCS_LDS_TILES at creation)
     int sigma_march;     // lc_sigma float32 kernel choice: 1 marching kernel with wavefront shuffles, 0 LDS tiles (LCS_SIGMA_MARCH at creation)
     int xcd_chunk_rows;  // lc_advect tile order: tile rows per chunk dealt to the XCDs cyclically; default 1; 0 = one contiguous band per XCD (LCS_XCD_CHUNK_ROWS at creation)
+    int fir_prefilter;   // float32 order-3 pack: 1 one-pass truncated-convolution prefilter (default), 0 the recursive sweeps (LCS_FIR_PREFILTER at creation)
     const char *last_advect_kernel;
     const char *last_sigma_kernel;
     lc_trunc_cache *trunc;

@@ -460,10 +460,14 @@ def test_lds_tile_and_direct_gather_kernels_agree(eng, order, monkeypatch):
     slat, slon = flows.seed_grid(150, 200, lat, lon)
     f = eng.prepare_field(u, v, lat, lon, order)
     out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("LCS_LDS_TILES", flag)
-        x, y = eng.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=order)
-        out[flag] = (_np(x).astype(np.float64), _np(y).astype(np.float64))
+    try:
+        for flag in ("0", "1"):
+            eng.set_lds_tiles(int(flag))     # (the environment variable is read once, at context creation)
+            x, y = eng.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=order)
+            assert ("lds" in eng.last_advect_kernel()) == (flag == "1")
+            out[flag] = (_np(x).astype(np.float64), _np(y).astype(np.float64))
+    finally:
+        eng.set_lds_tiles(-1)
     dx = np.abs(out["0"][0] - out["1"][0])
     dx = np.minimum(dx, np.abs(dx - 360))
     dy = np.abs(out["0"][1] - out["1"][1])
@@ -482,6 +486,35 @@ def test_prefilter_wide_rows_lds_kernel(eng, O, dtype, tol):
     for t in range(nt):
         np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 0], O.spline_prefilter_mirror(u[t]), atol=tol)
         np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 1], O.spline_prefilter_mirror(v[t]), atol=tol)
+
+
+def test_one_pass_prefilter_matches_the_recursive_sweeps(eng, O, monkeypatch):
+    """float32, order 3: the truncated-convolution prefilter (one pass over the raw field, the default) against the
+    recursive sweeps (LCS_FIR_PREFILTER=0 at context creation) and against scipy's recursion in float64: ragged
+    tiles, pads, the fused-level image; a grid too small for the 14-node halo takes the sweeps either way."""
+    from lagrangiancoherence_amd.engine import Engine
+    u, v, lat, lon = _rand_field(77, nt=3, ny=97, nx=150, dtype=np.float32, scale=20.0)
+    monkeypatch.setenv("LCS_FIR_PREFILTER", "0")
+    eng0 = Engine(0)
+    monkeypatch.delenv("LCS_FIR_PREFILTER")
+    a, b = eng.prepare_field(u, v, lat, lon, 3), eng0.prepare_field(u, v, lat, lon, 3)
+    scale = float(np.abs(u).max())
+    for name in ("cub", "ext"):
+        x, y = _np(getattr(a, name)).astype(np.float64), _np(getattr(b, name)).astype(np.float64)
+        nlev = 3 if name == "cub" else 2          # ext has no last level
+        x, y = x.reshape(-1, 100, 153, 2)[:nlev], y.reshape(-1, 100, 153, 2)[:nlev]
+        assert x.shape[0] == nlev
+        assert np.abs(x - y).max() < 3e-6 * scale, name      # a few float32 ulps of the field's scale
+    img = _np(a.cub).astype(np.float64).reshape(3, 100, 153, 2)
+    for t in range(3):
+        np.testing.assert_allclose(img[t, 1:98, 1:151, 0], O.spline_prefilter_mirror(u[t].astype(np.float64)), atol=3e-6 * scale)
+    # pads mirror the coefficients exactly
+    assert np.array_equal(img[:, 0, 1:151], img[:, 2, 1:151]) and np.array_equal(img[:, 98, 1:151], img[:, 96, 1:151])
+    assert np.array_equal(img[:, 99, 1:151], img[:, 95, 1:151]) and np.array_equal(img[:, :, 0], img[:, :, 2])
+    assert np.array_equal(img[:, :, 151], img[:, :, 149]) and np.array_equal(img[:, :, 152], img[:, :, 148])
+    # small grid: both contexts run the same sweeps
+    u2, v2, lat2, lon2 = _rand_field(78, nt=2, ny=12, nx=40, dtype=np.float32, scale=5.0)
+    assert np.array_equal(_np(eng.prepare_field(u2, v2, lat2, lon2, 3).cub), _np(eng0.prepare_field(u2, v2, lat2, lon2, 3).cub))
 
 
 def test_ensemble_members_are_t0_windows(eng, O):
