@@ -26,16 +26,41 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def _strip_comments(src: str) -> str:
+    """C/C++ source without comments and with runs of white space collapsed (string literals kept as they are)."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == '"' or c == "'":                      # literal: copy through the closing quote
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def csrc_hash() -> str:
-    """sha256 (first 16 hex digits) over the kernel sources and the public header: what a committed rocprof
-    summary is stamped with, so a number replayed from profiles/ can be tied to the code it was measured on."""
+    """sha256 (first 16 hex digits) over the kernel sources and the public header, comments and white space
+    stripped: what a committed rocprof summary is stamped with, so a number replayed from profiles/ can be tied to
+    the CODE it was measured on (editing a comment does not orphan the measurements)."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     files.append(os.path.join(os.path.dirname(HERE), "include", "lcs_hip.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_strip_comments(open(f, encoding="utf-8").read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -1471,9 +1471,7 @@ struct InteriorPath<float, ORDER, FUSED> {
 // lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
 template <typename T, int ORDER, bool FUSED>
 __device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A) {
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give
-    // XCD k the k-th contiguous eighth of the tile list -- its L2 then serves one latitude band.
-    const int tile = xcd_tile_id(A);
+    const int tile = xcd_tile_id(A);  // tile rows dealt to the XCDs cyclically (see xcd_tile_id)
     if (tile >= A.ntiles) return;
     const int tyi = tile / A.ntx, txi = tile - tyi * A.ntx;
     const int ix = txi * TILE_W + (threadIdx.x % TILE_W);

@@ -8,10 +8,14 @@
 //   eigen step of LCS.__call__      LCS/LCS.py:152-154   ||M||_2 of the 3x3 built by a
 //                                   row-major reshape of the 9 components (Q13)
 // The reference materialises X,Y,Z, six derivative fields, three zero fields and a
-// pandas MultiIndex; here a workgroup computes X,Y,Z once for its tile plus a 2-cell
-// halo into LDS (as float when fd_fp32_cast, Q11), differences from LDS and solves the
-// 2x2 Gram eigenproblem in closed form.  HBM traffic: read x_dep,y_dep once (+halo
-// re-reads served by L2), write sigma once.
+// pandas MultiIndex; here X,Y,Z are computed once per cell (as float when fd_fp32_cast,
+// Q11), differenced on chip and the 2x2 Gram eigenproblem is solved in closed form.
+// HBM traffic: read x_dep,y_dep once (+halo re-reads served by L2), write sigma once.
+// Three kernels, one arithmetic per type:
+//   sigma_march_kernel_f32   float32, sigma only, even width (the default): a wave walks down its rows with
+//                            five rows of X,Y,Z in registers, x-neighbours by wavefront shuffle
+//   sigma_kernel_f32         float32, sigma only, any width: a 64 x 16 tile + halo through LDS
+//   sigma_kernel<T,S>        float64 and/or the 9-plane tensor output, numba's typing of the stencil (S)
 #include "lcs_common.h"
 
 namespace {

@@ -116,3 +116,25 @@ def test_x_boundary_mode_defaults():
     assert x_boundary_mode(False, "pointwise") == 0 and x_boundary_mode(False, "reference_outer", whole_grid=False) == 2
     with pytest.raises(ValueError):
         x_boundary_mode(False, "nearest")
+
+
+def test_csrc_hash_follows_code_not_comments(tmp_path, monkeypatch):
+    """profiles/ summaries are stamped with build.csrc_hash(); bench.py replays their counters only on a match.
+    The hash covers the code of csrc/ + the public header: comments and white space do not change it, code does."""
+    import shutil
+    from lagrangiancoherence_amd import build
+    h0 = build.csrc_hash()
+    assert len(h0) == 16 and h0 == build.csrc_hash()
+    assert build._strip_comments('a = 1; // x\n/* y */ s = "// kept";   b') == 'a = 1; s = "// kept"; b'
+    csrc = tmp_path / "pkg" / "csrc"
+    shutil.copytree(build.CSRC, csrc)
+    (tmp_path / "include").mkdir()
+    shutil.copy(os.path.join(os.path.dirname(build.HERE), "include", "lcs_hip.h"), tmp_path / "include" / "lcs_hip.h")
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    monkeypatch.setattr(build, "HERE", str(tmp_path / "pkg"))
+    assert build.csrc_hash() == h0
+    f = csrc / "sigma.hip"
+    f.write_text(f.read_text() + "\n// a trailing remark\n\n")
+    assert build.csrc_hash() == h0
+    f.write_text(f.read_text() + "\nstatic int lc_unused_marker = 1;\n")
+    assert build.csrc_hash() != h0
