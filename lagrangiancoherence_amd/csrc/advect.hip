@@ -54,6 +54,9 @@ struct AdvectArgs {
     T *x_out, *y_out, *traj_x, *traj_y;
     int ntx, ntiles;
     int xcd_chunk;  // tiles per chunk of the XCD-cyclic tile order; 0: one contiguous band of tiles per XCD
+    int tile_order;  // 0 as stored, 1 last tile row first, 2 from the poles inwards (xcd_tile_id)
+    int tile_order_two_seed;  // host side only: what the two-seed kernel's launch puts into tile_order
+    int pole_blocks, pole_lo, pole_hi;  // leading workgroups that take the pole rows (first pole_lo / last pole_hi local rows); 0: the tiles do
     unsigned *clamp_flag;  // NULL, or set to 1 when the non-cyclic longitude clamp moves any parcel (Q9)
 };
 
@@ -63,10 +66,24 @@ struct AdvectArgs {
 // band and they finish together even when the bands cost differently (redo rate, pole rows).
 template <typename T>
 __device__ __forceinline__ int xcd_tile_id(const AdvectArgs<T> &A) {
-    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+    const int b = (int)blockIdx.x - A.pole_blocks;  // pole_blocks is a multiple of 8: b % 8 is still the XCD
+    const int xcd = b % 8, j = b / 8;
     if (A.xcd_chunk <= 0) return xcd * ((A.ntiles + 7) / 8) + j;
     const int cj = j / A.xcd_chunk, r = j - cj * A.xcd_chunk;
-    return (cj * 8 + xcd) * A.xcd_chunk + r;
+    const int d = (cj * 8 + xcd) * A.xcd_chunk + r;  // position in dispatch order
+    // Order of the tile rows.  Next to a pole 1 / cos(lat) makes a time step many cells long, the windows leave
+    // their tiles at every sample and those workgroups live several times longer than the others: started last they
+    // are the launch's tail, started first they hide behind it.  1: the last row first, then 0, 1, 2, ... (default:
+    // order 3 17.69 -> 17.08 ms, float64 C2 and K = 0 1 % better than as stored); 2: from the poles inwards (last, 0,
+    // last-1, 1, ...: the launch ends on the equatorial rows, whose patches stay coherent longest) -- the two-seed
+    // order-1 kernel's default (C3 6.68 -> 6.40 ms like 1, but C5 426 -> 419 where 1 gives 440; order 3 17.54 and
+    // float64 C2 +5 % with it, so not for them); 0: as stored.
+    if (A.tile_order && d < A.ntiles) {
+        const int dr = d / A.ntx, c = d - dr * A.ntx, nty = A.ntiles / A.ntx;
+        const int row = A.tile_order == 2 ? ((dr & 1) ? (dr >> 1) : nty - 1 - (dr >> 1)) : (dr == 0 ? nty - 1 : dr - 1);
+        return row * A.ntx + c;
+    }
+    return d;
 }
 static inline int xcd_grid(int ntiles, int chunk) {
     if (chunk <= 0) return ((ntiles + 7) / 8) * 8;
@@ -426,6 +443,23 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
     }
     A.x_out[idx] = x;
     A.y_out[idx] = y;
+}
+
+// The global pole rows (first / last `order` seed rows, Q3) take the generic per-seed path through the whole series.
+// Inside a tile they would hold 8 lanes of a wave -- and with it the wave's workgroup -- several times a normal
+// workgroup's life (every sample a dependent global gather), and the workgroups of the last tile row would be the
+// launch's tail (measured on C3: 7.0 -> 6.7 ms without it).  So the launch starts with `pole_blocks` workgroups that
+// take those rows one seed per thread, all lanes busy, and the tiles skip them.  Same function, same results.
+template <typename T>
+__device__ __forceinline__ bool pole_block(const AdvectArgs<T> &A) {
+    if ((int)blockIdx.x >= A.pole_blocks) return false;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < (A.pole_lo + A.pole_hi) * A.nx) {
+        const int k = i / A.nx, ix = i - k * A.nx;
+        const int iy = k < A.pole_lo ? k : A.ny - A.pole_hi + (k - A.pole_lo);
+        advect_seed<T, 1, false>(A, A.lin, iy, ix);
+    }
+    return true;
 }
 
 // ======================================================================================
@@ -852,6 +886,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     constexpr int WOFF = ORDER == 3 ? 0 : LC_PAD_LO;  // padded window origin = (y0 + WOFF, x0 + WOFF)
     typedef EulerGeom<ORDER> E;
     __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH + E::ELEMS];
+    if (pole_block(A)) return;
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
@@ -864,7 +899,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     if (live) {
         const int grow = A.row0 + iy;
         if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path, whole integration (Q3)
-            advect_seed<float, 1, false>(A, A.lin, iy, ix);
+            if (!A.pole_blocks) advect_seed<float, 1, false>(A, A.lin, iy, ix);  // (else the leading workgroups did them)
             live = false;
         }
     }
@@ -1129,6 +1164,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     constexpr int LT_PITCH = LT_COLS + 4;
     constexpr int WIN = 2, WOFF = LC_PAD_LO;
     __shared__ __attribute__((aligned(16))) f4 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
+    if (pole_block(A)) return;
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
@@ -1149,7 +1185,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
         if (live[q]) {
             const int grow = A.row0 + iy;
             if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path, whole integration (Q3)
-                advect_seed<float, 1, false>(A, A.lin, iy, ix);
+                if (!A.pole_blocks) advect_seed<float, 1, false>(A, A.lin, iy, ix);  // (else the leading workgroups did them)
                 live[q] = false;
             }
         }
@@ -1415,7 +1451,8 @@ struct LdsLaunch<float, ORDER> {
             // two seeds per lane: a block covers 8 x 64 seeds
             const int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
             A.ntiles = A.ntx * nty;
-            const int g2 = xcd_grid(A.ntiles, A.xcd_chunk);
+            A.tile_order = A.tile_order_two_seed;
+            const int g2 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
             if (A.K == 4 && A.cyclic) {
                 hipLaunchKernelGGL((advect_lds2_kernel<4, true>), dim3(g2), dim3(BLOCK), 0, st, A);
                 return "advect_lds2_kernel<4, true>";
@@ -1471,6 +1508,7 @@ struct InteriorPath<float, ORDER, FUSED> {
 // lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
 template <typename T, int ORDER, bool FUSED>
 __device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A) {
+    if (pole_block(A)) return;
     const int tile = xcd_tile_id(A);  // tile rows dealt to the XCDs cyclically (see xcd_tile_id)
     if (tile >= A.ntiles) return;
     const int tyi = tile / A.ntx, txi = tile - tyi * A.ntx;
@@ -1479,9 +1517,9 @@ __device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A) {
     if (ix >= A.nx || iy >= A.ny) return;
     const int grow = A.row0 + iy;
     const bool pole = grow < A.order || grow >= A.ny_global - A.order;  // tools.py:24-33 (Q3)
-    if (pole)
-        advect_seed<T, 1, false>(A, A.lin, iy, ix);
-    else
+    if (pole) {
+        if (!A.pole_blocks) advect_seed<T, 1, false>(A, A.lin, iy, ix);  // (else the leading workgroups did them)
+    } else
         InteriorPath<T, ORDER, FUSED>::run(A, iy, ix);
 }
 
@@ -1688,7 +1726,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
                 int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, int wind_f32 = 0) {
-    AdvectArgs<T> A;
+    AdvectArgs<T> A{};
     A.wind_f32 = wind_f32;
     A.lin = (const T *)packed_lin;
     A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
@@ -1740,7 +1778,17 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     const int nty = (ny + TILE_H - 1) / TILE_H;
     A.ntiles = A.ntx * nty;
     A.xcd_chunk = ctx->xcd_chunk_rows * A.ntx;
-    const int grid = xcd_grid(A.ntiles, A.xcd_chunk);
+    A.tile_order = ctx->tile_order >= 0 ? ctx->tile_order : 1;
+    A.tile_order_two_seed = ctx->tile_order >= 0 ? ctx->tile_order : 2;
+    {   // leading workgroups for the global pole rows present in this block of seed rows
+        const int lo = min(max(A.order - A.row0, 0), ny), hi = min(max(A.row0 + ny - (A.ny_global - A.order), 0), ny);
+        const long long npole = (long long)(lo + hi) * nx;
+        const bool on = ctx->pole_blocks && lo + hi <= ny && npole > 0 && npole < (1ll << 30);
+        A.pole_lo = on ? lo : 0;
+        A.pole_hi = on ? hi : 0;
+        A.pole_blocks = on ? (int)(((npole + BLOCK - 1) / BLOCK + 7) / 8 * 8) : 0;
+    }
+    const int grid = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
     // Kernel choice (float + fused levels only; measured on MI355X, 4096^2 seeds, 96 steps, K=4, 8x8-seed waves):
     //   order 1: direct gather 10.9 ms (vector-L1 lookup bound), LDS tiles 10.2 ms (VALU-issue bound);
     //   order 3: direct gather 37.8 ms, LDS tiles 20.4 ms.

@@ -18,6 +18,8 @@ struct lc_ctx {
     int sigma_march;     // lc_sigma float32 kernel choice: 1 marching kernel with wavefront shuffles, 0 LDS tiles (LCS_SIGMA_MARCH at creation)
     int xcd_chunk_rows;  // lc_advect tile order: tile rows per chunk dealt to the XCDs cyclically; default 1; 0 = one contiguous band per XCD (LCS_XCD_CHUNK_ROWS at creation)
     int fir_prefilter;   // float32 order-3 pack: 1 one-pass truncated-convolution prefilter (default), 0 the recursive sweeps (LCS_FIR_PREFILTER at creation)
+    int tile_order;      // lc_advect tile-row order: -1 per kernel (default), 0 as stored, 1 last row first, 2 poles inwards (LCS_TILE_ORDER at creation)
+    int pole_blocks;     // lc_advect: 1 leading workgroups take the global pole rows (default), 0 the tiles do (LCS_POLE_BLOCKS at creation)
     const char *last_advect_kernel;
     const char *last_sigma_kernel;
     lc_trunc_cache *trunc;
