@@ -313,32 +313,50 @@ def main():
     ev_marks = []
     in_row0 = lo - n_lo
 
-    def member_pass(field, t0, marks):
+    def member_pass(field, t0):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]     # start, advect, halo, sigma
+        marks[0].record()
         res = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, t0, nsteps, row0=lo,
                          ny_global=ny_global, halo=(n_lo, n_hi), return_traj=args.traj)
         x_ext, y_ext = res[0], res[1]
-        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
+        marks[1].record()
         sharded.halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rrank, rworld, engine=eng, comm=comm)
-        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
+        marks[2].record()
         sig = eng.sigma(x_ext, y_ext, slat_d[in_row0:in_row0 + x_ext.shape[0]], dlat, dlon, ny_global=ny_global,
                         in_row0=in_row0, out_row0=lo, n_out_rows=hi - lo)
-        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
-        return sig, x_ext, y_ext
+        marks[3].record()
+        return (sig, x_ext, y_ext), marks
 
     last = {}   # outputs of the most recent step (for the checks after the timed region); cleared before the
                 # next step allocates, so that steps reuse one set of device buffers instead of ping-ponging two
+    # c5: independent members alternate between two HIP streams, so one member's last workgroups (the tail of its
+    # launch) run beside the next member's first ones.  The events bracket each member on its own stream.
+    nstreams = max(1, int(os.environ.get("LCS_MEMBER_STREAMS", "2"))) if wk == "c5" else 1
+    side = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else []
 
     def one_step(record: bool):
         last.clear()
-        marks = [torch.cuda.Event(enable_timing=True)]
-        marks[0].record()
+        cur = torch.cuda.current_stream()
+        pack = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+        pack[0].record()
         field = eng.prepare_field(ud, vd, lat, lon, order)
-        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
-        res = None
-        for e in members:
-            res = member_pass(field, e if wk == "c5" else 0, marks)
+        pack[1].record()
+        res, mm = None, []
+        for i, e in enumerate(members):
+            if side:
+                st = side[i % nstreams]
+                st.wait_stream(cur)                 # the packed field (and the previous step's frees) are in order
+                with torch.cuda.stream(st):
+                    res, m = member_pass(field, e if wk == "c5" else 0)
+                for t in res:
+                    t.record_stream(cur)            # read later on the current stream (checks after the timed region)
+            else:
+                res, m = member_pass(field, e if wk == "c5" else 0)
+            mm.append(m)
+        for st in side:
+            cur.wait_stream(st)
         if record:
-            ev_marks.append(marks)
+            ev_marks.append((pack, mm))
         last.update(sig=res[0] if res else None, x_ext=res[1] if res else None, y_ext=res[2] if res else None, field=field)
 
     for _ in range(args.warmup):
@@ -360,18 +378,22 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    for marks in ev_marks:                            # marks: [start, pack, (advect, halo, sigma) x members]
-        ev["pack"].append(marks[0].elapsed_time(marks[1]))
-        adv = hal = sg = 0.0
-        for m in range(len(members)):
-            b = 1 + 3 * m
-            adv += marks[b].elapsed_time(marks[b + 1])
-            hal += marks[b + 1].elapsed_time(marks[b + 2])
-            sg += marks[b + 2].elapsed_time(marks[b + 3])
-        ev["advect"].append(adv)
-        ev["halo"].append(hal)
-        ev["sigma"].append(sg)
+    for pack, mm in ev_marks:                         # per member: [start, advect, halo, sigma] on the member's stream
+        ev["pack"].append(pack[0].elapsed_time(pack[1]))
+        ev["advect"].append(sum(m[0].elapsed_time(m[1]) for m in mm))
+        ev["halo"].append(sum(m[1].elapsed_time(m[2]) for m in mm))
+        ev["sigma"].append(sum(m[2].elapsed_time(m[3]) for m in mm))
     ms = {k: float(np.mean(vv)) for k, vv in ev.items()}
+    if side:
+        # members overlapped on several streams: the event brackets above overlap too.  Per-kernel durations for the
+        # roofline objects come from ONE member run alone on the current stream, after the timed region; the sums
+        # reported in kernel_ms are scaled from it, and the overlapped wall time is given beside them.
+        torch.cuda.synchronize()
+        _, m = member_pass(last["field"], members[0])
+        torch.cuda.synchronize()
+        n = len(members)
+        ms.update(advect=m[0].elapsed_time(m[1]) * n, halo=m[1].elapsed_time(m[2]) * n, sigma=m[2].elapsed_time(m[3]) * n,
+                  members_overlapped_wall=1e3 * elapsed / args.steps - ms["pack"])
     sig, x_ext, y_ext, field = last["sig"], last["x_ext"], last["y_ext"], last["field"]
     if sig is not None:
         assert bool(torch.isfinite(sig).all()), "non-finite sigma in the benchmark output"
@@ -458,7 +480,9 @@ def main():
             **({"field": [fny, fnx]} if args.field else {}),
             **({"return_traj": True} if args.traj else {}),
             "step": "pack + fused advect + halo exchange + sigma" + (" per member" if wk == "c5" else "")
-                    + "; u/v/seeds resident in HBM",
+                    + "; u/v/seeds resident in HBM"
+                    + (f"; independent members alternate between {nstreams} HIP streams (kernel_ms advect/halo/sigma = "
+                       "members x one member run alone; members_overlapped_wall = what they take together)" if side else ""),
         },
         "advect_particle_timesteps_per_s": pts_launch * n_launch * world / (ms["advect"] / 1e3),
         "ftle_mcells_per_s": (hi - lo) * nx * n_launch * world / (ms["sigma"] / 1e3) / 1e6,

@@ -537,6 +537,12 @@ def test_ensemble_members_are_t0_windows(eng, O):
         np.testing.assert_allclose(got[e], ref, rtol=SIG_RTOL64)
     with pytest.raises(ValueError):
         sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=6, nsteps=4)
+    # members alternate between HIP streams (default 2): same bits as one stream, departure points included
+    a = sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=5, nsteps=4, SETTLS_order=2, return_dpts=True, streams=1)
+    for ns in (2, 3):
+        b = sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=5, nsteps=4, SETTLS_order=2, return_dpts=True,
+                                 streams=ns)
+        assert a[0] == b[0] and all(bool((x == y).all()) for x, y in zip(a[1:], b[1:]))
 
 
 @pytest.mark.parametrize("order", [1, 3])
