@@ -1447,7 +1447,11 @@ struct LdsLaunch<float, ORDER> {
     // returns the launched kernel's name, or NULL when the LDS kernel does not apply
     static const char *launch(const AdvectArgs<float> &A0, int grid, hipStream_t st, int mode) {
         AdvectArgs<float> A = A0;
-        if (ORDER == 1 && mode != 2 && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16) {
+        // two seeds per lane pays once the launch is many rounds of workgroups deep; below ~8 M seeds the one-seed kernel's
+        // twice as many waves fill the machine better (4096 x 512 seeds, one GPU's share of C3 split 8 ways: +24 %;
+        // measured cross-over between 2896^2 and 3500^2).  mode 1 / 2 force either (tests, A/B); 3 = by size.
+        const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny >= (1ll << 23));
+        if (ORDER == 1 && two_seed && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16) {
             // two seeds per lane: a block covers 8 x 64 seeds
             const int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
             A.ntiles = A.ntx * nty;

@@ -13,6 +13,7 @@ module in `dropin.py`.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -82,6 +83,7 @@ class Engine:
         self.device = torch.device("cuda", self.device_index)
         ctx = C.c_void_p()
         _capi.check(self.lib.lc_ctx_create(self.device_index, C.byref(ctx)), self.lib)
+        self.lds_tiles_mode = -1      # what set_lds_tiles was last given (-1: the library's default, or LCS_LDS_TILES)
         self.ctx = ctx
 
     def close(self):
@@ -96,8 +98,10 @@ class Engine:
             pass
 
     def set_lds_tiles(self, mode: int):
-        """lc_advect float32 kernel choice: 1 per-wave LDS tiles (default), 0 direct gathers, -1 default."""
+        """lc_advect float32 kernel choice: -1 default (LDS tiles; at order 1 two seeds per lane from 2^23 seeds per call,
+        one below), 1 LDS tiles with two seeds per lane at order 1 whatever the size, 2 one seed per lane, 0 direct gathers."""
         _capi.check(self.lib.lc_ctx_set_lds_tiles(self.ctx, int(mode)), self.lib)
+        self.lds_tiles_mode = int(mode)
 
     def set_sigma_march(self, on: int):
         """lc_sigma float32 kernel choice: 1 marching kernel with wavefront shuffles (default), 0 LDS tiles, -1 default."""
@@ -106,6 +110,29 @@ class Engine:
     def last_advect_kernel(self) -> str:
         """Name of the kernel the last :meth:`advect` call launched (as a profiler shows it)."""
         return self.lib.lc_ctx_last_advect_kernel(self.ctx).decode()
+
+    TWO_SEED_MIN = 1 << 23   # seeds per call from which lc_advect's default is the two-seeds-per-lane kernel
+
+    class _Concurrent:
+        """Context manager for ``n`` advect calls running side by side on different streams: what fills the machine is
+        the seeds in flight, so the size rule of the default kernel choice is applied to ``n`` calls' worth."""
+
+        def __init__(self, eng, seeds_per_call, n):
+            self.eng, self.force = eng, eng.lds_tiles_mode == -1 and "LCS_LDS_TILES" not in os.environ \
+                and seeds_per_call < Engine.TWO_SEED_MIN <= seeds_per_call * n
+
+        def __enter__(self):
+            if self.force:
+                self.eng.set_lds_tiles(1)
+            return self
+
+        def __exit__(self, *exc):
+            if self.force:
+                self.eng.set_lds_tiles(-1)
+            return False
+
+    def concurrent_calls(self, seeds_per_call: int, n: int):
+        return Engine._Concurrent(self, int(seeds_per_call), int(n))
 
     def last_sigma_kernel(self) -> str:
         """Name of the kernel the last :meth:`sigma` / :meth:`flowmap_gradient` call launched."""

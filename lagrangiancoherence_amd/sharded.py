@@ -184,21 +184,22 @@ def ensemble_lcs(engine, field, seed_lat, seed_lon, timestep, n_members: int, ns
         return engine.lcs(field, seed_lat, seed_lon, timestep, SETTLS_order=SETTLS_order, interp_order=interp_order,
                           cyclic_xboundary=cyclic_xboundary, t0=e, nsteps=nsteps, fd_fp32_cast=fd_fp32_cast,
                           tensor_layout=tensor_layout)
-    for i, e in enumerate(mine):
-        if side:
-            st = side[i % len(side)]
-            st.wait_stream(cur)          # the field and the seeds were produced on the current stream
-            with torch.cuda.stream(st):
+    with engine.concurrent_calls(len(seed_lat) * len(seed_lon), max(len(side), 1)):
+        for i, e in enumerate(mine):
+            if side:
+                st = side[i % len(side)]
+                st.wait_stream(cur)          # the field and the seeds were produced on the current stream
+                with torch.cuda.stream(st):
+                    r = one(e)
+                for v in r.values():
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(cur)  # consumed on the current stream below and by the caller
+            else:
                 r = one(e)
-            for v in r.values():
-                if isinstance(v, torch.Tensor):
-                    v.record_stream(cur)  # consumed on the current stream below and by the caller
-        else:
-            r = one(e)
-        out.append(r["sigma"])
-        if return_dpts:
-            xs.append(r["x_dep"])
-            ys.append(r["y_dep"])
+            out.append(r["sigma"])
+            if return_dpts:
+                xs.append(r["x_dep"])
+                ys.append(r["y_dep"])
     for st in side:
         cur.wait_stream(st)
     st = lambda a: torch.stack(a) if a else None

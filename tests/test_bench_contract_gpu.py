@@ -34,7 +34,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm", "algorithmic_GBps", "csrc_hash"):
         assert k in rf, k
     # the fused LDS-tile kernel is bound by vector-ALU instruction throughput; the fraction is a physical one
-    assert rf["bound"] == "valu" and rf["kernel"] == "advect_lds2_kernel<4, true>"
+    # (a 256^2 miniature is far below the 2^23 seeds from which the two-seed kernel is the default: one seed per lane)
+    assert rf["bound"] == "valu" and rf["kernel"] == "advect_lds_kernel<1, 4, true>"
     assert rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert 0 < rf["frac"] <= 1 and 0 < rf["hbm"]["compulsory_frac"] <= 1
     # no committed counter summary matches a miniature variant: replayed fields are null, never stale numbers
@@ -47,6 +48,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 
 def test_bench_direct_kernel_is_named_as_such():
+    d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--no-cpu-baseline", env={"LCS_LDS_TILES": "1"})
+    assert d["roofline"]["kernel"] == "advect_lds2_kernel<4, true>"      # forced: two seeds per lane whatever the size
     d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--settls", "0", "--no-cpu-baseline")
     assert d["roofline"]["kernel"] == "advect_kernel_f32<1>" and d["roofline"]["bound"] == "tcp"
     d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--no-cpu-baseline", env={"LCS_LDS_TILES": "0"})

@@ -78,7 +78,7 @@ def test_float32_kernels_agree_with_each_other_and_the_oracle(fny, fnx, nt, K, o
     f = eng.prepare_field(u, v, lat, lon, order)
     out = {}
     try:
-        for flag in ("0", "1", "2"):     # direct gathers, LDS tiles (two seeds per lane at order 1), LDS tiles one seed per lane
+        for flag in ("0", "1", "2"):     # direct gathers, LDS tiles forced to two seeds per lane at order 1, one seed per lane
             eng.set_lds_tiles(int(flag))
             x, y = eng.advect(f, slat, slon, dt, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic,
                               noncyclic_clamp="pointwise")     # the fused kernels' own per-point clamp
