@@ -95,9 +95,11 @@ int lc_sync(lc_ctx *ctx);
  * lc_ctx_create (profiling A/B; results are bit-identical either way).  No reference counterpart. */
 int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode);
 /* Kernel choice of lc_sigma for float32 sigma-only calls on grids of even width: 1 = marching kernel (a wave walks
- * down its rows with five rows of X, Y, Z in registers and takes the x-neighbours by wavefront shuffle; default),
- * 0 = the LDS-tile kernel that also serves odd widths.  -1 restores the default.  LCS_SIGMA_MARCH (0/1) sets the
- * initial value, read ONCE in lc_ctx_create.  Results are bit-identical either way.  No reference counterpart. */
+ * down its rows with five rows of X, Y, Z in registers and takes the x-neighbours by wavefront shuffle), 0 = the
+ * LDS-tile kernel that also serves odd widths, -1 = default: the marching kernel from 2^23 cells per call upwards
+ * (its waves walk 24 rows one after the other: smaller grids finish sooner as many short-lived tiles).
+ * LCS_SIGMA_MARCH (0/1) sets the initial value, read ONCE in lc_ctx_create.  Results are bit-identical either way.
+ * No reference counterpart. */
 int lc_ctx_set_sigma_march(lc_ctx *ctx, int on);
 /* Name of the kernel the context's last lc_advect call launched (static string, "" before the first call);
  * what a profiler shows, so a benchmark labels its numbers with the kernel that actually ran. */

@@ -50,8 +50,8 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     if (const char *ev = getenv("LCS_POLE_BLOCKS")) c->pole_blocks = ev[0] != '0';  // read once, here
     c->fir_prefilter = 1;
     if (const char *ev = getenv("LCS_FIR_PREFILTER")) c->fir_prefilter = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);  // read once, here
-    c->sigma_march = 1;
-    if (const char *ev = getenv("LCS_SIGMA_MARCH")) c->sigma_march = ev[0] != '0';  // read once, here
+    c->sigma_march = 2;  // by size
+    if (const char *ev = getenv("LCS_SIGMA_MARCH")) c->sigma_march = ev[0] == '0' ? 0 : (ev[0] == '1' ? 1 : 2);  // read once, here
     c->last_advect_kernel = "";
     c->last_sigma_kernel = "";
     c->trunc = nullptr;
@@ -69,7 +69,7 @@ extern "C" int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode) {
 extern "C" int lc_ctx_set_sigma_march(lc_ctx *ctx, int on) {
     LC_REQUIRE(ctx, "lc_ctx_set_sigma_march: null context");
     LC_REQUIRE(on >= -1 && on <= 1, "lc_ctx_set_sigma_march: on must be -1, 0 or 1");
-    ctx->sigma_march = on != 0;
+    ctx->sigma_march = on < 0 ? 2 : on;
     return LC_OK;
 }
 

@@ -413,7 +413,11 @@ int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, i
     A.sigma = (T *)sigma_out;
     A.tensor = (T *)tensor_out;
     if constexpr (sizeof(T) == 4) {
-        if (!tensor_out && nx % MCOLS == 0 && nx >= 2 * MCOLS && ctx->sigma_march &&
+        // the marching kernel's waves walk MROWS + 4 rows one after the other: a latency floor of ~20 us whatever the
+        // size, so below 2^23 cells the LDS-tile kernel (more, shorter-lived workgroups) is the faster one
+        // (2048^2: 27.5 vs 29.2 us; 2896^2: 50.9 vs 43.2).  sigma_march 1 forces it (tests, A/B), 2 = by size.
+        const bool march = ctx->sigma_march == 1 || (ctx->sigma_march == 2 && (long long)nx * n_out_rows >= (1ll << 23));
+        if (!tensor_out && nx % MCOLS == 0 && nx >= 2 * MCOLS && march &&
             (((uintptr_t)x_dep | (uintptr_t)y_dep | (uintptr_t)sigma_out) & 7) == 0) {  // float, sigma only, even width
             constexpr int MROWS = LCS_SIGMA_MROWS;
             const int nspans = (nx + MSPAN_OUT - 1) / MSPAN_OUT, nstrips = (n_out_rows + MROWS - 1) / MROWS;

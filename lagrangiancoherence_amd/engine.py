@@ -104,7 +104,8 @@ class Engine:
         self.lds_tiles_mode = int(mode)
 
     def set_sigma_march(self, on: int):
-        """lc_sigma float32 kernel choice: 1 marching kernel with wavefront shuffles (default), 0 LDS tiles, -1 default."""
+        """lc_sigma float32 kernel choice: -1 default (marching kernel with wavefront shuffles from 2^23 cells per call,
+        LDS tiles below), 1 marching kernel whatever the size, 0 LDS tiles."""
         _capi.check(self.lib.lc_ctx_set_sigma_march(self.ctx, int(on)), self.lib)
 
     def last_advect_kernel(self) -> str:

@@ -324,10 +324,12 @@ def test_sigma_marching_and_lds_tile_kernels_agree_bitwise(eng, O, ny, nx, layou
     dlat, dlon = float(lat[1] - lat[0]), float(lon[1] - lon[0])
     lat32 = lat.astype(np.float32)
     try:
-        eng.set_sigma_march(1)
+        eng.set_sigma_march(1)      # forced: by default grids below 2^23 cells take the LDS-tile kernel
         a = _np(eng.sigma(xd, yd, lat32, dlat, dlon, tensor_layout=layout))
+        assert eng.last_sigma_kernel() == "sigma_march_kernel_f32"
         eng.set_sigma_march(0)
         b = _np(eng.sigma(xd, yd, lat32, dlat, dlon, tensor_layout=layout))
+        assert eng.last_sigma_kernel() == "sigma_kernel_f32"
         assert np.array_equal(a, b, equal_nan=True)
         if ny >= 41:   # a row window with halo, through both kernels
             kw = dict(ny_global=ny, in_row0=9, out_row0=11, n_out_rows=17)
