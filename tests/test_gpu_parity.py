@@ -519,6 +519,34 @@ def test_one_pass_prefilter_matches_the_recursive_sweeps(eng, O, monkeypatch):
     assert np.array_equal(_np(eng.prepare_field(u2, v2, lat2, lon2, 3).cub), _np(eng0.prepare_field(u2, v2, lat2, lon2, 3).cub))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("order", [1, 3])
+def test_launch_geometry_does_not_change_results(eng, dtype, order, monkeypatch):
+    """The global pole rows run in leading workgroups of their own and the tile rows are dealt out from the poles
+    (LCS_POLE_BLOCKS, LCS_TILE_ORDER, LCS_XCD_CHUNK_ROWS, read at context creation): none of it may change a bit.
+    Shapes where every row is a pole row, row windows holding only the lower / only the upper pole rows / none."""
+    from lagrangiancoherence_amd.engine import Engine
+    for k, v in (("LCS_POLE_BLOCKS", "0"), ("LCS_TILE_ORDER", "0"), ("LCS_XCD_CHUNK_ROWS", "0")):
+        monkeypatch.setenv(k, v)
+    plain = Engine(0)
+    for k in ("LCS_POLE_BLOCKS", "LCS_TILE_ORDER", "LCS_XCD_CHUNK_ROWS"):
+        monkeypatch.delenv(k)
+    u, v, lat, lon = flows.era5_like(nt=6, ny=40, nx=90)
+    u, v, lat, lon = (a.astype(dtype) for a in (u, v, lat, lon))
+    try:
+        fa, fb = eng.prepare_field(u, v, lat, lon, order), plain.prepare_field(u, v, lat, lon, order)
+        for sny, snx in ((2 * order, 70), (2 * order + 1, 9), (75, 133), (33, 64)):
+            slat, slon = (a.astype(dtype) for a in flows.seed_grid(sny, snx, lat, lon))
+            windows = [(0, sny)] + ([(0, sny // 2), (sny // 2, sny), (order, sny - order)] if sny > 4 * order else [])
+            for lo, hi in windows:
+                kw = dict(SETTLS_order=2, interp_order=order, cyclic_xboundary=True, row0=lo, ny_global=sny)
+                xa, ya = eng.advect(fa, slat[lo:hi], slon, -3600.0, **kw)
+                xb, yb = plain.advect(fb, slat[lo:hi], slon, -3600.0, **kw)
+                assert bool((xa == xb).all()) and bool((ya == yb).all()), (sny, snx, lo, hi)
+    finally:
+        plain.close()
+
+
 def test_ensemble_members_are_t0_windows(eng, O):
     # BASELINE config 5 in miniature: member e = the same seeds started at time level e
     from lagrangiancoherence_amd import sharded
