@@ -93,7 +93,8 @@ def stamped_counters(kernel: str, workload: dict, csrc: str):
         if d.get("workload") != workload or d.get("csrc_hash") != csrc:
             continue
         for k, v in d.get("kernels", {}).items():
-            if k.replace(" ", "") != kernel.replace(" ", ""):
+            kk, want = k.replace(" ", ""), kernel.replace(" ", "")
+            if kk != want and not (kk.startswith(want + "<") and "<" not in want):   # "name" matches "name<template args>"
                 continue
             if "hbm_bytes_per_launch" in v:
                 out["traffic"] = v["hbm_bytes_per_launch"]
@@ -496,6 +497,9 @@ def main():
             "bound": "hbm", "kernel": eng.last_sigma_kernel(), "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": sigma_gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": sigma_gbps / copy_gbps,
             "algorithmic_bytes_per_cell": 3 * s_p,
+            **(lambda st: {"traffic": st.get("traffic"), "traffic_source": st.get("traffic_source"),
+                           "hbm_traffic_frac": (st["traffic"] / sig_s / 1e9 / HBM_PEAK_GBPS) if st.get("traffic") else None})(
+                stamped_counters(eng.last_sigma_kernel(), wl, csrc)),
             "note": "SURVEY 8d's bound (read x_dep, y_dep, write sigma); the kernel itself is limited by the VALU work of "
                     "two sincos + stencils + two square roots per cell (DESIGN 4)",
         },
