@@ -526,11 +526,12 @@ def test_launch_geometry_does_not_change_results(eng, dtype, order, monkeypatch)
     (LCS_POLE_BLOCKS, LCS_TILE_ORDER, LCS_XCD_CHUNK_ROWS, read at context creation): none of it may change a bit.
     Shapes where every row is a pole row, row windows holding only the lower / only the upper pole rows / none."""
     from lagrangiancoherence_amd.engine import Engine
+    for k in ("LCS_POLE_BLOCKS", "LCS_TILE_ORDER", "LCS_XCD_CHUNK_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    eng = Engine(0)            # a fresh context with the default geometry (the shared one may carry kernel choices)
     for k, v in (("LCS_POLE_BLOCKS", "0"), ("LCS_TILE_ORDER", "0"), ("LCS_XCD_CHUNK_ROWS", "0")):
         monkeypatch.setenv(k, v)
     plain = Engine(0)
-    for k in ("LCS_POLE_BLOCKS", "LCS_TILE_ORDER", "LCS_XCD_CHUNK_ROWS"):
-        monkeypatch.delenv(k)
     u, v, lat, lon = flows.era5_like(nt=6, ny=40, nx=90)
     u, v, lat, lon = (a.astype(dtype) for a in (u, v, lat, lon))
     try:
@@ -545,6 +546,7 @@ def test_launch_geometry_does_not_change_results(eng, dtype, order, monkeypatch)
                 assert bool((xa == xb).all()) and bool((ya == yb).all()), (sny, snx, lo, hi)
     finally:
         plain.close()
+        eng.close()
 
 
 def test_ensemble_members_are_t0_windows(eng, O):
