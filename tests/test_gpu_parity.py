@@ -521,7 +521,7 @@ def test_one_pass_prefilter_matches_the_recursive_sweeps(eng, O, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("order", [1, 3])
-def test_launch_geometry_does_not_change_results(eng, dtype, order, monkeypatch):
+def test_launch_geometry_does_not_change_results(dtype, order, monkeypatch):
     """The global pole rows run in leading workgroups of their own and the tile rows are dealt out from the poles
     (LCS_POLE_BLOCKS, LCS_TILE_ORDER, LCS_XCD_CHUNK_ROWS, read at context creation): none of it may change a bit.
     Shapes where every row is a pole row, row windows holding only the lower / only the upper pole rows / none."""
