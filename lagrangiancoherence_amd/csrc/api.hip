@@ -52,6 +52,8 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     if (const char *ev = getenv("LCS_FIR_PREFILTER")) c->fir_prefilter = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);  // read once, here
     c->sigma_march = 2;  // by size
     if (const char *ev = getenv("LCS_SIGMA_MARCH")) c->sigma_march = ev[0] == '0' ? 0 : (ev[0] == '1' ? 1 : 2);  // read once, here
+    c->lds_tiles_init = c->lds_tiles;
+    c->sigma_march_init = c->sigma_march;
     c->last_advect_kernel = "";
     c->last_sigma_kernel = "";
     c->trunc = nullptr;
@@ -62,14 +64,14 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
 extern "C" int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode) {
     LC_REQUIRE(ctx, "lc_ctx_set_lds_tiles: null context");
     LC_REQUIRE(mode >= -1 && mode <= 2, "lc_ctx_set_lds_tiles: mode must be -1, 0, 1 or 2");
-    ctx->lds_tiles = mode < 0 ? 3 : mode;
+    ctx->lds_tiles = mode < 0 ? ctx->lds_tiles_init : mode;
     return LC_OK;
 }
 
 extern "C" int lc_ctx_set_sigma_march(lc_ctx *ctx, int on) {
     LC_REQUIRE(ctx, "lc_ctx_set_sigma_march: null context");
     LC_REQUIRE(on >= -1 && on <= 1, "lc_ctx_set_sigma_march: on must be -1, 0 or 1");
-    ctx->sigma_march = on < 0 ? 2 : on;
+    ctx->sigma_march = on < 0 ? ctx->sigma_march_init : on;
     return LC_OK;
 }
 
