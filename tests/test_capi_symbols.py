@@ -138,3 +138,28 @@ def test_csrc_hash_follows_code_not_comments(tmp_path, monkeypatch):
     assert build.csrc_hash() == h0
     f.write_text(f.read_text() + "\nstatic int lc_unused_marker = 1;\n")
     assert build.csrc_hash() != h0
+
+
+def test_bench_replays_counters_only_from_summaries_of_the_running_code(tmp_path, monkeypatch):
+    """bench.py's `traffic` / `limiting_unit` are replayed from profiles/*/*_pmc_*.json -- only when the summary's
+    csrc_hash equals the running code's and the workload matches; a kernel name matches its templated spelling."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    prof = tmp_path / "profiles" / "rXX"
+    prof.mkdir(parents=True)
+    wl = {"workload": "c3", "seeds": 64, "nt": 5, "order": 1, "K": 4, "dtype": "f32"}
+    (prof / "x_pmc_traffic.json").write_text(json.dumps({"workload": wl, "csrc_hash": "abc", "kernels": {
+        "advect_lds2_kernel<4, true>": {"hbm_bytes_per_launch": 123.0},
+        "sigma_march_kernel_f32<20, 0>": {"hbm_bytes_per_launch": 7.0}}}))
+    (prof / "x_pmc_sq_tcp.json").write_text(json.dumps({"workload": wl, "csrc_hash": "abc", "kernels": {
+        "advect_lds2_kernel<4, true>": {"derived": {"valu_issue_frac": 0.9, "none": None}}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got = bench.stamped_counters("advect_lds2_kernel<4, true>", wl, "abc")
+    assert got["traffic"] == 123.0 and got["limiting_unit"] == {"valu_issue_frac": 0.9}
+    assert got["traffic_source"].endswith("x_pmc_traffic.json")
+    assert bench.stamped_counters("sigma_march_kernel_f32", wl, "abc")["traffic"] == 7.0      # name<template args>
+    assert bench.stamped_counters("advect_lds2_kernel<4, true>", wl, "other-code") == {}       # code changed
+    assert bench.stamped_counters("advect_lds2_kernel<4, true>", dict(wl, seeds=128), "abc") == {}   # another workload
+    assert bench.stamped_counters("advect_lds_kernel<1, 4, true>", wl, "abc") == {}            # another kernel
