@@ -147,6 +147,107 @@ def cpu_baseline(flows, u, v, lat, lon, dt, K, order, nsteps):
                       f"{c1 - c0:.1f} s on a host with {os.cpu_count()} cores"}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 without an external launcher.  `python bench.py --gpus N` (WORLD_SIZE unset) starts the N ranks itself, as
+# FRESH child processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on
+# 127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank does.  The parent never touches the GPU (no
+# torch import, no HIP call) and never replaces itself with another program; a rank that fails or a run that
+# exceeds the wall-clock limit takes the other ranks down with it (by the PIDs started here), so a stuck
+# communicator costs a clear error, not the lease.  Under `python -m torch.distributed.run ...` (WORLD_SIZE set)
+# none of this runs: the process is a rank.
+# ---------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, child_argv, timeout_s: float, extra_env=None, out=None, err=None) -> int:
+    """Run `child_argv` as n ranks; rank 0's stdout lines that start with "{" go to `out` (the JSON line), everything
+    else to `err`.  Returns 0 if every rank exited 0; the first non-zero exit code otherwise (124: time limit)."""
+    import signal
+    import subprocess
+    import threading
+    out = out or sys.stdout
+    err = err or sys.stderr
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = {**os.environ, **(extra_env or {}), "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n),
+               "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+        procs.append(subprocess.Popen(list(child_argv), env=env, stdout=subprocess.PIPE, stderr=None, text=True,
+                                      start_new_session=True))
+
+    def relay(r, p):
+        for line in p.stdout:
+            if r == 0 and line.lstrip().startswith("{"):
+                out.write(line)
+                out.flush()
+            else:
+                err.write(f"[rank {r}] {line}")
+                err.flush()
+    threads = [threading.Thread(target=relay, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+
+    def stop_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)           # the process group this function created for that rank
+                except (ProcessLookupError, PermissionError):
+                    pass
+    deadline = time.monotonic() + timeout_s
+    code = 0
+    while True:
+        states = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(states) if c not in (None, 0)]
+        if bad:
+            code = bad[0][1] if bad[0][1] > 0 else 128 - bad[0][1]
+            err.write(f"bench.py: rank {bad[0][0]} exited with {bad[0][1]}; stopping the other ranks\n")
+            break
+        if all(c == 0 for c in states):
+            break
+        if time.monotonic() > deadline:
+            code = 124
+            err.write(f"bench.py: the {n}-rank run did not finish within {timeout_s:.0f} s; stopping it\n")
+            break
+        time.sleep(0.1)
+    if code:
+        stop_all(signal.SIGTERM)
+        t_end = time.monotonic() + 10
+        while time.monotonic() < t_end and any(p.poll() is None for p in procs):
+            time.sleep(0.1)
+        stop_all(signal.SIGKILL)
+    for p in procs:
+        try:
+            p.wait(timeout=15)
+        except Exception:
+            pass
+    for t in threads:
+        t.join(timeout=5)
+    err.flush()
+    return code
+
+
+def watchdog(seconds: float, what: str, rank: int):
+    """Wall-clock guard for a call that may hang inside a communicator (ncclCommInitRank, the first collective): if it
+    is not cancelled in time, the process says what it was waiting for and exits non-zero (the parent then stops the
+    other ranks).  Returns the timer; call .cancel() when the guarded call has returned."""
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py rank {rank}: {what} did not finish within {seconds:.0f} s -- giving up\n")
+        sys.stderr.flush()
+        os._exit(70)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def run_c2(args, torch, flows, Engine, local_rank, csrc):
     """BASELINE configs[1] on one GPU (a parity config; reported for the float64 path's rate)."""
     K, order = args.settls, args.order
@@ -232,6 +333,19 @@ def main():
     ap.add_argument("--members", type=int, default=64, help="c5: ensemble members (start times)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not a rank yet: start the ranks as fresh children BEFORE anything here touches the GPU (spawn_ranks above)
+        if args.workload == "c2":
+            raise SystemExit("--workload c2 is a one-GPU configuration")
+        if not os.environ.get("LCS_BENCH_ONE_GPU"):
+            import torch                                   # device_count() does not initialise the GPU
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"--gpus {args.gpus}: this machine shows {have} GPU(s) (one rank per GPU; "
+                                 "LCS_BENCH_BACKEND=gloo LCS_BENCH_ONE_GPU=1 rehearses the N>1 path on one)")
+        limit = float(os.environ.get("LCS_BENCH_TIMEOUT", "1500"))
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]], limit))
+
     import torch
     import torch.distributed as dist
     from lagrangiancoherence_amd import flows, sharded
@@ -243,20 +357,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world                                  # under a launcher the launcher's world size is the truth
     # LCS_BENCH_BACKEND=gloo + LCS_BENCH_ONE_GPU=1: rehearsal of the N>1 path with every rank on GPU 0
     # (RCCL refuses two ranks on one device); the driver's multi-GPU runs use nccl = RCCL over xGMI.
     backend = os.environ.get("LCS_BENCH_BACKEND", "nccl")
     if os.environ.get("LCS_BENCH_ONE_GPU"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    rccl_ranks = None
+    init_limit = float(os.environ.get("LCS_BENCH_INIT_TIMEOUT", "180"))
     if world > 1:
+        import datetime
+        # a stuck rendezvous / ncclCommInitRank / first collective must end in a message and a non-zero exit
+        wd = watchdog(init_limit, f"init_process_group({backend!r}) + the first collective over {world} ranks", rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=init_limit))
+            one = torch.ones(1, dtype=torch.int32, device="cuda")
+            dist.all_reduce(one)                           # forces the communicator: every rank's 1, summed by RCCL
+            torch.cuda.synchronize()
+            rccl_ranks = int(one.item())                   # the world size the nccl (= RCCL) backend actually spanned
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=init_limit))
+            dist.barrier()
+        wd.cancel()
 
     if args.workload == "c2":
         if world > 1:
@@ -309,7 +433,12 @@ def main():
     # LCS_NATIVE_HALO=1: halo exchange through the C ABI (lc_halo_exchange, RCCL directly) instead of
     # torch.distributed point-to-point (the default; both are RCCL over xGMI with the nccl backend)
     native = bool(os.environ.get("LCS_NATIVE_HALO"))
-    comm = sharded.native_comm(eng, rank, world) if (rworld > 1 and native) else None
+    comm = None
+    if rworld > 1 and native:
+        wd = watchdog(init_limit, "lc_comm_create (ncclCommInitRank through the C ABI)", rank)
+        comm = sharded.native_comm(eng, rank, world)
+        rccl_ranks = eng.comm_count(comm)[0]               # ncclCommCount of the C ABI's own communicator
+        wd.cancel()
     ev = {k: [] for k in ("pack", "advect", "halo", "sigma")}
     ev_marks = []
     in_row0 = lo - n_lo
@@ -432,6 +561,19 @@ def main():
                 halo_check[other.replace(".", "_") + "_error"] = str(exc)[:200]
         # (not an assert: a failed check is REPORTED in the JSON line, next to the number it discredits)
 
+    s_f = s_p = 4
+    n_launch = max(len(members), 1)
+    pts_launch = (hi - lo) * nx * nsteps                                        # per GPU, one advect launch
+    adv_ms = ms["advect"] / n_launch
+    per_rank = None
+    if world > 1:
+        # every rank's own event times and flop fraction (rank 0 reports them; `value` uses the max-over-ranks wall)
+        mine = {"rank": rank, "device": local_rank, "rows": [lo, hi], "members": len(members),
+                "kernel_ms": {k: round(v, 4) for k, v in ms.items()}, "kernel": advect_kernel,
+                "roofline_frac": (pts_launch * flops_pts(K, order, True) / (adv_ms / 1e3) / 1e12 / FP32_VECTOR_TFLOPS)
+                if adv_ms > 0 else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank != 0:                                   # only rank 0 reports
         if world > 1:
             dist.destroy_process_group()
@@ -440,10 +582,6 @@ def main():
     pts_per_step = n_mem_global * ny_global * nx * nsteps
     value = pts_per_step * args.steps / elapsed
     copy_gbps = measured_copy_peak(torch)                                       # after the timed region
-    s_f = s_p = 4
-    n_launch = max(len(members), 1)
-    pts_launch = (hi - lo) * nx * nsteps                                        # per GPU, one advect launch
-    adv_ms = ms["advect"] / n_launch
     sig_s = ms["sigma"] / n_launch / 1e3
     sigma_gbps = (hi - lo) * nx * 3 * s_p / sig_s / 1e9
     # compulsory HBM bytes of one launch: the nsteps+1 levels of img it reads, the nsteps of ext, seeds, outputs
@@ -506,6 +644,11 @@ def main():
     }
     if halo_check is not None:
         out["halo_check"] = halo_check
+    if world > 1:
+        out["backend"] = backend
+        out["rccl_ranks"] = rccl_ranks          # ranks the RCCL communicator spanned (null in the gloo rehearsal)
+        out["halo_ms"] = ms["halo"]
+        out["per_rank"] = per_rank
 
     # ---- CPU baseline: the oracle (numpy+scipy port) on a bounded sample, rank 0, N=1 only ----
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

@@ -290,6 +290,8 @@ typedef struct lc_comm lc_comm;
 int lc_comm_unique_id(void *id_out, size_t id_bytes /* >= 128 */);
 int lc_comm_create(lc_ctx *ctx, int nranks, int rank, const void *id, size_t id_bytes, lc_comm **out);
 int lc_comm_destroy(lc_comm *comm);
+/* ncclCommCount / ncclCommUserRank of the communicator: the ranks RCCL itself spans (a benchmark reports it). */
+int lc_comm_count(const lc_comm *comm, int *nranks_out, int *rank_out);
 int lc_halo_exchange(lc_ctx *ctx, lc_comm *comm, void *x_ext, void *y_ext, int dtype,
                      int n_rows, int nx, int n_lo, int n_hi);
 

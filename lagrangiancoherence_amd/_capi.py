@@ -51,6 +51,7 @@ PROTOTYPES = {
     "lc_comm_unique_id": (_i, [_vp, _sz]),
     "lc_comm_create": (_i, [_vp, _i, _i, _vp, _sz, C.POINTER(_vp)]),
     "lc_comm_destroy": (_i, [_vp]),
+    "lc_comm_count": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "lc_halo_exchange": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "lc_common_grid": (_i, [C.POINTER(_i), C.POINTER(_i), _vp, _vp]),
     "lc_lcs_global_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _d, _i, _i, _d, _i, _i, _vp, _vp, _vp]),

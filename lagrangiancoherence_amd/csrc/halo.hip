@@ -38,6 +38,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -71,6 +73,8 @@ bool load_rccl() {
     LC_SYM(GetUniqueId, "ncclGetUniqueId")
     LC_SYM(CommInitRank, "ncclCommInitRank")
     LC_SYM(CommDestroy, "ncclCommDestroy")
+    LC_SYM(CommCount, "ncclCommCount")
+    LC_SYM(CommUserRank, "ncclCommUserRank")
     LC_SYM(GroupStart, "ncclGroupStart")
     LC_SYM(GroupEnd, "ncclGroupEnd")
     LC_SYM(Send, "ncclSend")
@@ -125,6 +129,16 @@ extern "C" int lc_comm_destroy(lc_comm *comm) {
     if (!comm) return LC_OK;
     if (g_rccl.handle && comm->comm) g_rccl.CommDestroy(comm->comm);
     delete comm;
+    return LC_OK;
+}
+
+extern "C" int lc_comm_count(const lc_comm *comm, int *nranks_out, int *rank_out) {
+    LC_REQUIRE(comm && comm->comm && g_rccl.handle, "lc_comm_count: null communicator");
+    int n = 0, r = 0;
+    LC_RCCL_CHECK(g_rccl.CommCount(comm->comm, &n));  // what RCCL itself says, not what lc_comm_create was told
+    LC_RCCL_CHECK(g_rccl.CommUserRank(comm->comm, &r));
+    if (nranks_out) *nranks_out = n;
+    if (rank_out) *rank_out = r;
     return LC_OK;
 }
 

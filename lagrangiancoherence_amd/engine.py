@@ -386,6 +386,12 @@ class Engine:
                     self.lib)
         return comm
 
+    def comm_count(self, comm):
+        """(nranks, rank) as RCCL itself reports them for the communicator (``lc_comm_count``)."""
+        n, r = C.c_int(), C.c_int()
+        _capi.check(self.lib.lc_comm_count(comm, C.byref(n), C.byref(r)), self.lib)
+        return n.value, r.value
+
     def comm_destroy(self, comm):
         if comm:
             self.lib.lc_comm_destroy(comm)

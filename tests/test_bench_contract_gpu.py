@@ -92,3 +92,40 @@ def test_bench_two_ranks_rehearsal_carries_a_halo_check(wk, extra, units, scalin
         hc = d["halo_check"]
         assert hc["timed_path"] == "torch.distributed" and hc["timed_path_ok"] is True
     assert abs(d["value"] - units / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+
+
+@pytest.mark.parametrize("wk,extra,units", [
+    ("c3", ["--seeds", "256", "--nt", "5"], 512 * 256 * 4),
+    ("c5", ["--seeds", "256", "--nt", "14", "--members", "4"], 4 * 256 * 256 * 10),
+])
+def test_bench_gpus_2_launches_its_own_ranks(wk, extra, units):
+    """Exactly the driver's command form, `python bench.py --gpus 2 ...` with NO launcher around it: bench.py starts the
+    two ranks itself as fresh children (rehearsed over gloo with both on GPU 0), relays rank 0's single JSON line and
+    reports every rank's own kernel times."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LCS_BENCH_BACKEND="gloo", LCS_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--workload", wk, *extra], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # stdout carries the one JSON line and nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["rccl_ranks"] is None   # (nccl: the world size RCCL spanned)
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1]
+    for p in d["per_rank"]:
+        assert p["kernel_ms"]["advect"] > 0 and 0 < p["roofline_frac"] <= 1
+    assert d["halo_ms"] >= 0
+    if wk == "c3":
+        assert d["halo_check"]["timed_path_ok"] is True and d["per_rank"][1]["rows"] == [256, 512]
+    assert abs(d["value"] - units / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+
+
+def test_bench_gpus_2_fails_loudly_when_a_rank_cannot_start():
+    """A rank that dies (here: an init limit of 0 seconds fires the watchdog) must end the whole run non-zero with a
+    message, not hang it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LCS_BENCH_BACKEND="gloo", LCS_BENCH_ONE_GPU="1", LCS_BENCH_INIT_TIMEOUT="0.001")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--seeds", "256", "--nt", "5"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "did not finish within" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
