@@ -101,6 +101,13 @@ int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode);
  * LCS_SIGMA_MARCH (0/1) sets the initial value, read ONCE in lc_ctx_create.  Results are bit-identical either way.
  * No reference counterpart. */
 int lc_ctx_set_sigma_march(lc_ctx *ctx, int on);
+/* lc_advect / lc_advect_from run a series of nsteps time levels as consecutive launches of at most `levels` levels,
+ * each continuing from the positions the previous one stored (0 = one launch, the default).  Results are bit-identical
+ * whatever the value; it shapes the launches only (workgroups of one launch stay within `levels` levels of each other,
+ * so their tiles of the wind images meet in L2 / the Infinity Cache -- sparse seed grids, long series).  The
+ * environment variable LCS_LEVEL_CHUNK sets the initial value, read ONCE in lc_ctx_create.  No reference counterpart
+ * (the reference's loop over time levels is LCS/trajectory.py:80-126). */
+int lc_ctx_set_level_chunk(lc_ctx *ctx, int levels);
 /* Name of the kernel the context's last lc_advect call launched (static string, "" before the first call);
  * what a profiler shows, so a benchmark labels its numbers with the kernel that actually ran. */
 const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx);
@@ -204,6 +211,24 @@ int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub,
               double timestep, int settls_order, int interp_order, int cyclic_x,
               int t0, int nsteps,
               void *x_out, void *y_out, void *traj_x, void *traj_y);
+
+/* lc_advect continuing from given positions instead of the seed grid: x_start, y_start [ny*nx] (dtype elements,
+ * device; both NULL = lc_advect).  The seed coordinates are still needed -- conversion_x is a function of the SEED
+ * latitude for the whole integration (LCS/trajectory.py:56-57, Q5) and the pole-row rule of the seed row index
+ * (LCS/tools.py:24-39, Q3).  Running levels [t0, t0+a) with lc_advect and [t0+a, t0+a+b) with lc_advect_from on the
+ * first call's outputs gives, bit for bit, what one call over a+b levels gives: the loop body of
+ * LCS/trajectory.py:80-126 carries no state from one time level to the next except the positions.  x_start / y_start
+ * may alias x_out / y_out (in place).  traj entry 0 = the start positions.  Not with LC_X_CLAMP_REFERENCE_OUTER. */
+int lc_advect_from(lc_ctx *ctx, const void *packed_lin, const void *packed_cub,
+                   const void *packed_ext, int dtype,
+                   int nt, int ny_f, int nx_f,
+                   double lat_min, double lat_max, double lon_min, double lon_max,
+                   const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx,
+                   int row0, int ny_global,
+                   const void *x_start, const void *y_start,
+                   double timestep, int settls_order, int interp_order, int cyclic_x,
+                   int t0, int nsteps,
+                   void *x_out, void *y_out, void *traj_x, void *traj_y);
 
 /* One interpolation pass on its own: tools.xr_map_coordinates (LCS/tools.py:11-41) for the
  * u and v fields of time level `level` at the given positions (degrees), same index

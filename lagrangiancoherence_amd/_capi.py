@@ -29,6 +29,7 @@ PROTOTYPES = {
     "lc_sync": (_i, [_vp]),
     "lc_ctx_set_lds_tiles": (_i, [_vp, _i]),
     "lc_ctx_set_sigma_march": (_i, [_vp, _i]),
+    "lc_ctx_set_level_chunk": (_i, [_vp, _i]),
     "lc_ctx_last_advect_kernel": (C.c_char_p, [_vp]),
     "lc_ctx_last_sigma_kernel": (C.c_char_p, [_vp]),
     "lc_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
@@ -42,6 +43,8 @@ PROTOTYPES = {
     "lc_spectral_truncate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lc_advect": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i,
                        _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lc_advect_from": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i, _vp, _vp,
+                            _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lc_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lc_sigma": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _d, _d, _i, _i, _i, _i, _vp]),
     "lc_flowmap_gradient": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _d, _d, _i, _vp]),

@@ -52,6 +52,12 @@ struct AdvectArgs {
     int K, order, cyclic, t0, nsteps;
     int wind_f32;  // double instantiation only: the wind is float32-valued -> numpy's promotion rules (Q10)
     T *x_out, *y_out, *traj_x, *traj_y;
+    const T *x_start, *y_start;  // NULL: start from the seed grid; else [ny*nx] positions to continue from (lc_advect_from)
+    int traj_skip0;              // 1: traj entry 0 (the start positions) is already in place (a later chunk of one call)
+    int traj_pair_ok, out_pair_ok;  // two-seed kernel, PATCH_WIDE: nx even and traj / out bases 8-byte aligned (paired stores)
+    int traj_line_ok;            // two-seed kernel, PATCH_LINES: nx % 4 == 0 and traj bases 16-byte aligned (whole-line stores)
+    int patch_mode;              // two-seed kernel: -1 by call (PATCH_LINES with trajectories, else PATCH_TALL), or a Patch value
+    int xcd_rows;                // tile rows per XCD chunk (xcd_chunk = xcd_rows * ntx, recomputed when a launcher changes ntx)
     int ntx, ntiles;
     int xcd_chunk;  // tiles per chunk of the XCD-cyclic tile order; 0: one contiguous band of tiles per XCD
     int tile_order;  // 0 as stored, 1 last tile row first, 2 from the poles inwards (xcd_tile_id)
@@ -95,6 +101,17 @@ template <typename T>
 struct Pair {
     T u, v;
 };
+
+// Starting position of seed (iy, ix): its grid point (trajectory.py:68-70), or where an earlier call left it
+// (lc_advect_from).  May alias x_out / y_out: every seed's start is read by the thread that later writes it.
+template <typename T>
+__device__ __forceinline__ T start_x(const AdvectArgs<T> &A, int iy, int ix) {
+    return A.x_start ? A.x_start[(size_t)iy * A.nx + ix] : A.seed_lon[ix];
+}
+template <typename T>
+__device__ __forceinline__ T start_y(const AdvectArgs<T> &A, int iy, int ix) {
+    return A.y_start ? A.y_start[(size_t)iy * A.nx + ix] : A.seed_lat[iy];
+}
 
 template <typename T>
 void set_fast_transform(AdvectArgs<T> &A) {
@@ -393,15 +410,16 @@ __device__ __forceinline__ T settls_bracket(const AdvectArgs<T> &A, T e, T c, T 
 template <typename T, int ORDER, bool WRAP, bool FUSED = false>
 __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image, int iy, int ix) {
 #pragma clang fp contract(off)
-    T x = A.seed_lon[ix];
-    T y = A.seed_lat[iy];
+    T x = start_x<T>(A, iy, ix);
+    T y = start_y<T>(A, iy, ix);
     // trajectory.py:56 -- 180 / (pi * R * |cos(lat * pi / 180)|), seed latitude (Q5)
-    const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((y * T(3.141592653589793)) / T(180))));
+    const T ys = A.seed_lat[iy];
+    const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((ys * T(3.141592653589793)) / T(180))));
     const T dtcx = A.dt * cx_conv;        // timestep * conversion_x
     const T hdtcx = A.half_dt * cx_conv;  // (0.5 * timestep) * conversion_x
     const size_t idx = (size_t)iy * A.nx + ix;
     const size_t plane = (size_t)A.ny * A.nx;
-    if (A.traj_x) {
+    if (A.traj_x && !A.traj_skip0) {
         A.traj_x[idx] = x;
         A.traj_y[idx] = y;
     }
@@ -566,16 +584,17 @@ __device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
 #pragma clang fp contract(fast)
     static_assert(ORDER >= 1 && ORDER <= 5, "interp_order");
     if (ORDER != 1 && ORDER != 3) return;  // general orders go through advect_seed (InteriorPath)
-    float x = A.seed_lon[ix];
-    float y = A.seed_lat[iy];
+    float x = start_x<float>(A, iy, ix);
+    float y = start_y<float>(A, iy, ix);
+    const float ys = A.seed_lat[iy];
     const float cx_conv =
-        180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((y * (float)3.141592653589793) / 180.0f)));
+        180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((ys * (float)3.141592653589793) / 180.0f)));
     const float dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
     const size_t idx = (size_t)iy * A.nx + ix;
     const size_t plane = (size_t)A.ny * A.nx;
     const unsigned row_bytes = (unsigned)A.pitch * 8u;
     const unsigned origin = ORDER == 3 ? 0u : row_bytes + 8u;  // order 3 window starts one node up/left
-    if (A.traj_x) {
+    if (A.traj_x && !A.traj_skip0) {
         A.traj_x[idx] = x;
         A.traj_y[idx] = y;
     }
@@ -905,14 +924,16 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     }
     if (__ballot(live) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
     // (longitude, latitude) in adjacent registers: index map and position update are packed operations
-    f2 p = {A.seed_lon[min(ix, A.nx - 1)], A.seed_lat[min(iy, A.ny - 1)]};
+    const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);
+    f2 p = {start_x<float>(A, sy_i, sx_i), start_y<float>(A, sy_i, sx_i)};
+    const float ys = A.seed_lat[sy_i];  // conversion_x is a function of the SEED latitude (Q5), wherever the parcel is now
     const float cx_conv =
-        180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((p.y * (float)3.141592653589793) / 180.0f)));
+        180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((ys * (float)3.141592653589793) / 180.0f)));
     const f2 dd = {A.dt * cx_conv, A.dtcy};        // degrees per (m/s) over a full step (trajectory.py:55-57,86-87)
     const f2 hd = {A.half_dt * cx_conv, A.hdtcy};  // ... over a SETTLS half step (trajectory.py:110-112)
     const size_t idx = live ? (size_t)iy * A.nx + ix : 0;
     const size_t plane = (size_t)A.ny * A.nx;
-    if (live && A.traj_x) {
+    if (live && A.traj_x && !A.traj_skip0) {
         A.traj_x[idx] = p.x;
         A.traj_y[idx] = p.y;
     }
@@ -1148,10 +1169,46 @@ __device__ unsigned long long g_redo[3][3][3];  // [latitude band 0-30 / 30-60 /
 #ifndef LCS_LDS2_NUM_SGPR
 #define LCS_LDS2_NUM_SGPR 96
 #endif
-template <int KFIX, bool CYCLIC>
+// Which seeds a wave holds, and how return_traj's positions reach memory (template parameter MODE).  Per-seed arithmetic
+// does not depend on it: results are bit-identical in every mode.
+//   PATCH_TALL   lane = column + 8 * row, the lane's second seed 8 rows further down: 8 x 16 seeds per wave, the four waves
+//                of a workgroup stacked in latitude (8 x 64).  The default without trajectories (fewest distinct lines per
+//                Euler gather: 6.47 ms on C3 against 6.85 for PATCH_WIDE).  With trajectories every store instruction
+//                writes 8 rows x 32 bytes: quarter-line partial writes, for each of which the L2 FETCHES the rest of the
+//                128-byte line (profiles/r03: +9.7 GB of fetches = 3/4 of the 12.9 GB stored, TCC_MISS x 7, advect
+//                6.5 -> 11.8 ms).
+//   PATCH_WIDE   the lane's second seed one column on: 16 x 8 seeds per wave, one 8-byte store per lane = 8 rows x 64
+//                bytes per instruction.  11.8 -> 11.2 ms; half lines still make the L2 fetch the other half.  Kept for A/B.
+//   PATCH_LINES  tall patches, the four waves SIDE BY SIDE in longitude (32 x 16 seeds per workgroup); after each time level
+//                the waves put their positions into an LDS slab, meet at ONE workgroup barrier (two slabs alternate, so one
+//                barrier per level is enough), and every wave writes a plane of 8 rows x 32 columns with one
+//                global_store_dwordx4 per lane: whole 128-byte lines.  The default with trajectories when nx % 4 == 0.
+enum Patch { PATCH_TALL = 0, PATCH_WIDE = 1, PATCH_LINES = 2 };
+// The whole-line trajectory store.  Measured on C3 with return_traj (advect ms, profiles/r03): plain 9.24-9.35, nontemporal
+// (`nt`: the written lines do not push the wind tiles out of the XCD's L2) 8.27-8.29, write-through sc1 9.16-9.29,
+// sc0 sc1 9.25-9.36.  -DLCS_TRAJ_STORE_KIND=0 plain, 1 nt (default), 2 sc1, 3 sc0 sc1.
+#ifndef LCS_TRAJ_STORE_KIND
+#define LCS_TRAJ_STORE_KIND 1
+#endif
+__device__ __forceinline__ void traj_store_line(float *dst, f4 v) {
+#if LCS_TRAJ_STORE_KIND == 1
+    __builtin_nontemporal_store(v, (f4 *)dst);
+#elif LCS_TRAJ_STORE_KIND == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");  // (s_nop: the >8-byte store-data hazard the compiler cannot see inside asm)
+#elif LCS_TRAJ_STORE_KIND == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#else
+    *(f4 *)dst = v;
+#endif
+}
+#define LCS_TRAJ_STORE(dst, v) traj_store_line(dst, v)
+constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byte aligned)
+
+template <int KFIX, bool CYCLIC, int MODE>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2_NUM_SGPR)))
     advect_lds2_kernel(const AdvectArgs<float> A) {
 #pragma clang fp contract(fast)
+    constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES;
     constexpr int ORDER = 1;
     const int K = KFIX >= 0 ? KFIX : A.K;
     typedef Lds2Geom G;
@@ -1164,13 +1221,18 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     constexpr int LT_PITCH = LT_COLS + 4;
     constexpr int WIN = 2, WOFF = LC_PAD_LO;
     __shared__ __attribute__((aligned(16))) f4 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
+    // PATCH_LINES: two slabs (alternating by level) of the workgroup's 16 x 32 longitudes and latitudes
+    __shared__ __attribute__((aligned(16))) float s_slab[2][2][LINES ? 16 * SLAB_PITCH : 4];
     if (pole_block(A)) return;
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ix = txi * TILE_W + (lane % TILE_W);
-    const int iy0 = tyi * (TILE_H * SPL) + wave * (8 * SPL) + lane / TILE_W;  // seed q sits 8 rows further down
+    // workgroup origin and the lane's first seed (see enum Patch)
+    const int ix0 = WIDE ? txi * (TILE_W * SPL) + SPL * (lane % TILE_W)
+                  : LINES ? txi * (TILE_W * 4) + wave * TILE_W + (lane % TILE_W) : txi * TILE_W + (lane % TILE_W);
+    const int iy0 = WIDE ? tyi * TILE_H + wave * 8 + lane / TILE_W
+                  : LINES ? tyi * (8 * SPL) + lane / TILE_W : tyi * (TILE_H * SPL) + wave * (8 * SPL) + lane / TILE_W;
     f4 *tile = s_tiles[wave];
 
     bool live[SPL];
@@ -1180,7 +1242,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     bool any = false;
 #pragma unroll
     for (int q = 0; q < SPL; ++q) {
-        const int iy = iy0 + 8 * q;
+        const int ix = ix0 + (WIDE ? q : 0), iy = iy0 + (WIDE ? 0 : 8 * q);
         live[q] = ix < A.nx && iy < A.ny;
         if (live[q]) {
             const int grow = A.row0 + iy;
@@ -1191,18 +1253,47 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
         }
         any |= live[q];
         // lanes without a seed shadow a neighbouring one so that they follow the same path; only their stores are masked
-        p[q] = (f2){A.seed_lon[min(ix, A.nx - 1)], A.seed_lat[min(iy, A.ny - 1)]};
+        const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);
+        p[q] = (f2){start_x<float>(A, sy_i, sx_i), start_y<float>(A, sy_i, sx_i)};
+        const float ys = A.seed_lat[sy_i];  // conversion_x is a function of the SEED latitude (Q5), wherever the parcel is now
         const float cx_conv =
-            180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((p[q].y * (float)3.141592653589793) / 180.0f)));
+            180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((ys * (float)3.141592653589793) / 180.0f)));
         dd[q] = (f2){A.dt * cx_conv, A.dtcy};        // trajectory.py:55-57,86-87
         hd[q] = (f2){A.half_dt * cx_conv, A.hdtcy};  // trajectory.py:110-112
         idx[q] = live[q] ? (size_t)iy * A.nx + ix : 0;
-        if (live[q] && A.traj_x) {
-            A.traj_x[idx[q]] = p[q].x;
-            A.traj_y[idx[q]] = p[q].y;
-        }
     }
-    if (__ballot(any) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
+    // WIDE: the lane's two positions are neighbours in memory -- one 8-byte store when both are live and 8-byte aligned
+    // (nx even and an aligned base: the launcher checks, A.traj_pair_ok)
+    const bool pair = WIDE && live[0] && live[1] && A.traj_pair_ok;
+    auto store_pair = [&](float *dx, float *dy, size_t off) {
+        if (pair) {
+            *(f2 *)(dx + off + idx[0]) = (f2){p[0].x, p[1].x};
+            *(f2 *)(dy + off + idx[0]) = (f2){p[0].y, p[1].y};
+        } else {
+#pragma unroll
+            for (int q = 0; q < SPL; ++q)
+                if (live[q]) {
+                    dx[off + idx[q]] = p[q].x;
+                    dy[off + idx[q]] = p[q].y;
+                }
+        }
+    };
+    if (A.traj_x && !A.traj_skip0) store_pair(A.traj_x, A.traj_y, 0);
+    // PATCH_LINES: whole-line stores for workgroups whose 32 columns are all inside the grid (the others, and grids whose
+    // rows are not 16-byte aligned, store per lane as above).  Workgroup-uniform: either all four waves meet at the
+    // level's barrier or none does -- so a wave without seeds stays in the loop (it shadows its neighbours' seeds).
+    const bool lines = LINES && A.traj_x && A.traj_line_ok && (txi + 1) * (TILE_W * 4) <= A.nx;
+    if (!lines && __ballot(any) == 0ull) return;  // whole wave (no workgroup barrier below unless `lines`)
+    // the 8 rows x 32 columns this wave writes per level: plane (wave >> 1: longitudes, latitudes), rows (wave & 1) * 8 ...
+    const int sl_row = (wave & 1) * 8 + (lane >> 3), sl_col = (lane & 7) * 4;
+    bool sl_ok = false;
+    size_t sl_idx = 0;
+    if (lines) {
+        const int iyr = tyi * (8 * SPL) + sl_row, grow = A.row0 + iyr;
+        sl_ok = iyr < A.ny && (A.pole_blocks == 0 || (grow >= A.order && grow < A.ny_global - A.order));  // pole rows: written by their own workgroups
+        if (!A.pole_blocks && iyr < A.ny && (grow < A.order || grow >= A.ny_global - A.order)) sl_ok = false;  // ... or by advect_seed above
+        sl_idx = (size_t)min(iyr, A.ny - 1) * A.nx + (size_t)txi * (TILE_W * 4) + sl_col;
+    }
     float ymax_v = A.y_max;
     asm volatile("" : "+v"(ymax_v));
     const unsigned tile_addr = lds_address(tile);
@@ -1222,7 +1313,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     // node c+2 of the lane's tile row (the x-difference of node c+1 needs it): loaded with the tile, 8 more bytes
     // per lane; the last lane of a row re-reads its own node instead (its entry c+1 is never a window origin)
     const unsigned st_next = st_off + (st_col + 2 < LT_COLS ? 16u : 0u);
-    constexpr int CENTRE = TILE_W / 2 + TILE_W * 7;  // seed 0 of the lane in the patch's 8th row: its middle
+    // seed 0 of the lane in the patch's middle: row 8 of 16 (tall patches), row 4 of 8 and column 8 of 16 (PATCH_WIDE)
+    constexpr int CENTRE = WIDE ? TILE_W / 2 + TILE_W * 4 : TILE_W / 2 + TILE_W * 7;
     const f2 zero = {0.0f, 0.0f};
     f2 dprev = {0.0f, 0.0f};
 #ifdef LCS_STAMPS
@@ -1409,12 +1501,26 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
             for (int q = 0; q < SPL; ++q) p[q] = pn[q];
         }
 #pragma unroll
-        for (int q = 0; q < SPL; ++q) {
-            p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);  // the level's one latitude clamp
-            if (live[q] && A.traj_x) {
-                A.traj_x[(size_t)(s + 1) * plane + idx[q]] = p[q].x;
-                A.traj_y[(size_t)(s + 1) * plane + idx[q]] = p[q].y;
+        for (int q = 0; q < SPL; ++q) p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);  // the level's one latitude clamp
+        if (LINES && lines) {
+            float *sx = s_slab[s & 1][0], *sy = s_slab[s & 1][1];
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                const int o = (lane / TILE_W + 8 * q) * SLAB_PITCH + wave * TILE_W + (lane % TILE_W);
+                sx[o] = p[q].x;
+                sy[o] = p[q].y;
             }
+            // LDS writes done, then the level's one barrier.  The slab written at level s is read below by other waves;
+            // it is written again at level s + 2, which every wave reaches only after the barrier of level s + 1, i.e.
+            // after every wave has finished these reads.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const f4 line = *(const f4 *)(s_slab[s & 1][wave >> 1] + sl_row * SLAB_PITCH + sl_col);
+            if (sl_ok) {
+                float *dst = ((wave >> 1) ? A.traj_y : A.traj_x) + (size_t)(s + 1) * plane + sl_idx;
+                LCS_TRAJ_STORE(dst, line);
+            }
+        } else if (A.traj_x) {
+            store_pair(A.traj_x, A.traj_y, (size_t)(s + 1) * plane);
         }
 #ifdef LCS_STAMPS
         asm volatile("" : : "v"(p[0].x), "v"(p[1].x));
@@ -1429,11 +1535,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
         for (int i = 0; i < 3; ++i) atomicAdd(&g_stamps[4 + i], acc_n[i]);
     }
 #endif
+    if (WIDE && pair && A.out_pair_ok) {
+        *(f2 *)(A.x_out + idx[0]) = (f2){p[0].x, p[1].x};
+        *(f2 *)(A.y_out + idx[0]) = (f2){p[0].y, p[1].y};
+    } else {
 #pragma unroll
-    for (int q = 0; q < SPL; ++q) {
-        if (live[q]) {
-            A.x_out[idx[q]] = p[q].x;
-            A.y_out[idx[q]] = p[q].y;
+        for (int q = 0; q < SPL; ++q) {
+            if (live[q]) {
+                A.x_out[idx[q]] = p[q].x;
+                A.y_out[idx[q]] = p[q].y;
+            }
         }
     }
 }
@@ -1452,23 +1563,42 @@ struct LdsLaunch<float, ORDER> {
         // measured cross-over between 2896^2 and 3500^2).  mode 1 / 2 force either (tests, A/B); 3 = by size.
         const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny >= (1ll << 23));
         if (ORDER == 1 && two_seed && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16) {
-            // two seeds per lane: a block covers 8 x 64 seeds
-            const int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
+            // two seeds per lane; a workgroup covers 8 x 64 seeds (PATCH_TALL), 16 x 32 (PATCH_WIDE) or 32 x 16 (PATCH_LINES)
+            const int mode = A.patch_mode >= 0 ? A.patch_mode : (A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 ? PATCH_LINES : PATCH_TALL);
+            int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
+            if (mode == PATCH_WIDE) {
+                A.ntx = (A.nx + TILE_W * SPL - 1) / (TILE_W * SPL);
+                nty = (A.ny + TILE_H - 1) / TILE_H;
+            } else if (mode == PATCH_LINES) {
+                A.ntx = (A.nx + TILE_W * 4 - 1) / (TILE_W * 4);
+                nty = (A.ny + 8 * SPL - 1) / (8 * SPL);
+            }
+            A.xcd_chunk = A.xcd_rows * A.ntx;
             A.ntiles = A.ntx * nty;
             A.tile_order = A.tile_order_two_seed;
             const int g2 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
-            if (A.K == 4 && A.cyclic) {
-                hipLaunchKernelGGL((advect_lds2_kernel<4, true>), dim3(g2), dim3(BLOCK), 0, st, A);
-                return "advect_lds2_kernel<4, true>";
-            } else if (A.K == 4) {
-                hipLaunchKernelGGL((advect_lds2_kernel<4, false>), dim3(g2), dim3(BLOCK), 0, st, A);
-                return "advect_lds2_kernel<4, false>";
-            } else if (A.cyclic) {
-                hipLaunchKernelGGL((advect_lds2_kernel<-1, true>), dim3(g2), dim3(BLOCK), 0, st, A);
-                return "advect_lds2_kernel<-1, true>";
+#define LC_LDS2(KF, CY, MD, NAME)                                                                      \
+    {                                                                                                  \
+        hipLaunchKernelGGL((advect_lds2_kernel<KF, CY, MD>), dim3(g2), dim3(BLOCK), 0, st, A);         \
+        return NAME;                                                                                   \
+    }
+            if (mode == PATCH_LINES) {
+                if (A.K == 4 && A.cyclic) LC_LDS2(4, true, PATCH_LINES, "advect_lds2_kernel<4, true, 2>")
+                if (A.K == 4) LC_LDS2(4, false, PATCH_LINES, "advect_lds2_kernel<4, false, 2>")
+                if (A.cyclic) LC_LDS2(-1, true, PATCH_LINES, "advect_lds2_kernel<-1, true, 2>")
+                LC_LDS2(-1, false, PATCH_LINES, "advect_lds2_kernel<-1, false, 2>")
             }
-            hipLaunchKernelGGL((advect_lds2_kernel<-1, false>), dim3(g2), dim3(BLOCK), 0, st, A);
-            return "advect_lds2_kernel<-1, false>";
+            if (mode == PATCH_WIDE) {
+                if (A.K == 4 && A.cyclic) LC_LDS2(4, true, PATCH_WIDE, "advect_lds2_kernel<4, true, 1>")
+                if (A.K == 4) LC_LDS2(4, false, PATCH_WIDE, "advect_lds2_kernel<4, false, 1>")
+                if (A.cyclic) LC_LDS2(-1, true, PATCH_WIDE, "advect_lds2_kernel<-1, true, 1>")
+                LC_LDS2(-1, false, PATCH_WIDE, "advect_lds2_kernel<-1, false, 1>")
+            }
+            if (A.K == 4 && A.cyclic) LC_LDS2(4, true, PATCH_TALL, "advect_lds2_kernel<4, true, 0>")
+            if (A.K == 4) LC_LDS2(4, false, PATCH_TALL, "advect_lds2_kernel<4, false, 0>")
+            if (A.cyclic) LC_LDS2(-1, true, PATCH_TALL, "advect_lds2_kernel<-1, true, 0>")
+            LC_LDS2(-1, false, PATCH_TALL, "advect_lds2_kernel<-1, false, 0>")
+#undef LC_LDS2
         }
         // the fixed-size tile must fit inside one padded time level
         if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return nullptr;
@@ -1729,9 +1859,18 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 int nx_f,
                 double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
-                int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, int wind_f32 = 0) {
+                int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, const void *x_start,
+                const void *y_start, int wind_f32 = 0) {
     AdvectArgs<T> A{};
     A.wind_f32 = wind_f32;
+    A.x_start = (const T *)x_start;
+    A.y_start = (const T *)y_start;
+    A.traj_skip0 = 0;
+    A.traj_pair_ok = (nx % 2 == 0) && ((size_t)traj_x % (2 * sizeof(T)) == 0) && ((size_t)traj_y % (2 * sizeof(T)) == 0);
+    A.out_pair_ok = (nx % 2 == 0) && ((size_t)x_out % (2 * sizeof(T)) == 0) && ((size_t)y_out % (2 * sizeof(T)) == 0);
+    A.traj_line_ok = (nx % 4 == 0) && ((size_t)traj_x % 16 == 0) && ((size_t)traj_y % 16 == 0) && sizeof(T) == 4;
+    A.patch_mode = ctx->patch_mode;
+    A.xcd_rows = ctx->xcd_chunk_rows;
     A.lin = (const T *)packed_lin;
     A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
     A.ext = (order == 1 || order == 3) ? (const T *)packed_ext : nullptr;  // general orders: two-sample form
@@ -1802,25 +1941,51 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // measured and dropped (it costs 5 % everywhere to save 8 % in that extreme).
     // lc_ctx_set_lds_tiles / LCS_LDS_TILES (read once at context creation) override (profiling).
     const bool use_lds = ctx->lds_tiles != 0;
-    const bool fused64 = sizeof(T) == 8 && A.ext != nullptr;  // opt-in single-sample iterations in float64
+    const bool fused64 = sizeof(T) == 8 && A.ext != nullptr;  // single-sample iterations in float64
     const char *name = nullptr;
-    if (order == 2 || order == 4 || order == 5) {  // generic direct kernel, any dtype
-        name = order == 2 ? DirectLaunch<T, 2>::launch(A, grid, ctx->stream)
-             : order == 4 ? DirectLaunch<T, 4>::launch(A, grid, ctx->stream) : DirectLaunch<T, 5>::launch(A, grid, ctx->stream);
-    } else if (order == 3) {
-        if (fused64) {
-            hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-            name = "advect_kernel<double, 3, true>";
-        } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
-            name = DirectLaunch<T, 3>::launch(A, grid, ctx->stream);
+    auto launch = [&](const AdvectArgs<T> &A) {
+        if (order == 2 || order == 4 || order == 5) {  // generic direct kernel, any dtype
+            name = order == 2 ? DirectLaunch<T, 2>::launch(A, grid, ctx->stream)
+                 : order == 4 ? DirectLaunch<T, 4>::launch(A, grid, ctx->stream) : DirectLaunch<T, 5>::launch(A, grid, ctx->stream);
+        } else if (order == 3) {
+            if (fused64) {
+                hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+                name = "advect_kernel<double, 3, true>";
+            } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
+                name = DirectLaunch<T, 3>::launch(A, grid, ctx->stream);
+            }
+        } else {
+            if (fused64) {
+                hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+                name = "advect_kernel<double, 1, true>";
+            } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
+                name = DirectLaunch<T, 1>::launch(A, grid, ctx->stream);
+            }
         }
-    } else {
-        if (fused64) {
-            hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
-            name = "advect_kernel<double, 1, true>";
-        } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
-            name = DirectLaunch<T, 1>::launch(A, grid, ctx->stream);
+    };
+    // Level chunks (lc_ctx_set_level_chunk): the series runs as consecutive launches of at most `chunk` time levels,
+    // each continuing from the positions the previous one left in x_out / y_out (a seed's start is read by the thread
+    // that writes its result, so in place is safe).  A launch's workgroups then stay within `chunk` levels of each
+    // other -- their tiles of the wind images meet in L2 / the Infinity Cache instead of being spread over the whole
+    // series (sparse seed grids: DESIGN 4) -- and the launch's tail is one chunk long.  Positions at a level's end are
+    // the kernels' whole state (the latitude clamp is applied before they are stored), so chunked == unchunked, bit
+    // for bit.
+    const int chunk = ctx->level_chunk > 0 ? ctx->level_chunk : (nsteps > 0 ? nsteps : 1);
+    const size_t plane_elems = (size_t)ny * nx;
+    for (int s0 = 0; s0 == 0 || s0 < nsteps; s0 += chunk) {
+        AdvectArgs<T> C = A;
+        C.t0 = t0 + s0;
+        C.nsteps = nsteps - s0 < chunk ? nsteps - s0 : chunk;
+        if (s0 > 0) {
+            C.x_start = A.x_out;
+            C.y_start = A.y_out;
+            C.traj_skip0 = 1;
+            if (A.traj_x) {
+                C.traj_x = A.traj_x + (size_t)s0 * plane_elems;
+                C.traj_y = A.traj_y + (size_t)s0 * plane_elems;
+            }
         }
+        launch(C);
     }
     ctx->last_advect_kernel = name;
     if (outer) {
@@ -1954,7 +2119,24 @@ extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed
                          const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx, int row0, int ny_global,
                          double timestep, int settls_order, int interp_order, int cyclic_x, int t0, int nsteps,
                          void *x_out, void *y_out, void *traj_x, void *traj_y) {
+    return lc_advect_from(ctx, packed_lin, packed_cub, packed_ext, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
+                          seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, nullptr, nullptr, timestep, settls_order,
+                          interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y);
+}
+
+extern "C" int lc_advect_from(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *packed_ext,
+                              int dtype, int nt, int ny_f, int nx_f, double lat_min, double lat_max, double lon_min,
+                              double lon_max, const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx, int row0,
+                              int ny_global, const void *x_start, const void *y_start, double timestep, int settls_order,
+                              int interp_order, int cyclic_x, int t0, int nsteps, void *x_out, void *y_out, void *traj_x,
+                              void *traj_y) {
     LC_REQUIRE(ctx, "lc_advect: null context");
+    LC_REQUIRE((x_start == nullptr) == (y_start == nullptr), "lc_advect_from: x_start and y_start must both be set or both NULL");
+    if (x_start && cyclic_x == LC_X_CLAMP_REFERENCE_OUTER) {
+        lc_set_error("lc_advect_from: LC_X_CLAMP_REFERENCE_OUTER restarts from the seed grid when a parcel leaves the box "
+                     "and cannot continue from given positions");
+        return LC_EUNSUPPORTED;
+    }
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64 || dtype == LC_F64_WIND_F32, "lc_advect: bad dtype %d", dtype);
     LC_REQUIRE(dtype != LC_F64_WIND_F32 || !packed_ext, "lc_advect: LC_F64_WIND_F32 keeps the two-sample form (no ext)");
     if (interp_order < 1 || interp_order > 5) {
@@ -1991,9 +2173,9 @@ extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed
     if (dtype == LC_F32)
         return advect_impl<float>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
                                   seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
-                                  interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y);
+                                  interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start);
     return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
                                seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
-                               interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y,
+                               interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start,
                                dtype == LC_F64_WIND_F32);
 }

@@ -52,6 +52,10 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     if (const char *ev = getenv("LCS_FIR_PREFILTER")) c->fir_prefilter = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);  // read once, here
     c->sigma_march = 2;  // by size
     if (const char *ev = getenv("LCS_SIGMA_MARCH")) c->sigma_march = ev[0] == '0' ? 0 : (ev[0] == '1' ? 1 : 2);  // read once, here
+    c->level_chunk = 0;
+    if (const char *ev = getenv("LCS_LEVEL_CHUNK")) c->level_chunk = atoi(ev) > 0 ? atoi(ev) : 0;  // read once, here
+    c->patch_mode = -1;
+    if (const char *ev = getenv("LCS_PATCH_MODE")) c->patch_mode = (ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : -1;  // read once, here
     c->lds_tiles_init = c->lds_tiles;
     c->sigma_march_init = c->sigma_march;
     c->last_advect_kernel = "";
@@ -72,6 +76,13 @@ extern "C" int lc_ctx_set_sigma_march(lc_ctx *ctx, int on) {
     LC_REQUIRE(ctx, "lc_ctx_set_sigma_march: null context");
     LC_REQUIRE(on >= -1 && on <= 1, "lc_ctx_set_sigma_march: on must be -1, 0 or 1");
     ctx->sigma_march = on < 0 ? ctx->sigma_march_init : on;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_set_level_chunk(lc_ctx *ctx, int levels) {
+    LC_REQUIRE(ctx, "lc_ctx_set_level_chunk: null context");
+    LC_REQUIRE(levels >= 0, "lc_ctx_set_level_chunk: levels must be >= 0 (0 = one launch for the whole series)");
+    ctx->level_chunk = levels;
     return LC_OK;
 }
 

@@ -108,6 +108,11 @@ class Engine:
         LDS tiles below), 1 marching kernel whatever the size, 0 LDS tiles."""
         _capi.check(self.lib.lc_ctx_set_sigma_march(self.ctx, int(on)), self.lib)
 
+    def set_level_chunk(self, levels: int):
+        """Run every advect call as consecutive launches of at most ``levels`` time levels (0: one launch).  Results are
+        bit-identical; it shapes the launches only (``lc_ctx_set_level_chunk``)."""
+        _capi.check(self.lib.lc_ctx_set_level_chunk(self.ctx, int(levels)), self.lib)
+
     def last_advect_kernel(self) -> str:
         """Name of the kernel the last :meth:`advect` call launched (as a profiler shows it)."""
         return self.lib.lc_ctx_last_advect_kernel(self.ctx).decode()
@@ -242,8 +247,11 @@ class Engine:
     # ------------------------------------------------------------------ K1
     def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
                cyclic_xboundary=True, t0=0, nsteps=None, return_traj=False, row0=0, ny_global=None, halo=None,
-               noncyclic_clamp=None):
+               noncyclic_clamp=None, start=None):
         """Departure points of the seed rows given.  Returns (x, y[, traj_x, traj_y]) device tensors.
+
+        ``start=(x, y)``: continue from these ``(ny, nx)`` positions instead of the seed grid (``lc_advect_from``):
+        levels [t0, t0+a) followed by [t0+a, t0+a+b) from the first call's result equals one call over a+b levels.
 
         ``noncyclic_clamp`` (only with ``cyclic_xboundary=False``): see :func:`x_boundary_mode`.
 
@@ -269,12 +277,18 @@ class Engine:
         if return_traj:
             tx = self._empty((nsteps + 1, ny, nx), dtype)
             ty = self._empty((nsteps + 1, ny, nx), dtype)
+        sx = sy = None
+        if start is not None:
+            sx, sy = (self.to_device(a, dtype) for a in start)
+            if tuple(sx.shape) != (ny, nx) or tuple(sy.shape) != (ny, nx):
+                raise ValueError(f"start positions must be two ({ny}, {nx}) arrays")
         self._use_current_stream()
-        _capi.check(self.lib.lc_advect(
+        _capi.check(self.lib.lc_advect_from(
             self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order != 1 else None),
             self._ptr(field.ext if field.order == interp_order else None),
             _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[dtype], field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max,
-            self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, float(timestep), int(SETTLS_order),
+            self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, self._ptr(sx), self._ptr(sy),
+            float(timestep), int(SETTLS_order),
             int(interp_order), x_boundary_mode(cyclic_xboundary, noncyclic_clamp, int(row0) == 0 and ny == ny_global),
             int(t0), nsteps, self._ptr(x), self._ptr(y), self._ptr(tx), self._ptr(ty)), self.lib)
         if halo:

@@ -49,7 +49,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 def test_bench_direct_kernel_is_named_as_such():
     d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--no-cpu-baseline", env={"LCS_LDS_TILES": "1"})
-    assert d["roofline"]["kernel"] == "advect_lds2_kernel<4, true>"      # forced: two seeds per lane whatever the size
+    assert d["roofline"]["kernel"] == "advect_lds2_kernel<4, true, 0>"      # forced: two seeds per lane whatever the size
     d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--settls", "0", "--no-cpu-baseline")
     assert d["roofline"]["kernel"] == "advect_kernel_f32<1>" and d["roofline"]["bound"] == "tcp"
     d = _bench("--steps", "1", "--warmup", "0", "--seeds", "256", "--nt", "5", "--no-cpu-baseline", env={"LCS_LDS_TILES": "0"})

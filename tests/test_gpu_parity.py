@@ -687,3 +687,89 @@ def test_non_finite_and_huge_wind_values_stay_contained(eng, dtype):
                 assert (~np.isfinite(xn)).mean() < 0.01
             sig = _np(eng.sigma(x, y, slat, slat[1] - slat[0], slon[1] - slon[0]))
             assert sig.shape == xn.shape
+
+
+# ------------------------------------------------------------------ continuation, level chunks, wide patches
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("order,lds", [(1, -1), (1, 1), (1, 2), (1, 0), (3, -1)])
+def test_advect_from_continues_bit_for_bit(eng, dtype, order, lds):
+    """lc_advect_from: levels [t0, t0+a) then [t0+a, t0+a+b) from the first call's positions == one call over a+b
+    levels, bit for bit, in every kernel family (two-seed / one-seed LDS tiles, direct gathers, float64), with
+    trajectories, in place, and on a row block with pole rows (LCS/trajectory.py:80-126 carries only positions)."""
+    u, v, lat, lon = flows.era5_like(nt=10, ny=60, nx=120)
+    u, v, lat, lon = (a.astype(dtype) for a in (u * 1.5, v, lat, lon))
+    slat, slon = (a.astype(dtype) for a in flows.seed_grid(141, 202, lat, lon))
+    f = eng.prepare_field(u, v, lat, lon, order)
+    kw = dict(SETTLS_order=4, interp_order=order, cyclic_xboundary=True)
+    try:
+        eng.set_lds_tiles(lds)
+        x, y, tx, ty = eng.advect(f, slat, slon, -1800.0, t0=1, nsteps=8, return_traj=True, **kw)
+        xa, ya, txa, tya = eng.advect(f, slat, slon, -1800.0, t0=1, nsteps=3, return_traj=True, **kw)
+        xb, yb, txb, tyb = eng.advect(f, slat, slon, -1800.0, t0=4, nsteps=5, return_traj=True, start=(xa, ya), **kw)
+        assert bool((xb == x).all()) and bool((yb == y).all())
+        assert bool((txa == tx[:4]).all()) and bool((txb == tx[3:]).all()) and bool((tyb == ty[3:]).all())
+        # a row block (global row offset: the lower pole rows are in it), without trajectories
+        lo, hi = 0, 77
+        xr, yr = eng.advect(f, slat[lo:hi], slon, -1800.0, t0=4, nsteps=5, row0=lo, ny_global=141,
+                            start=(xa[lo:hi], ya[lo:hi]), **kw)
+        assert bool((xr == x[lo:hi]).all()) and bool((yr == y[lo:hi]).all())
+    finally:
+        eng.set_lds_tiles(-1)
+
+
+@pytest.mark.parametrize("order,lds,traj", [(1, 1, False), (1, 1, True), (1, 2, True), (3, -1, False), (1, 0, True)])
+def test_level_chunks_do_not_change_results(eng, order, lds, traj):
+    """lc_ctx_set_level_chunk: the series as consecutive launches of 1 / 3 / 4 levels == one launch, bit for bit."""
+    u, v, lat, lon = flows.era5_like(nt=12, ny=60, nx=120)
+    slat, slon = flows.seed_grid(130, 210, lat, lon)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    kw = dict(SETTLS_order=4, interp_order=order, cyclic_xboundary=True, return_traj=traj)
+    try:
+        eng.set_lds_tiles(lds)
+        eng.set_level_chunk(0)
+        ref = eng.advect(f, slat, slon, -1800.0, **kw)
+        for chunk in (1, 3, 4, 64):
+            eng.set_level_chunk(chunk)
+            got = eng.advect(f, slat, slon, -1800.0, **kw)
+            for a, b in zip(ref, got):
+                assert bool((a == b).all()), (chunk, tuple(a.shape))
+    finally:
+        eng.set_level_chunk(0)
+        eng.set_lds_tiles(-1)
+    with pytest.raises(ValueError):
+        eng.set_level_chunk(-1)
+
+
+@pytest.mark.parametrize("sny,snx", [(130, 212), (131, 211), (64, 32), (40, 100), (23, 18), (200, 512)])
+def test_patch_modes_of_the_two_seed_kernel_agree_bitwise(sny, snx, monkeypatch):
+    """Which seeds a wave of the two-seed kernel holds and how trajectories are stored (LCS_PATCH_MODE: 0 tall patches,
+    per-lane stores; 1 wide patches, paired stores; 2 whole-line stores through an LDS slab and one workgroup barrier per
+    level, the default with trajectories) only decides which lane holds which seed: positions and trajectories are
+    bit-identical -- widths that are no multiple of 4 or 32 (per-lane fallback), grid edges, pole rows and level chunks
+    included."""
+    from lagrangiancoherence_amd.engine import Engine
+    u, v, lat, lon = flows.era5_like(nt=7, ny=60, nx=120)
+    slat, slon = flows.seed_grid(sny, snx, lat, lon)
+    out = {}
+    for flag in ("0", "1", "2", ""):
+        if flag:
+            monkeypatch.setenv("LCS_PATCH_MODE", flag)
+        else:
+            monkeypatch.delenv("LCS_PATCH_MODE")
+        e = Engine(0)
+        try:
+            e.set_lds_tiles(1)
+            f = e.prepare_field(u, v, lat, lon, 1)
+            out[flag] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=1, return_traj=True)]
+            want = flag or ("2" if snx % 4 == 0 and snx >= 32 else "0")      # the default: lines where rows are 16-byte aligned
+            assert e.last_advect_kernel() == "advect_lds2_kernel<4, true, %s>" % want
+            out[flag + "n"] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=1)]
+            e.set_level_chunk(4)
+            out[flag + "c"] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=2, interp_order=1, return_traj=True)]
+        finally:
+            e.close()
+    for flag in ("1", "2", ""):
+        for suffix in ("", "n", "c"):
+            for a, b in zip(out["0" + suffix], out[flag + suffix]):
+                assert np.array_equal(a, b), (flag, suffix)
+    assert np.array_equal(out["0"][0], out["0n"][0])

@@ -1,14 +1,14 @@
 #!/bin/bash
-# A/B timing of library variants on the GPU box.
-# usage: tools/ab.sh <outdir> "<bench args>" name1=path1.so name2=path2.so ...   (REPS alternating repeats, default 2)
+# A/B timing of run-time knobs on the GPU box (same library, different environment).
+# usage: tools/ab_env.sh <outdir> "<bench args>" name1="ENV1=a ENV2=b" name2="" ...   (each variant runs REPS times, alternating)
 OUT=$1; shift
 ARGS=$1; shift
 REPS=${REPS:-2}
 mkdir -p gpurun_out/$OUT
 for rep in $(seq 1 $REPS); do
   for kv in "$@"; do
-    name=${kv%%=*}; lib=${kv#*=}
-    LCS_LIB=$PWD/$lib python bench.py --no-cpu-baseline $ARGS > gpurun_out/$OUT/${name}_$rep.json 2> gpurun_out/$OUT/${name}_$rep.err || { echo "$name FAILED"; tail -3 gpurun_out/$OUT/${name}_$rep.err; }
+    name=${kv%%=*}; envs=${kv#*=}
+    env $envs python bench.py --no-cpu-baseline $ARGS > gpurun_out/$OUT/${name}_$rep.json 2> gpurun_out/$OUT/${name}_$rep.err || { echo "$name FAILED"; tail -3 gpurun_out/$OUT/${name}_$rep.err; }
   done
 done
 python - "$OUT" <<'PY'
