@@ -464,6 +464,12 @@ def main():
     nstreams = max(1, int(os.environ.get("LCS_MEMBER_STREAMS", "2"))) if wk == "c5" else 1
     side = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else []
 
+    # c5: LEVEL-MAJOR order over the members (sharded.ensemble_advect: every member's first chunk of levels, then every
+    # member's next ...), so consecutive launches share all but one of their time levels in the Infinity Cache / L2.
+    # LCS_ENSEMBLE_CHUNK=0 restores one launch per member.
+    ens_chunk = int(os.environ.get("LCS_ENSEMBLE_CHUNK", str(sharded.ENSEMBLE_CHUNK))) if wk == "c5" else 0
+    level_major = wk == "c5" and ens_chunk > 0 and len(members) > 1
+
     def one_step(record: bool):
         last.clear()
         cur = torch.cuda.current_stream()
@@ -472,6 +478,20 @@ def main():
         field = eng.prepare_field(ud, vd, lat, lon, order)
         pack[1].record()
         res, mm = None, []
+        if level_major:
+            m = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            m[0].record()
+            pos = sharded.ensemble_advect(eng, field, slat_d, slon_d, dt, members, nsteps, K, order, True, ens_chunk, nstreams)
+            m[1].record()          # (ensemble_advect has joined its streams into the current one)
+            m[2].record()
+            sig = None
+            for x, y in pos:
+                sig = eng.sigma(x, y, slat_d, dlat, dlon)
+            m[3].record()
+            if record:
+                ev_marks.append((pack, [m]))
+            last.update(sig=sig, x_ext=pos[-1][0], y_ext=pos[-1][1], field=field)
+            return
         with eng.concurrent_calls((hi - lo) * nx, max(len(side), 1)):   # the kernel choice sees the seeds in flight
             for i, e in enumerate(members):
                 if side:
@@ -515,7 +535,9 @@ def main():
         ev["halo"].append(sum(m[1].elapsed_time(m[2]) for m in mm))
         ev["sigma"].append(sum(m[2].elapsed_time(m[3]) for m in mm))
     ms = {k: float(np.mean(vv)) for k, vv in ev.items()}
-    if side:
+    if level_major:
+        ms["members_overlapped_wall"] = ms["advect"] + ms["sigma"]     # advect = the ensemble's wall on all streams
+    elif side:
         # members overlapped on several streams: the event brackets above overlap too.  Per-kernel durations for the
         # roofline objects come from ONE member run alone on the current stream, after the timed region; the sums
         # reported in kernel_ms are scaled from it, and the overlapped wall time is given beside them.
@@ -622,7 +644,10 @@ def main():
             **({"return_traj": True} if args.traj else {}),
             "step": "pack + fused advect + halo exchange + sigma" + (" per member" if wk == "c5" else "")
                     + "; u/v/seeds resident in HBM"
-                    + (f"; independent members alternate between {nstreams} HIP streams (kernel_ms advect/halo/sigma = "
+                    + (f"; members advected in level-major order, {ens_chunk} levels per launch, continuing in place "
+                       f"(lc_advect_from), launches alternating between {nstreams} HIP streams; kernel_ms.advect = the "
+                       "ensemble's wall time" if level_major else
+                       f"; independent members alternate between {nstreams} HIP streams (kernel_ms advect/halo/sigma = "
                        "members x one member run alone; members_overlapped_wall = what they take together)" if side else ""),
         },
         "advect_particle_timesteps_per_s": pts_launch * n_launch * world / (ms["advect"] / 1e3),

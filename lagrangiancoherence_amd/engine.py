@@ -247,8 +247,11 @@ class Engine:
     # ------------------------------------------------------------------ K1
     def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
                cyclic_xboundary=True, t0=0, nsteps=None, return_traj=False, row0=0, ny_global=None, halo=None,
-               noncyclic_clamp=None, start=None):
+               noncyclic_clamp=None, start=None, out=None):
         """Departure points of the seed rows given.  Returns (x, y[, traj_x, traj_y]) device tensors.
+
+        ``out=(x, y)``: write the results into these ``(ny, nx)`` tensors (may be the ``start`` tensors: in place)
+        instead of allocating.
 
         ``start=(x, y)``: continue from these ``(ny, nx)`` positions instead of the seed grid (``lc_advect_from``):
         levels [t0, t0+a) followed by [t0+a, t0+a+b) from the first call's result equals one call over a+b levels.
@@ -266,8 +269,17 @@ class Engine:
         ny_global = ny if ny_global is None else int(ny_global)
         nsteps = field.nt - 1 - t0 if nsteps is None else int(nsteps)
         n_lo, n_hi = halo if halo else (0, 0)
-        x_buf = self._empty((n_lo + ny + n_hi, nx), dtype)
-        y_buf = self._empty((n_lo + ny + n_hi, nx), dtype)
+        if out is not None:
+            if halo:
+                raise ValueError("out= and halo= cannot be combined")
+            x_buf, y_buf = out
+            want = getattr(self.torch, np.dtype(dtype).name)
+            for b in (x_buf, y_buf):
+                if tuple(b.shape) != (ny, nx) or b.dtype != want or not b.is_contiguous() or b.device != self.device:
+                    raise ValueError(f"out tensors must be contiguous ({ny}, {nx}) {np.dtype(dtype).name} tensors on {self.device}")
+        else:
+            x_buf = self._empty((n_lo + ny + n_hi, nx), dtype)
+            y_buf = self._empty((n_lo + ny + n_hi, nx), dtype)
         x, y = x_buf[n_lo:n_lo + ny], y_buf[n_lo:n_lo + ny]
         if halo:  # rows to be received: NaN until the exchange fills them, so a skipped exchange cannot pass unnoticed
             for buf in (x_buf, y_buf):

@@ -19,7 +19,7 @@ from __future__ import annotations
 HALO = 2  # rows; LCS/tools.py:202-207 (4th-order, +-2 points), SURVEY Q12
 
 __all__ = ["HALO", "row_partition", "halo_rows", "halo_exchange", "halo_exchange_into", "ensemble_partition",
-           "sharded_lcs", "ensemble_lcs", "native_comm"]
+           "sharded_lcs", "ensemble_lcs", "ensemble_advect", "native_comm", "ENSEMBLE_CHUNK"]
 
 
 def row_partition(ny_global: int, world: int, rank: int):
@@ -160,9 +160,52 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
     return {"sigma": sig, "x_dep": x, "y_dep": y, "rows": (lo, hi)}
 
 
+ENSEMBLE_CHUNK = 8   # time levels per launch of ensemble_advect's level-major order (measured on config 5)
+
+
+def ensemble_advect(engine, field, seed_lat, seed_lon, timestep, members, nsteps: int, SETTLS_order=0, interp_order=1,
+                    cyclic_xboundary=True, level_chunk=None, streams: int = 2):
+    """Departure points of ensemble members (member ``e`` = start level ``t0 = e``, ``nsteps`` steps), advected in
+    LEVEL-MAJOR order: every member's first ``level_chunk`` levels, then every member's next chunk, ... each launch
+    continuing in place from the member's positions (``lc_advect_from``).  Members ``e`` and ``e+1`` of a chunk read
+    time levels ``[e + c, e + c + chunk]`` and ``[e + 1 + c, ...]`` -- all but one in common -- so consecutive launches
+    find the wind images in the Infinity Cache / L2 instead of streaming every member's whole series from HBM one
+    after the other (config 5 on one MI355X: 345 -> see DESIGN 4).  Results are bit-identical to one launch per member
+    (the loop of LCS/trajectory.py:80-126 carries only positions from level to level).  ``level_chunk=0``: member-major,
+    one launch per member.  Returns ``[(x, y), ...]`` in the order of ``members``; all streams are joined before it returns."""
+    import numpy as np
+    import torch
+    members = list(members)
+    chunk = ENSEMBLE_CHUNK if level_chunk is None else int(level_chunk)
+    if chunk <= 0 or chunk >= nsteps:
+        chunk = max(nsteps, 1)
+    dtype = getattr(torch, np.dtype(field.dtype).name)
+    ny, nx = len(seed_lat), len(seed_lon)
+    slat, slon = engine.to_device(seed_lat, field.dtype), engine.to_device(seed_lon, field.dtype)
+    pos = [(torch.empty((ny, nx), dtype=dtype, device=engine.device), torch.empty((ny, nx), dtype=dtype, device=engine.device))
+           for _ in members]
+    cur = torch.cuda.current_stream(engine.device)
+    side = [torch.cuda.Stream(engine.device) for _ in range(int(streams))] if int(streams) > 1 and len(members) > 1 else []
+    for st in side:
+        st.wait_stream(cur)                  # the field, the seeds and the buffers above belong to the current stream
+    with engine.concurrent_calls(ny * nx, max(len(side), 1)):
+        for c0 in range(0, max(nsteps, 1), chunk):
+            n = min(chunk, nsteps - c0)
+            for i, e in enumerate(members):  # member i keeps its stream: its chunks stay in order
+                kw = dict(t0=e + c0, nsteps=n, start=pos[i] if c0 else None, out=pos[i])
+                if side:
+                    with torch.cuda.stream(side[i % len(side)]):
+                        engine.advect(field, slat, slon, timestep, SETTLS_order, interp_order, cyclic_xboundary, **kw)
+                else:
+                    engine.advect(field, slat, slon, timestep, SETTLS_order, interp_order, cyclic_xboundary, **kw)
+    for st in side:
+        cur.wait_stream(st)
+    return pos
+
+
 def ensemble_lcs(engine, field, seed_lat, seed_lon, timestep, n_members: int, nsteps: int, rank: int = 0,
                  world: int = 1, SETTLS_order=0, interp_order=1, cyclic_xboundary=True, fd_fp32_cast=True,
-                 tensor_layout="reference", return_dpts=False, streams: int = 2):
+                 tensor_layout="reference", return_dpts=False, streams: int = 2, level_chunk=None):
     """BASELINE config 5: member ``e`` starts at time level ``t0 = e`` and runs ``nsteps`` steps over the
     same seed grid.  Members are sharded over ranks in contiguous blocks; nothing is exchanged (gathering
     the sigma fields is the caller's business).  Returns ``(member_indices, sigma[len(members), ny, nx])``,
@@ -177,6 +220,20 @@ def ensemble_lcs(engine, field, seed_lat, seed_lon, timestep, n_members: int, ns
         raise ValueError(f"{n_members} members x {nsteps} steps need {n_members + nsteps} time levels, have {field.nt}")
     mine = ensemble_partition(n_members, world, rank)
     out, xs, ys = [], [], []
+    if (ENSEMBLE_CHUNK if level_chunk is None else int(level_chunk)) > 0 and len(mine) > 1:
+        # level-major advection of all of this rank's members (ensemble_advect), then sigma member by member
+        import numpy as np
+        seed_lat = np.asarray(seed_lat, dtype=field.dtype)
+        seed_lon = np.asarray(seed_lon, dtype=field.dtype)
+        pos = ensemble_advect(engine, field, seed_lat, seed_lon, timestep, mine, nsteps, SETTLS_order, interp_order,
+                              cyclic_xboundary, level_chunk, streams)
+        dlat, dlon = float(seed_lat[1] - seed_lat[0]), float(seed_lon[1] - seed_lon[0])
+        for x, y in pos:
+            out.append(engine.sigma(x, y, seed_lat, dlat, dlon, fd_fp32_cast=fd_fp32_cast, tensor_layout=tensor_layout))
+        st = lambda a: torch.stack(a) if a else None
+        if return_dpts:
+            return mine, st(out), st([p[0] for p in pos]), st([p[1] for p in pos])
+        return mine, st(out)
     cur = torch.cuda.current_stream(engine.device)
     side = [torch.cuda.Stream(engine.device) for _ in range(int(streams))] if int(streams) > 1 and len(mine) > 1 else []
 

@@ -575,6 +575,12 @@ def test_ensemble_members_are_t0_windows(eng, O):
         b = sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=5, nsteps=4, SETTLS_order=2, return_dpts=True,
                                  streams=ns)
         assert a[0] == b[0] and all(bool((x == y).all()) for x, y in zip(a[1:], b[1:]))
+    # level-major order (every member's first chunk of levels, then every member's next: ensemble_advect) == member by
+    # member (level_chunk=0), bit for bit, whatever the chunk and the number of streams
+    for chunk, ns in ((0, 1), (1, 2), (3, 1), (3, 3), (None, 2)):
+        b = sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=5, nsteps=4, SETTLS_order=2, return_dpts=True,
+                                 streams=ns, level_chunk=chunk)
+        assert a[0] == b[0] and all(bool((x == y).all()) for x, y in zip(a[1:], b[1:])), (chunk, ns)
 
 
 @pytest.mark.parametrize("order", [1, 3])
