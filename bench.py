@@ -290,7 +290,7 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {ny}x{nx} seeds = field nodes, moving ideal vortex, {nt} levels, "
                                f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order,
-                   **({"fuse_levels": True} if args.fuse_levels else {})},
+                   "fuse_levels": bool(args.fuse_levels)},
         "kernel_ms": ms,
         "roofline": roofline(eng.last_advect_kernel(), "valu", pts, ms["advect"], K, order, 8, 8, bool(args.fuse_levels),
                              comp, wl, csrc),
@@ -324,14 +324,17 @@ def main():
                     help="return_traj=True: also store the positions after every step (not the headline)")
     ap.add_argument("--wind-scale", type=float, default=1.0,
                     help="multiply the synthetic wind (stress case: stronger stretching; not the headline)")
-    ap.add_argument("--fuse-levels", action="store_true",
-                    help="c2 only: sample the fused image 2F[t]-F[t+1] once per SETTLS iteration in float64 too "
-                         "(rounding-level differences from the reference's two-sample order; default keeps that order)")
+    ap.add_argument("--exact-order", action="store_true",
+                    help="c2 only: numpy / scipy's exact operation order in float64 (two samples per SETTLS iteration, "
+                         "true divisions; fuse_levels=False) instead of the default fused-level form, which differs "
+                         "from it by rounding only (<= 1e-10 degrees on this configuration)")
+    ap.add_argument("--fuse-levels", action="store_true", help=argparse.SUPPRESS)   # the default since round 3
     ap.add_argument("--field", default=None, metavar="NY,NX",
                     help="resolution of the synthetic wind field (default 720,1440 = 0.25 degrees; not the "
                          "headline when changed: probes other seed-to-node density ratios)")
     ap.add_argument("--members", type=int, default=64, help="c5: ensemble members (start times)")
     args = ap.parse_args()
+    args.fuse_levels = not args.exact_order
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not a rank yet: start the ranks as fresh children BEFORE anything here touches the GPU (spawn_ranks above)

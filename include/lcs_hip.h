@@ -268,11 +268,12 @@ int lc_flowmap_gradient(lc_ctx *ctx, const void *x_dep, const void *y_dep, int d
                         int ny, int nx, const void *seed_lat_dev, double dlat, double dlon,
                         int fd_fp32_cast, void *def_tensor_out);
 
-/* tools.fourth_order_derivative (LCS/tools.py:190-228, the isglobal branch): 5-point
- * index-space difference of a [ny*nx] array along dim 0 (latitude; one-sided/2 on the
- * 2 first/last rows) or dim 1 (longitude, cyclic); result in the input dtype. */
+/* tools.fourth_order_derivative (LCS/tools.py:190-245): 5-point index-space difference of a [ny*nx] array along
+ * dim 0 (latitude; one-sided/2 on the 2 first/last rows, :210-217) or dim 1 (longitude: cyclic when isglobal != 0,
+ * :220-228, else one-sided/2 on the 2 first/last columns, :229-244; the reference ignores isglobal for dim 0 and so
+ * does this); result in the input dtype. */
 int lc_fourth_order_derivative(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int nx,
-                               int dim, void *out_dev);
+                               int dim, int isglobal, void *out_dev);
 
 /* ---- optional smoothing of the departure fields ----------------------------
  * Replaces scipy.ndimage.gaussian_filter(x, sigma) at LCS/LCS.py:187-190

@@ -48,7 +48,7 @@ PROTOTYPES = {
     "lc_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lc_sigma": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _d, _d, _i, _i, _i, _i, _vp]),
     "lc_flowmap_gradient": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _d, _d, _i, _vp]),
-    "lc_fourth_order_derivative": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "lc_fourth_order_derivative": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lc_gaussian_filter": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp]),
     "lc_ridge_classify": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _d, _vp, _vp, _vp, _vp]),
     "lc_comm_unique_id": (_i, [_vp, _sz]),

@@ -364,9 +364,9 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     LC_HIP_CHECK(hipMemcpyAsync(v.p, v_host, fbytes, hipMemcpyHostToDevice, st));
     LC_HIP_CHECK(hipMemcpyAsync(slat.p, seed_lat_host, ny * es, hipMemcpyHostToDevice, st));
     LC_HIP_CHECK(hipMemcpyAsync(slon.p, seed_lon_host, nx * es, hipMemcpyHostToDevice, st));
-    // float path: one combined sample per SETTLS iteration (ext image of the matching order)
+    // one combined sample per SETTLS iteration (ext image of the matching order), float32 and float64 alike
     const bool fusable = interp_order == 1 || interp_order == 3;
-    if (dtype == LC_F32 && settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
+    if (settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
     LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
     if (interp_order != 1) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, interp_order, cub.p, ext.p));
     LC_TRY(lc_advect(ctx, lin.p, cub.p, ext.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p,
@@ -502,7 +502,7 @@ extern "C" int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v
     LC_TRY(lin.alloc(pbytes));
     if (interp_order != 1) LC_TRY(cub.alloc(pbytes));
     const bool fusable = interp_order == 1 || interp_order == 3;
-    if (wdtype == LC_F32 && settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny, nx) * es));
+    if (settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny, nx) * es));
     LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
     if (interp_order != 1) LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, interp_order, cub.p, ext.p));
     LC_TRY(x.alloc(sbytes));

@@ -452,10 +452,11 @@ int sigma_impl(lc_ctx *ctx, const void *x_dep, const void *y_dep, int in_row0, i
     return LC_OK;
 }
 
-// tools.fourth_order_derivative on its own (LCS/tools.py:190-228, isglobal branch): index-space
-// stencil on a 2-D array, numba typing (S differences, double scaling, S store).
+// tools.fourth_order_derivative on its own (LCS/tools.py:190-245): index-space stencil on a 2-D array, numba typing
+// (S differences, double scaling, S store).  dim 1: cyclic in longitude when isglobal (:220-228), else the one-sided
+// difference / 2 on the two first and two last columns (:229-244), as dim 0 always does on its rows (:210-217).
 template <typename S>
-__global__ void index_derivative_kernel(const S *__restrict__ a, S *__restrict__ out, int ny, int nx, int dim) {
+__global__ void index_derivative_kernel(const S *__restrict__ a, S *__restrict__ out, int ny, int nx, int dim, int isglobal) {
 #pragma clang fp contract(off)
     const size_t n = (size_t)ny * nx;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -469,10 +470,17 @@ __global__ void index_derivative_kernel(const S *__restrict__ a, S *__restrict__
             else
                 r = (4.0 / 3.0) * (double)(a[i + nx] - a[i - nx]) / 2.0 -
                     (1.0 / 3.0) * (double)(a[i + 2 * (size_t)nx] - a[i - 2 * (size_t)nx]) / 4.0;
-        } else {
+        } else if (isglobal) {
             const S *row = a + (size_t)y * nx;
             const int xp1 = (x + 1) % nx, xm1 = (x - 1 + nx) % nx, xp2 = (x + 2) % nx, xm2 = (x - 2 + nx) % nx;
             r = (4.0 / 3.0) * (double)(row[xp1] - row[xm1]) / 2.0 - (1.0 / 3.0) * (double)(row[xp2] - row[xm2]) / 4.0;
+        } else {
+            if (x < 2)
+                r = (double)(a[i + 1] - a[i]) / 2.0;
+            else if (x >= nx - 2)
+                r = (double)(a[i] - a[i - 1]) / 2.0;
+            else
+                r = (4.0 / 3.0) * (double)(a[i + 1] - a[i - 1]) / 2.0 - (1.0 / 3.0) * (double)(a[i + 2] - a[i - 2]) / 4.0;
         }
         out[i] = (S)r;
     }
@@ -481,7 +489,7 @@ __global__ void index_derivative_kernel(const S *__restrict__ a, S *__restrict__
 }  // namespace
 
 extern "C" int lc_fourth_order_derivative(lc_ctx *ctx, const void *in_dev, int dtype, int ny, int nx, int dim,
-                                          void *out_dev) {
+                                          int isglobal, void *out_dev) {
     LC_REQUIRE(ctx, "lc_fourth_order_derivative: null context");
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_fourth_order_derivative: bad dtype %d", dtype);
     LC_REQUIRE(in_dev && out_dev && in_dev != out_dev, "lc_fourth_order_derivative: bad pointers");
@@ -492,10 +500,10 @@ extern "C" int lc_fourth_order_derivative(lc_ctx *ctx, const void *in_dev, int d
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     if (dtype == LC_F32)
         hipLaunchKernelGGL(index_derivative_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream,
-                           (const float *)in_dev, (float *)out_dev, ny, nx, dim);
+                           (const float *)in_dev, (float *)out_dev, ny, nx, dim, isglobal != 0);
     else
         hipLaunchKernelGGL(index_derivative_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
-                           (const double *)in_dev, (double *)out_dev, ny, nx, dim);
+                           (const double *)in_dev, (double *)out_dev, ny, nx, dim, isglobal != 0);
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }

@@ -169,10 +169,12 @@ class Engine:
         """Upload (if needed) and pack a wind series.  u, v: (nt, ny_f, nx_f).
 
         ``fuse_levels``: also build ext[t] = 2 F[t] - F[t+1] so each SETTLS iteration takes one
-        gather instead of two (linear interpolation => same value up to rounding).  Default: on for
-        float32 (which cannot be bit-identical to scipy's double evaluation anyway), off for float64
-        (keeps the reference's operation order and numpy/scipy's exact results; ``True`` there trades
-        that for speed -- positions move by ~1e-13 degrees)."""
+        gather instead of two (interpolation is linear in the field => the same value up to rounding).
+        Default: on, for float32 and -- since round 3 -- float64 (orders 1 and 3; float64 positions move by
+        <= 1e-10 degrees against the reference's operation order on config 2, inside the 1e-9 degrees the float64
+        parity tests state).  ``fuse_levels=False`` keeps numpy / scipy's exact operation order in float64
+        (two samples per iteration, true divisions, scipy's tap sum): results equal to the CPU oracle's to
+        ~1e-13 degrees, at 1.4x the time."""
         if interp_order not in (1, 2, 3, 4, 5):
             raise ValueError(f"interp_order {interp_order} unsupported (scipy's spline orders 1..5; "
                              "0 fails in the reference too, LCS/tools.py:24-30)")
@@ -193,7 +195,7 @@ class Engine:
         n = self.lib.lc_packed_elems(nt, ny_f, nx_f)
         self._use_current_stream()
         if fuse_levels is None:
-            fuse_levels = dtype == np.dtype(np.float32)
+            fuse_levels = True
         if wind_f32 or interp_order in (2, 4, 5):   # general orders: generic direct kernel, two-sample form
             fuse_levels = False
         ext = None
@@ -366,8 +368,8 @@ class Engine:
                                                  self._ptr(out)), self.lib)
         return out
 
-    def index_derivative(self, a, dim):
-        """tools.fourth_order_derivative(a, dim, isglobal=True) (LCS/tools.py:190-228); dtype preserved."""
+    def index_derivative(self, a, dim, isglobal=True):
+        """tools.fourth_order_derivative(a, dim, isglobal) (LCS/tools.py:190-245); dtype preserved."""
         torch = self.torch
         dtype = np.dtype(str(a.dtype).replace("torch.", ""))
         if dtype not in _NP2LC:
@@ -377,7 +379,7 @@ class Engine:
         out = self._empty((ny, nx), dtype)
         self._use_current_stream()
         _capi.check(self.lib.lc_fourth_order_derivative(self.ctx, self._ptr(ad), _NP2LC[dtype], ny, nx, int(dim),
-                                                        self._ptr(out)), self.lib)
+                                                        int(bool(isglobal)), self._ptr(out)), self.lib)
         return out
 
     def ridge_classify(self, hxx, hxy, hyy, gx, gy, tolerance, return_eigvec=False):

@@ -43,11 +43,9 @@ def xr_map_coordinates(da, new_x, new_y, isglobal=True, order=1):
 def fourth_order_derivative(arr, dim=0, isglobal=True):
     """4th-order 5-point difference in index space on a 2-D array, result in ``arr.dtype``.
     Signature of LCS/tools.py:191 (numba in the reference)."""
-    if not isglobal and dim == 1:
-        raise NotImplementedError("only the isglobal=True (cyclic longitude) branch is on the hot path")
     eng = get_engine()
     a = np.ascontiguousarray(arr)
-    return _to_np(eng.index_derivative(a, dim))
+    return _to_np(eng.index_derivative(a, dim, isglobal))
 
 
 def derivative_spherical_coords(da, dim=0, isglobal=True):
@@ -76,6 +74,8 @@ def find_ridges_spherical_hessian(da, sigma=.5, scheme='first_order', tolerance_
     gradient/eigenvector product is within ``tolerance_threshold`` and the Hessian eigenvalue of largest
     magnitude is negative, else 0.  Gaussian smoothing, the five float32-cast 4th-order derivatives and
     the per-point ``numpy.linalg.eig`` (a Python loop in the reference) all run on the device.
+    ``isglobal=False``: the longitude stencil is one-sided on the two first / last columns instead of cyclic
+    (tools.py:229-244); latitude is the same either way.
 
     ``return_eigvectors=True`` returns the reference's six-tuple (tools.py:140-147):
     ``(ridges, eigmin, raw product, eigvectors, gradient, angle)`` -- ``eigvectors`` has a leading
@@ -84,8 +84,6 @@ def find_ridges_spherical_hessian(da, sigma=.5, scheme='first_order', tolerance_
     leading ``elements`` dimension ``['ddadx', 'ddady']``; ``angle`` is ``180/pi * arctan(e0/e1)`` of the
     unmasked vector (tools.py:125).
     """
-    if not isglobal:
-        raise NotImplementedError("only the isglobal=True (cyclic longitude) branch is provided")
     dims = tuple(da.dims)
     lat, lon = _coord(da, "latitude"), _coord(da, "longitude")
     ilat, ilon = np.argsort(lat, kind="stable"), np.argsort(lon, kind="stable")       # tools.py:70-71
@@ -101,7 +99,7 @@ def find_ridges_spherical_hessian(da, sigma=.5, scheme='first_order', tolerance_
     dy = (np.pi / 180) * (lat[1] - lat[0]) * 6371000                                   # tools.py:256
 
     def D(f, dim):   # derivative_spherical_coords: float32 cast, index stencil, metric (tools.py:258-264)
-        d = eng.index_derivative(f.to(torch.float32), dim).to(torch.float64)
+        d = eng.index_derivative(f.to(torch.float32), dim, isglobal).to(torch.float64)   # isglobal: tools.py:77-81
         return d / dy if dim == 0 else d / dx
     ddadx, ddady = D(a, 1), D(a, 0)                                                    # tools.py:77-78
     d2x2, d2y2, dxdy = D(ddadx, 1), D(ddady, 0), D(ddadx, 0)                           # tools.py:79-81

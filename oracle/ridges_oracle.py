@@ -26,17 +26,18 @@ from .lcs_oracle import derivative_spherical_coords
 __all__ = ["find_ridges_spherical_hessian", "dlanv2_sym"]
 
 
-def find_ridges_spherical_hessian(values, lat, lon, sigma=.5, tolerance_threshold=0.0005e-3, return_eigvectors=False):
+def find_ridges_spherical_hessian(values, lat, lon, sigma=.5, tolerance_threshold=0.0005e-3, return_eigvectors=False,
+                                  isglobal=True):
     """values: (nlat, nlon), lat/lon ascending.  Returns (ridge mask, eigmin, dt_prod_raw), each (nlat, nlon);
     with ``return_eigvectors`` also (eigvectors (2, nlat, nlon) zeroed where eigmin >= 0, gradient (2, nlat, nlon),
     angle (nlat, nlon)) -- the extra members of the reference's six-tuple (tools.py:123-133,140-147).
-    tools.py:67-155 with isglobal=True."""
+    tools.py:67-155; ``isglobal`` goes to every derivative_spherical_coords call as in tools.py:77-81."""
     da = np.asarray(values, dtype=np.float64)
     if isinstance(sigma, (float, int)):
         da = gaussian_filter(da, sigma=sigma)                                     # tools.py:74-75
 
     def D(a, dim):
-        return derivative_spherical_coords(a, lat, lon, dim=dim)                  # float32 cast inside (R2)
+        return derivative_spherical_coords(a, lat, lon, dim=dim, isglobal=isglobal)   # float32 cast inside (R2)
     ddadx, ddady = D(da, 1), D(da, 0)                                             # tools.py:77-78
     d2dadx2, d2dady2, d2dadxdy = D(ddadx, 1), D(ddady, 0), D(ddadx, 0)            # tools.py:79-81
     hess = np.stack([d2dadx2, d2dadxdy, d2dadxdy, d2dady2]).reshape(4, -1)        # tools.py:87-90

@@ -142,6 +142,14 @@ def test_tools_helpers_vs_scipy_and_oracle():
     a32 = (1e6 * rng.standard_normal((29, 40))).astype(np.float32)
     for dim in (0, 1):
         assert np.array_equal(fourth_order_derivative(a32, dim=dim), O.fourth_order_derivative(a32, dim=dim))
+        for dt_ in (np.float32, np.float64):     # the regional branch (LCS/tools.py:229-244), bit for bit, both dtypes
+            a = a32.astype(dt_)
+            assert np.array_equal(fourth_order_derivative(a, dim=dim, isglobal=False),
+                                  O.fourth_order_derivative(a, dim=dim, isglobal=False))
+        dr = derivative_spherical_coords(labelled.DataArray(a32.astype(np.float64), ['latitude', 'longitude'],
+                                                            {'latitude': lat, 'longitude': lon}), dim=dim, isglobal=False)
+        np.testing.assert_allclose(dr.values, O.derivative_spherical_coords(a32.astype(np.float64), lat, lon, dim=dim,
+                                                                            isglobal=False), rtol=1e-15)
         d = derivative_spherical_coords(labelled.DataArray(a32.astype(np.float64), ['latitude', 'longitude'],
                                                            {'latitude': lat, 'longitude': lon}), dim=dim)
         np.testing.assert_allclose(d.values, O.derivative_spherical_coords(a32.astype(np.float64), lat, lon, dim=dim),

@@ -652,21 +652,23 @@ def test_lcs_host_float32_route(eng):
 
 @pytest.mark.parametrize("order", [1, 3])
 def test_float64_fused_levels_option(eng, O, order):
-    """prepare_field(fuse_levels=True) in float64: one sample of 2F[t]-F[t+1] per SETTLS iteration instead of
-    the reference's two.  Opt-in; results move by rounding only (the default path stays identical to the
-    oracle's operation order)."""
+    """float64 default (fuse_levels=True): one sample of 2F[t]-F[t+1] per SETTLS iteration, index map by multiplication,
+    fused lerps -- results move by rounding only.  fuse_levels=False keeps numpy / scipy's operation order (two samples,
+    true divisions, scipy's tap sum) and lands another three orders closer to the oracle."""
     u, v, lat, lon = flows.config2(n=96, nt=13)
-    f_exact = eng.prepare_field(u, v, lat, lon, order)
-    f_fused = eng.prepare_field(u, v, lat, lon, order, fuse_levels=True)
+    f_exact = eng.prepare_field(u, v, lat, lon, order, fuse_levels=False)
+    f_fused = eng.prepare_field(u, v, lat, lon, order)
     assert f_exact.ext is None and f_fused.ext is not None
     xe, ye = eng.advect(f_exact, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
+    assert eng.last_advect_kernel() == "advect_kernel<double, %d, false>" % order
     xf, yf = eng.advect(f_fused, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
+    assert eng.last_advect_kernel() == "advect_kernel<double, %d, true>" % order
     xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=order,
                                   cyclic_xboundary=True)
     for got, ref in ((xf, xo), (yf, yo)):
         d = np.abs(_np(got) - ref)
         assert np.minimum(d, np.abs(d - 360)).max() < 1e-10            # rounding-level (fp64 tolerance, degrees)
-    assert np.abs(_np(xe) - xo).max() < 1e-9 and np.abs(_np(ye) - yo).max() < 1e-9
+    assert np.abs(_np(xe) - xo).max() < 1e-12 and np.abs(_np(ye) - yo).max() < 1e-12
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -173,6 +173,15 @@ def test_kat7_stencil_polynomial():
     exp = (4 / 3) * (b[(jj + 1) % nx] - b[(jj - 1) % nx]) / 2 - (1 / 3) * (b[(jj + 2) % nx] - b[(jj - 2) % nx]) / 4
     np.testing.assert_allclose(d1[3], exp.astype(np.float32), rtol=1e-7)
     assert d0.dtype == np.float32 and d1.dtype == np.float32
+    # isglobal=False (LCS/tools.py:229-244): no wrap -- interior columns as before, the two first / last columns the
+    # one-sided difference divided by 2, exactly as dim 0 treats its rows; dim 0 itself ignores the flag
+    d1r = O.fourth_order_derivative(a32, dim=1, isglobal=False)
+    np.testing.assert_array_equal(d1r[:, 2:-2], d1[:, 2:-2])
+    for c in (0, 1):
+        np.testing.assert_array_equal(d1r[:, c], (a32[:, c + 1] - a32[:, c]) / 2)
+    for c in (nx - 1, nx - 2):
+        np.testing.assert_array_equal(d1r[:, c], (a32[:, c] - a32[:, c - 1]) / 2)
+    np.testing.assert_array_equal(O.fourth_order_derivative(a32, dim=0, isglobal=False), d0)
 
 
 def test_q7_cyclic_wrap_values():

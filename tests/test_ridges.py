@@ -130,3 +130,27 @@ def test_find_ridges_drop_in_vs_oracle():
         a_ref = np.where(np.isnan(ref6[5]), 0, ref6[5])
         a_got = np.where(np.isnan(six[5].values.T), 0, six[5].values.T)
         np.testing.assert_allclose(a_got[ok], a_ref[ok], rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_find_ridges_regional_branch_vs_oracle():
+    """find_ridges_spherical_hessian(isglobal=False) (LCS/tools.py:52-55,77-81): every derivative takes the regional
+    longitude stencil (one-sided on the two first / last columns, tools.py:229-244) instead of the cyclic one."""
+    from LagrangianCoherence.LCS.tools import find_ridges_spherical_hessian
+    from lagrangiancoherence_amd import labelled
+    lat = np.linspace(-30, 30, 61)
+    lon = np.linspace(-80, -20, 91)                                              # a regional box: nothing to wrap
+    LON, LAT = np.meshgrid(lon, lat)
+    f = np.exp(-((LAT - 0.3 * (LON + 50)) / 6.0) ** 2) + 0.1 * np.sin(np.deg2rad(9 * LON)) * np.cos(np.deg2rad(7 * LAT))
+    da = labelled.DataArray(f, ["latitude", "longitude"], {"latitude": lat, "longitude": lon}, name="ftle")
+    tol = 2e-7
+    out = {}
+    for g in (False, True):
+        ridges, eigmin = find_ridges_spherical_hessian(da, sigma=0.8, tolerance_threshold=tol, isglobal=g)
+        m_ref, e_ref, dt_ref = RO.find_ridges_spherical_hessian(f, lat, lon, sigma=0.8, tolerance_threshold=tol, isglobal=g)
+        np.testing.assert_allclose(eigmin.values, e_ref, rtol=1e-12, atol=1e-25)
+        borderline = np.abs(np.abs(dt_ref) - tol) < 1e-9 * tol
+        assert np.array_equal(ridges.values[~borderline], m_ref[~borderline])
+        out[g] = eigmin.values
+    # the two branches differ on the box's edge columns (second derivatives: 4 columns deep) and nowhere else
+    assert np.array_equal(out[False][:, 4:-4], out[True][:, 4:-4]) and not np.array_equal(out[False][:, :4], out[True][:, :4])
