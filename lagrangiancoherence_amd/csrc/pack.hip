@@ -389,26 +389,31 @@ __global__ void __launch_bounds__(64) prefilter_rows_lds_kernel(T *__restrict__ 
 
 // Order 1 in one pass over the PADDED image: every node (pads included) reads its mirrored
 // source once and writes lin[t] and, when asked, ext[t] = 2 F[t] - F[t+1].
+// A block takes 256 consecutive nodes of one padded row of one level (grid: x chunks, padded rows, levels): no
+// integer division anywhere -- the first form, one flat index per node decomposed with two 64-bit divisions, was bound
+// by that arithmetic, not by memory (C3: 0.60 ms for 3.4 GB; config 2 in float64 with both images: 2.5 ms for 10 GB).
 template <typename T>
-__global__ void pack_fused_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ lin,
-                                  T *__restrict__ ext, int nt, int ny, int nx) {
+__global__ void __launch_bounds__(256) pack_fused_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ lin,
+                                                         T *__restrict__ ext, int nt, int ny, int nx) {
     const int pitch = nx + LC_PAD;
-    const size_t level = (size_t)(ny + LC_PAD) * pitch;
-    const size_t plane = (size_t)ny * nx;
-    const size_t total = level * nt;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t t = i / level;
-        const size_t r = i - t * level;
-        const int py = (int)(r / pitch);
-        const int px = (int)(r - (size_t)py * pitch);
-        const int sy = mirror_index(py - LC_PAD_LO, ny), sx = mirror_index(px - LC_PAD_LO, nx);
-        const size_t src = t * plane + (size_t)sy * nx + sx;
-        const T a = u[src], b = v[src];
-        lin[2 * i] = a;
-        lin[2 * i + 1] = b;
-        if (ext && t + 1 < (size_t)nt) {
-            ext[2 * i] = T(2) * a - u[src + plane];
-            ext[2 * i + 1] = T(2) * b - v[src + plane];
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= pitch) return;
+    const size_t plane = (size_t)ny * nx, level = (size_t)(ny + LC_PAD) * pitch;
+    const int sx = mirror_index(px - LC_PAD_LO, nx);
+    for (int py = blockIdx.y; py < ny + LC_PAD; py += gridDim.y) {     // (the grid covers every row and level unless
+        const int sy = mirror_index(py - LC_PAD_LO, ny);               //  a dimension exceeds 65535 blocks)
+        const size_t so = (size_t)sy * nx + sx, po = (size_t)py * pitch + px;
+        for (int t = blockIdx.z; t < nt; t += gridDim.z) {
+            const T *us = u + (size_t)t * plane, *vs = v + (size_t)t * plane;
+            const T a = us[so], b = vs[so];
+            T *l = lin + ((size_t)t * level + po) * 2;
+            l[0] = a;
+            l[1] = b;
+            if (ext && t + 1 < nt) {
+                T *e = ext + ((size_t)t * level + po) * 2;
+                e[0] = T(2) * a - us[plane + so];
+                e[1] = T(2) * b - vs[plane + so];
+            }
         }
     }
 }
@@ -417,26 +422,29 @@ __global__ void pack_fused_kernel(const T *__restrict__ u, const T *__restrict__
 // reads its mirrored interior source at levels t and t+1 (interior nodes are final by now), writes its own pad
 // of img[t] if it is one, and its node of ext[t].  Replaces fill_pads_kernel + extrapolate_kernel.
 template <typename T>
-__global__ void pads_ext_kernel(T *__restrict__ img, T *__restrict__ ext, int nt, int ny, int nx) {
+__global__ void __launch_bounds__(256) pads_ext_kernel(T *__restrict__ img, T *__restrict__ ext, int nt, int ny, int nx) {
+    // same decomposition as pack_fused_kernel: 256 nodes of one padded row per block, no integer division
     const int pitch = nx + LC_PAD;
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= pitch) return;
     const size_t level = (size_t)(ny + LC_PAD) * pitch;
-    const size_t total = level * nt;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t t = i / level;
-        const size_t r = i - t * level;
-        const int py = (int)(r / pitch), px = (int)(r - (size_t)py * pitch);
-        const int y = py - LC_PAD_LO, x = px - LC_PAD_LO;
+    const int x = px - LC_PAD_LO, sx = mirror_index(x, nx);
+    for (int py = blockIdx.y; py < ny + LC_PAD; py += gridDim.y) {
+        const int y = py - LC_PAD_LO, sy = mirror_index(y, ny);
         const bool pad = !(y >= 0 && y < ny && x >= 0 && x < nx);
-        const int sy = mirror_index(y, ny), sx = mirror_index(x, nx);
-        const size_t sidx = (t * level + (size_t)(sy + LC_PAD_LO) * pitch + (sx + LC_PAD_LO)) * 2;
-        const T a = img[sidx], b = img[sidx + 1];
-        if (pad) {
-            img[2 * i] = a;
-            img[2 * i + 1] = b;
-        }
-        if (t + 1 < (size_t)nt) {
-            ext[2 * i] = T(2) * a - img[sidx + level * 2];
-            ext[2 * i + 1] = T(2) * b - img[sidx + level * 2 + 1];
+        const size_t so = ((size_t)(sy + LC_PAD_LO) * pitch + (sx + LC_PAD_LO)) * 2, po = ((size_t)py * pitch + px) * 2;
+        for (int t = blockIdx.z; t < nt; t += gridDim.z) {
+            T *lv = img + (size_t)t * level * 2;
+            const T a = lv[so], b = lv[so + 1];
+            if (pad) {
+                lv[po] = a;
+                lv[po + 1] = b;
+            }
+            if (t + 1 < nt) {
+                T *e = ext + (size_t)t * level * 2;
+                e[po] = T(2) * a - lv[level * 2 + so];
+                e[po + 1] = T(2) * b - lv[level * 2 + so + 1];
+            }
         }
     }
 }
@@ -577,8 +585,9 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
     const size_t nodes = (size_t)nt * ny * nx;
     const int threads = 256;
     if (order == 1) {
-        hipLaunchKernelGGL(pack_fused_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, u, v, packed, ext, nt, ny,
-                           nx);
+        // (grid.y and grid.z are capped at 65535 blocks: the kernel loops over what is beyond)
+        hipLaunchKernelGGL(pack_fused_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nt < 65535 ? nt : 65535),
+                           dim3(threads), 0, ctx->stream, u, v, packed, ext, nt, ny, nx);
         LC_HIP_CHECK(hipGetLastError());
         return LC_OK;
     }
@@ -592,7 +601,7 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
             hipLaunchKernelGGL(prefilter_fir_kernel, grid, dim3(256), 0, ctx->stream, u, v, packed, both ? ext : nullptr, nt, ny, nx,
                                cubic_fir_taps());
             if (ext && nt >= 2 && !both)  // ext = 2 img[t] - img[t+1] from the finished coefficients (pads rewritten, same values)
-                hipLaunchKernelGGL(pads_ext_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
+                hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nt < 65535 ? nt : 65535), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
             LC_HIP_CHECK(hipGetLastError());
             return LC_OK;
         }
@@ -622,7 +631,7 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
                            ny, nx, 1, P);
     }
     if (ext && nt >= 2)   // pads + fused-level image in one pass
-        hipLaunchKernelGGL(pads_ext_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
+        hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nt < 65535 ? nt : 65535), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
     else
         hipLaunchKernelGGL(fill_pads_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
     LC_HIP_CHECK(hipGetLastError());
