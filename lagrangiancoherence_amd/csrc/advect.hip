@@ -1549,6 +1549,282 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2
     }
 }
 
+// ======================================================================================
+// Order 3 (the reference's default, LCS/trajectory.py:16), TWO seeds per lane.
+//
+// advect_lds_kernel<3> with the seed patches, the patch modes and the trajectory stores of advect_lds2_kernel: a wave
+// advects 8 x 16 seeds, so the per-wave work of a time level -- anchoring and staging the 32 x 16-node tile of ext[t]
+// and the 16 x 8-node tile of img[t], the scalar bookkeeping, one rare branch per sample -- is shared by 128 seeds
+// instead of 64, and two independent 16-tap windows are in flight per lane.  Arithmetic per seed is exactly the
+// one-seed kernel's (cubic_apply on the same taps): results are bit-identical to it and to the direct-gather kernel.
+// ======================================================================================
+template <int MODE>
+struct PatchLanes {  // the lane's SPL seeds: where they are in the grid, their state, how they are stored (enum Patch)
+    static constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES;
+    bool live[SPL], any, pair, lines, sl_ok;
+    f2 p[SPL], dd[SPL], hd[SPL];
+    size_t idx[SPL], sl_idx, plane;
+    int lane, wave, sl_row, sl_col;
+
+    __device__ __forceinline__ void init(const AdvectArgs<float> &A, int txi, int tyi) {
+        lane = threadIdx.x & 63;
+        wave = threadIdx.x >> 6;
+        plane = (size_t)A.ny * A.nx;
+        const int ix0 = WIDE ? txi * (TILE_W * SPL) + SPL * (lane % TILE_W)
+                      : LINES ? txi * (TILE_W * 4) + wave * TILE_W + (lane % TILE_W) : txi * TILE_W + (lane % TILE_W);
+        const int iy0 = WIDE ? tyi * TILE_H + wave * 8 + lane / TILE_W
+                      : LINES ? tyi * (8 * SPL) + lane / TILE_W : tyi * (TILE_H * SPL) + wave * (8 * SPL) + lane / TILE_W;
+        any = false;
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+            const int ix = ix0 + (WIDE ? q : 0), iy = iy0 + (WIDE ? 0 : 8 * q);
+            live[q] = ix < A.nx && iy < A.ny;
+            if (live[q]) {
+                const int grow = A.row0 + iy;
+                if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path, whole integration (Q3)
+                    if (!A.pole_blocks) advect_seed<float, 1, false>(A, A.lin, iy, ix);  // (else the leading workgroups did them)
+                    live[q] = false;
+                }
+            }
+            any |= live[q];
+            // lanes without a seed shadow a neighbouring one so that they follow the same path; only their stores are masked
+            const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);
+            p[q] = (f2){start_x<float>(A, sy_i, sx_i), start_y<float>(A, sy_i, sx_i)};
+            const float ys = A.seed_lat[sy_i];  // conversion_x is a function of the SEED latitude (Q5)
+            const float cx_conv =
+                180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((ys * (float)3.141592653589793) / 180.0f)));
+            dd[q] = (f2){A.dt * cx_conv, A.dtcy};        // trajectory.py:55-57,86-87
+            hd[q] = (f2){A.half_dt * cx_conv, A.hdtcy};  // trajectory.py:110-112
+            idx[q] = live[q] ? (size_t)iy * A.nx + ix : 0;
+        }
+        pair = WIDE && live[0] && live[1] && A.traj_pair_ok;
+        // PATCH_LINES: whole-line stores for workgroups whose 32 columns are all inside the grid; workgroup-uniform
+        lines = LINES && A.traj_x && A.traj_line_ok && (txi + 1) * (TILE_W * 4) <= A.nx;
+        sl_row = (wave & 1) * 8 + (lane >> 3);
+        sl_col = (lane & 7) * 4;
+        sl_ok = false;
+        sl_idx = 0;
+        if (lines) {
+            const int iyr = tyi * (8 * SPL) + sl_row, grow = A.row0 + iyr;
+            sl_ok = iyr < A.ny && grow >= A.order && grow < A.ny_global - A.order;  // (pole rows are written by their own threads)
+            sl_idx = (size_t)min(iyr, A.ny - 1) * A.nx + (size_t)txi * (TILE_W * 4) + sl_col;
+        }
+    }
+    __device__ __forceinline__ void store_lanes(float *dx, float *dy, size_t off) const {
+        if (pair) {
+            *(f2 *)(dx + off + idx[0]) = (f2){p[0].x, p[1].x};
+            *(f2 *)(dy + off + idx[0]) = (f2){p[0].y, p[1].y};
+        } else {
+#pragma unroll
+            for (int q = 0; q < SPL; ++q)
+                if (live[q]) {
+                    dx[off + idx[q]] = p[q].x;
+                    dy[off + idx[q]] = p[q].y;
+                }
+        }
+    }
+    // positions after time level s -> traj entry s + 1 (slab: the workgroup's [2 slabs][2 planes][16 * SLAB_PITCH] floats)
+    __device__ __forceinline__ void store_level(const AdvectArgs<float> &A, float *slab, int s) const {
+        if (LINES && lines) {
+            float *sx = slab + (size_t)(s & 1) * 2 * 16 * SLAB_PITCH, *sy = sx + 16 * SLAB_PITCH;
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                const int o = (lane / TILE_W + 8 * q) * SLAB_PITCH + wave * TILE_W + (lane % TILE_W);
+                sx[o] = p[q].x;
+                sy[o] = p[q].y;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (one barrier per level: see advect_lds2_kernel)
+            const f4 line = *(const f4 *)(((wave >> 1) ? sy : sx) + sl_row * SLAB_PITCH + sl_col);
+            if (sl_ok) LCS_TRAJ_STORE(((wave >> 1) ? A.traj_y : A.traj_x) + (size_t)(s + 1) * plane + sl_idx, line);
+        } else if (A.traj_x) {
+            store_lanes(A.traj_x, A.traj_y, (size_t)(s + 1) * plane);
+        }
+    }
+    __device__ __forceinline__ void store_final(const AdvectArgs<float> &A) const {
+        if (WIDE && pair && A.out_pair_ok) {
+            *(f2 *)(A.x_out + idx[0]) = (f2){p[0].x, p[1].x};
+            *(f2 *)(A.y_out + idx[0]) = (f2){p[0].y, p[1].y};
+        } else {
+#pragma unroll
+            for (int q = 0; q < SPL; ++q)
+                if (live[q]) {
+                    A.x_out[idx[q]] = p[q].x;
+                    A.y_out[idx[q]] = p[q].y;
+                }
+        }
+    }
+};
+
+// 97 VGPRs as compiled = 4 waves per SIMD; asked for 5 (96 VGPRs) it measures 16.05-16.1 ms on C3 against 16.6-16.7, asked
+// for 6 (spills) 17.4; the one-seed kernel 17.2 on the same box (profiles/r03).
+#ifndef LCS_LDS2_O3_MINWAVES
+#define LCS_LDS2_O3_MINWAVES 5
+#endif
+template <int KFIX, bool CYCLIC, int MODE>
+__global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_kernel(const AdvectArgs<float> A) {
+#pragma clang fp contract(fast)
+    constexpr int ORDER = 3;
+    constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES;
+    const int K = KFIX >= 0 ? KFIX : A.K;
+    typedef TileGeom<ORDER> G;
+    typedef EulerGeom<ORDER> E;
+    static_assert(E::ON, "the two-seed order-3 kernel takes its Euler sample from the LDS tile of img[t]");
+    constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
+    constexpr int WIN = ORDER + 1, WOFF = 0;  // padded window origin = (y0, x0): one node up / left of the cell
+    __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH + E::ELEMS];
+    __shared__ __attribute__((aligned(16))) float s_slab[2][2][LINES ? 16 * SLAB_PITCH : 4];
+    if (pole_block(A)) return;
+    const int tile_id = xcd_tile_id(A);
+    if (tile_id >= A.ntiles) return;  // whole block
+    const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
+    PatchLanes<MODE> L;
+    L.init(A, txi, tyi);
+    if (A.traj_x && !A.traj_skip0) L.store_lanes(A.traj_x, A.traj_y, 0);
+    if (!L.lines && __ballot(L.any) == 0ull) return;  // whole wave (no workgroup barrier below unless `lines`)
+    const int lane = L.lane;
+    f2 *tile = s_tiles[L.wave], *etile = tile + LT_ROWS * LT_PITCH;
+    float ymax_v = A.y_max;
+    asm volatile("" : "+v"(ymax_v));
+    const unsigned tile_addr = lds_address(tile), etile_addr = lds_address(etile);
+    unsigned pitch_bytes = (unsigned)LT_PITCH * 8u, epitch_bytes = (unsigned)E::PITCH * 8u;
+    asm volatile("" : "+s"(pitch_bytes));
+    asm volatile("" : "+s"(epitch_bytes));
+    const f2 pmin = {A.lon_min, A.lat_min}, sc = {A.sx, A.sy};
+    auto to_index = [&](f2 v) { return (v - pmin) * sc; };  // subtract first: exact 0 at the grid origin
+    const float xlo = A.x_min, xhi = A.x_max;
+    auto x_needs_care = [&](float x) { return CYCLIC ? !(fabsf(x) < 180.0f) : !((x > xlo) & (x < xhi)); };
+    const float *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    const float kpred = 0.5f * (float)(K > 0 ? K - 1 : 0);
+    const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
+    const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 8u;
+    constexpr int NPASS = LT_ROWS / G::ROWS_PER_PASS;
+    const int e_row = lane / E::LANES_PER_ROW, e_col = (lane % E::LANES_PER_ROW) * 2;
+    const unsigned e_off = ((unsigned)e_row * (unsigned)pad_cols + (unsigned)e_col) * 8u;
+    constexpr int CENTRE = WIDE ? TILE_W / 2 + TILE_W * 4 : TILE_W / 2 + TILE_W * 7;  // seed 0 of the lane in the patch's middle
+    const f2 zero = {0.0f, 0.0f};
+    f2 (&p)[SPL] = L.p;
+    for (int s = 0; s < A.nsteps; ++s) {
+        // ---- 1. Euler samples out of a 16 x 8-node tile of img[t] around the patch's current position -----------
+        f2 c0[SPL], e[SPL], pn[SPL];
+        TapL t0[SPL];
+        bool bad[SPL], anybad = false;
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+            c0[q] = to_index(p[q]);
+            t0[q] = tap_of(c0[q]);
+            bad[q] = ((unsigned)t0[q].x0 > (unsigned)(A.nx_f - 2)) | ((unsigned)t0[q].y0 > (unsigned)(A.ny_f - 2));
+        }
+        {
+            const int exm = __builtin_amdgcn_readlane(t0[0].x0, CENTRE), eym = __builtin_amdgcn_readlane(t0[0].y0, CENTRE);
+            const int eox = min(max(exm + WOFF - (E::COLS - WIN) / 2, 0), pad_cols - E::COLS);
+            const int eoy = min(max(eym + WOFF - (E::ROWS - WIN) / 2, 0), pad_rows - E::ROWS);
+            const char *src = (const char *)lvl + ((size_t)__umul24((unsigned)eoy, (unsigned)pad_cols) + (unsigned)eox) * 8;
+            f4 es[E::NPASS];
+#pragma unroll
+            for (int r = 0; r < E::NPASS; ++r)
+                __builtin_memcpy(&es[r], src + (size_t)(r * E::ROWS_PER_PASS) * pad_cols * 8 + e_off, 16);
+            __builtin_amdgcn_wave_barrier();  // the previous level's reads of this region are done
+#pragma unroll
+            for (int r = 0; r < E::NPASS; ++r) *(f4 *)(etile + (r * E::ROWS_PER_PASS + e_row) * E::PITCH + e_col) = es[r];
+            __builtin_amdgcn_wave_barrier();
+            // window origins the tile serves: inside it AND in [0, n-2]
+            const int sox = eox - WOFF, soy = eoy - WOFF;
+            const int hx = min(sox + E::COLS - WIN, A.nx_f - 2), hy = min(soy + E::ROWS - WIN, A.ny_f - 2);
+            const int lx = max(sox, 0), ly = max(soy, 0);
+            const unsigned ebase = etile_addr + (unsigned)(lx - sox) * 8u + (unsigned)(ly - soy) * ((unsigned)E::PITCH * 8u);
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                const int rx = t0[q].x0 - lx, ry = t0[q].y0 - ly;
+                bad[q] |= ((unsigned)rx > (unsigned)(hx - lx)) | ((unsigned)ry > (unsigned)(hy - ly)) | (hx < lx) | (hy < ly);
+                e[q] = window_lds<ORDER, E::PITCH>(ebase, epitch_bytes, rx, ry, t0[q], zero);
+                pn[q] = L.dd[q] * e[q] + p[q];
+                bad[q] |= x_needs_care(pn[q].x);
+                anybad |= bad[q];
+            }
+        }
+        if (anybad) {  // exact sequence for the lanes / seeds that need it
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                if (bad[q]) {
+                    const TapL t = tap_of(index_coords(A, p[q]));
+                    e[q] = window_global<ORDER>(lvl, A, t, zero);
+                    pn[q] = L.dd[q] * e[q] + p[q];
+                    clamp_position_p(A, pn[q], ymax_v);
+                }
+            }
+        }
+        const f2 dnow = (pn[0] - p[0]) * sc;  // this level's Euler displacement in index space
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) p[q] = pn[q];
+        // ---- 2. tile of ext[t], anchored on the centre lane's travel as this level's displacement predicts it --------
+        int lo_x = 0x40000000, lo_y = 0x40000000, lim_x = 0, lim_y = 0;  // no tile: nothing is "inside"
+        unsigned base_addr = tile_addr;
+        if (K > 0) {
+            const f2 ca = dnow * (1.0f + kpred) + c0[0];
+            const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
+            const int rym = __builtin_amdgcn_readlane((int)floor_to_uint(ca.y), CENTRE);
+            const int ox = min(max(rxm + WOFF - (LT_COLS - WIN) / 2, 0), pad_cols - LT_COLS);
+            const int oy = min(max(rym + WOFF - (LT_ROWS - WIN) / 2, 0), pad_rows - LT_ROWS);
+            const char *src = (const char *)elv + ((size_t)__umul24((unsigned)oy, (unsigned)pad_cols) + (unsigned)ox) * 8;
+            f4 stage[NPASS];
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r)
+                __builtin_memcpy(&stage[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_off, 16);
+            __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r) *(f4 *)(tile + (r * G::ROWS_PER_PASS + st_row) * LT_PITCH + st_col) = stage[r];
+            __builtin_amdgcn_wave_barrier();
+            const int sox = ox - WOFF, soy = oy - WOFF;
+            const int hx = min(sox + LT_COLS - WIN, A.nx_f - 2), hy = min(soy + LT_ROWS - WIN, A.ny_f - 2);
+            const int lx = max(sox, 0), ly = max(soy, 0);
+            if (hx >= lx && hy >= ly) {
+                lo_x = lx;
+                lo_y = ly;
+                lim_x = hx - lx;
+                lim_y = hy - ly;
+                base_addr = tile_addr + (unsigned)(lx - sox) * 8u + (unsigned)(ly - soy) * ((unsigned)LT_PITCH * 8u);
+            }
+        }
+        // ---- 3. K iterations out of LDS (latitude clamp deferred to the redo path / the level's end) ---------------
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            anybad = false;
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                const TapL t = tap_of(to_index(p[q]));  // absolute coordinate: its rounding must not depend on the tile
+                const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;
+                bad[q] = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
+                const f2 ew = window_lds<ORDER, LT_PITCH>(base_addr, pitch_bytes, rx, ry, t, e[q]);  // e + sample of ext[t]
+                pn[q] = L.hd[q] * ew + p[q];
+                bad[q] |= x_needs_care(pn[q].x);
+                anybad |= bad[q];
+            }
+            if (anybad) {
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) {
+                    if (bad[q]) {  // exact sequence, global gather
+                        f2 pc = p[q];
+                        pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
+                        const TapL t = tap_of(index_coords(A, pc));
+                        pn[q] = L.hd[q] * window_global<ORDER>(elv, A, t, e[q]) + pc;
+                        clamp_position_p(A, pn[q], ymax_v);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) p[q] = pn[q];
+        }
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);  // the level's one latitude clamp
+        L.store_level(A, &s_slab[0][0][0], s);
+        lvl += A.level_elems;
+        elv += A.level_elems;
+    }
+    L.store_final(A);
+}
+
 template <typename T, int ORDER>
 struct LdsLaunch {
     static const char *launch(const AdvectArgs<T> &, int, hipStream_t, int) { return nullptr; }
@@ -1599,6 +1875,43 @@ struct LdsLaunch<float, ORDER> {
             if (A.cyclic) LC_LDS2(-1, true, PATCH_TALL, "advect_lds2_kernel<-1, true, 0>")
             LC_LDS2(-1, false, PATCH_TALL, "advect_lds2_kernel<-1, false, 0>")
 #undef LC_LDS2
+        }
+        if (ORDER == 3 && two_seed && A.ext && A.K > 0 && A.nx_f + LC_PAD >= TileGeom<3>::COLS && A.ny_f + LC_PAD >= TileGeom<3>::ROWS) {
+            // order 3, two seeds per lane: the same patches and patch modes as above
+            const int mode = A.patch_mode >= 0 ? A.patch_mode : (A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 ? PATCH_LINES : PATCH_TALL);
+            int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
+            if (mode == PATCH_WIDE) {
+                A.ntx = (A.nx + TILE_W * SPL - 1) / (TILE_W * SPL);
+                nty = (A.ny + TILE_H - 1) / TILE_H;
+            } else if (mode == PATCH_LINES) {
+                A.ntx = (A.nx + TILE_W * 4 - 1) / (TILE_W * 4);
+                nty = (A.ny + 8 * SPL - 1) / (8 * SPL);
+            }
+            A.xcd_chunk = A.xcd_rows * A.ntx;
+            A.ntiles = A.ntx * nty;
+            const int g2 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
+#define LC_LDS2O3(KF, CY, MD, NAME)                                                                       \
+    {                                                                                                     \
+        hipLaunchKernelGGL((advect_lds2_o3_kernel<KF, CY, MD>), dim3(g2), dim3(BLOCK), 0, st, A);         \
+        return NAME;                                                                                      \
+    }
+            if (mode == PATCH_LINES) {
+                if (A.K == 4 && A.cyclic) LC_LDS2O3(4, true, PATCH_LINES, "advect_lds2_o3_kernel<4, true, 2>")
+                if (A.K == 4) LC_LDS2O3(4, false, PATCH_LINES, "advect_lds2_o3_kernel<4, false, 2>")
+                if (A.cyclic) LC_LDS2O3(-1, true, PATCH_LINES, "advect_lds2_o3_kernel<-1, true, 2>")
+                LC_LDS2O3(-1, false, PATCH_LINES, "advect_lds2_o3_kernel<-1, false, 2>")
+            }
+            if (mode == PATCH_WIDE) {
+                if (A.K == 4 && A.cyclic) LC_LDS2O3(4, true, PATCH_WIDE, "advect_lds2_o3_kernel<4, true, 1>")
+                if (A.K == 4) LC_LDS2O3(4, false, PATCH_WIDE, "advect_lds2_o3_kernel<4, false, 1>")
+                if (A.cyclic) LC_LDS2O3(-1, true, PATCH_WIDE, "advect_lds2_o3_kernel<-1, true, 1>")
+                LC_LDS2O3(-1, false, PATCH_WIDE, "advect_lds2_o3_kernel<-1, false, 1>")
+            }
+            if (A.K == 4 && A.cyclic) LC_LDS2O3(4, true, PATCH_TALL, "advect_lds2_o3_kernel<4, true, 0>")
+            if (A.K == 4) LC_LDS2O3(4, false, PATCH_TALL, "advect_lds2_o3_kernel<4, false, 0>")
+            if (A.cyclic) LC_LDS2O3(-1, true, PATCH_TALL, "advect_lds2_o3_kernel<-1, true, 0>")
+            LC_LDS2O3(-1, false, PATCH_TALL, "advect_lds2_o3_kernel<-1, false, 0>")
+#undef LC_LDS2O3
         }
         // the fixed-size tile must fit inside one padded time level
         if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return nullptr;

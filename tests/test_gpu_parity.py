@@ -748,8 +748,9 @@ def test_level_chunks_do_not_change_results(eng, order, lds, traj):
         eng.set_level_chunk(-1)
 
 
+@pytest.mark.parametrize("order", [1, 3])
 @pytest.mark.parametrize("sny,snx", [(130, 212), (131, 211), (64, 32), (40, 100), (23, 18), (200, 512)])
-def test_patch_modes_of_the_two_seed_kernel_agree_bitwise(sny, snx, monkeypatch):
+def test_patch_modes_of_the_two_seed_kernel_agree_bitwise(sny, snx, order, monkeypatch):
     """Which seeds a wave of the two-seed kernel holds and how trajectories are stored (LCS_PATCH_MODE: 0 tall patches,
     per-lane stores; 1 wide patches, paired stores; 2 whole-line stores through an LDS slab and one workgroup barrier per
     level, the default with trajectories) only decides which lane holds which seed: positions and trajectories are
@@ -767,13 +768,20 @@ def test_patch_modes_of_the_two_seed_kernel_agree_bitwise(sny, snx, monkeypatch)
         e = Engine(0)
         try:
             e.set_lds_tiles(1)
-            f = e.prepare_field(u, v, lat, lon, 1)
-            out[flag] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=1, return_traj=True)]
+            f = e.prepare_field(u, v, lat, lon, order)
+            out[flag] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=order, return_traj=True)]
             want = flag or ("2" if snx % 4 == 0 and snx >= 32 else "0")      # the default: lines where rows are 16-byte aligned
-            assert e.last_advect_kernel() == "advect_lds2_kernel<4, true, %s>" % want
-            out[flag + "n"] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=1)]
+            assert e.last_advect_kernel() == ("advect_lds2_kernel<4, true, %s>" if order == 1 else "advect_lds2_o3_kernel<4, true, %s>") % want
+            out[flag + "n"] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=order)]
             e.set_level_chunk(4)
-            out[flag + "c"] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=2, interp_order=1, return_traj=True)]
+            out[flag + "c"] = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=2, interp_order=order, return_traj=True)]
+            if flag == "0":     # the one-seed-per-lane kernel of the same order: the same bits
+                e.set_level_chunk(0)
+                e.set_lds_tiles(2)
+                one = [_np(t) for t in e.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=order, return_traj=True)]
+                assert "advect_lds_kernel" in e.last_advect_kernel()
+                for a, b in zip(out["0"], one):
+                    assert np.array_equal(a, b)
         finally:
             e.close()
     for flag in ("1", "2", ""):
