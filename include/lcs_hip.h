@@ -65,8 +65,10 @@ enum lc_xboundary {
     /* cyclic_xboundary=False exactly as the reference computes it: `positions_x[np.where(x < x_min)] = x_min` on a
      * DataArray is orthogonal indexing, so every (row, col) in the cross product of offending rows and offending
      * columns is set (trajectory.py:96-97, 122-123).  lc_advect runs the fused kernel first and, only
-     * if a parcel really left the box, re-runs sub-step by sub-step with that rule (synchronous in this mode;
-     * needs the whole seed grid: row0 = 0, ny = ny_global). */
+     * if a parcel really left the box, re-runs sub-step by sub-step with that rule (synchronous in this mode).
+     * The rule couples every seed row through the offending COLUMNS: a call on a row block (row0 != 0 or
+     * ny != ny_global) needs lc_ctx_set_flag_allreduce, through which the ranks of a row-sharded grid OR their
+     * column flags after every sub-step; without it such a call is refused. */
     LC_X_CLAMP_REFERENCE_OUTER = 2
 };
 
@@ -101,6 +103,16 @@ int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode);
  * LCS_SIGMA_MARCH (0/1) sets the initial value, read ONCE in lc_ctx_create.  Results are bit-identical either way.
  * No reference counterpart. */
 int lc_ctx_set_sigma_march(lc_ctx *ctx, int on);
+/* Row-sharded grids with LC_X_CLAMP_REFERENCE_OUTER: `fn(user, flags_dev, count)` must replace the `count` uint32
+ * flags at `flags_dev` (device memory of this context) by their element-wise MAXIMUM over all ranks that hold row
+ * blocks of the same seed grid, ordered after the work already enqueued on the context's stream and before
+ * anything enqueued on it afterwards (an all-reduce on that stream, or one that synchronises with it); it returns
+ * 0 on success.  Every rank's lc_advect calls it the same number of times: once for "did any parcel leave the box
+ * anywhere", then -- only if one did -- twice per sub-step for the offending-column flags (nx of them) of the
+ * reference's two assignments (LCS/trajectory.py:96-97, 122-123).  NULL (the default) = single process.
+ * lc_comm_flag_allreduce (below) is such a function for an lc_comm. */
+typedef int (*lc_flag_allreduce_fn)(void *user, void *flags_dev, size_t count);
+int lc_ctx_set_flag_allreduce(lc_ctx *ctx, lc_flag_allreduce_fn fn, void *user);
 /* lc_advect / lc_advect_from run a series of nsteps time levels as consecutive launches of at most `levels` levels,
  * each continuing from the positions the previous one stored (0 = one launch, the default).  Results are bit-identical
  * whatever the value; it shapes the launches only (workgroups of one launch stay within `levels` levels of each other,
@@ -320,6 +332,9 @@ int lc_comm_destroy(lc_comm *comm);
 int lc_comm_count(const lc_comm *comm, int *nranks_out, int *rank_out);
 int lc_halo_exchange(lc_ctx *ctx, lc_comm *comm, void *x_ext, void *y_ext, int dtype,
                      int n_rows, int nx, int n_lo, int n_hi);
+/* An lc_flag_allreduce_fn on RCCL: ncclAllReduce(max, uint32) in place over the communicator, on the stream of the
+ * context the communicator was created with.  Use: lc_ctx_set_flag_allreduce(ctx, lc_comm_flag_allreduce, comm). */
+int lc_comm_flag_allreduce(void *comm /* lc_comm* */, void *flags_dev, size_t count);
 
 /* ---- one-call host entry point ----------------------------------------------
  * What a reference-side binding would call from LCS.__call__ (LCS/LCS.py:129-157):

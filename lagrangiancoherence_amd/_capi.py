@@ -30,6 +30,7 @@ PROTOTYPES = {
     "lc_ctx_set_lds_tiles": (_i, [_vp, _i]),
     "lc_ctx_set_sigma_march": (_i, [_vp, _i]),
     "lc_ctx_set_level_chunk": (_i, [_vp, _i]),
+    "lc_ctx_set_flag_allreduce": (_i, [_vp, _vp, _vp]),
     "lc_ctx_last_advect_kernel": (C.c_char_p, [_vp]),
     "lc_ctx_last_sigma_kernel": (C.c_char_p, [_vp]),
     "lc_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
@@ -55,12 +56,15 @@ PROTOTYPES = {
     "lc_comm_create": (_i, [_vp, _i, _i, _vp, _sz, C.POINTER(_vp)]),
     "lc_comm_destroy": (_i, [_vp]),
     "lc_comm_count": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "lc_comm_flag_allreduce": (_i, [_vp, _vp, _sz]),
     "lc_halo_exchange": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "lc_common_grid": (_i, [C.POINTER(_i), C.POINTER(_i), _vp, _vp]),
     "lc_lcs_global_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _d, _i, _i, _d, _i, _i, _vp, _vp, _vp]),
     "lc_lcs_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i,
                          _d, _i, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _vp]),
 }
+
+FLAG_ALLREDUCE_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz)   # lc_flag_allreduce_fn of include/lcs_hip.h
 
 _lib = None
 

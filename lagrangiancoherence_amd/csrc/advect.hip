@@ -2090,6 +2090,9 @@ struct DirectLaunch<float, ORDER> {
 // -> [flag rows/cols above x_max, on the array as it stands after the first assignment] -> next sub-step,
 // which applies both cross products while loading.  Two-sample form and operation order of advect_seed.
 // Only reached when a parcel really left the box (lc_advect tries the fused kernel first).
+// Row-sharded grids: the row flags are local to a rank; the COLUMN flags of both assignments are OR-ed over the ranks
+// (lc_ctx_set_flag_allreduce) before they are used -- the offending columns of the first assignment before the second
+// looks at the array it leaves, those of the second before the next sub-step applies both.
 // ======================================================================================
 template <typename T>
 struct OuterArgs {
@@ -2118,7 +2121,8 @@ __global__ void outer_substep_kernel(const AdvectArgs<T> A, const OuterArgs<T> O
         T y = O.y[i];
         const T ys = A.seed_lat[iy];
         const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((ys * T(3.141592653589793)) / T(180))));
-        const bool pole = iy < A.order || iy >= A.ny_global - A.order;  // tools.py:24-33 (Q3); row0 == 0 here
+        const int grow = A.row0 + iy;
+        const bool pole = grow < A.order || grow >= A.ny_global - A.order;  // tools.py:24-33 (Q3), global row index
         const T *lvl = (pole ? A.lin : A.img) + (size_t)level * A.level_elems;
         if (!is_iter) {
             Pair<T> e = pole ? sample<T, 1, false>(lvl, A, x, y) : sample<T, ORDER, true>(lvl, A, x, y);
@@ -2231,19 +2235,28 @@ int advect_outer_impl(lc_ctx *ctx, AdvectArgs<T> A) {
                 default: LC_OUTER(1); break;
             }
 #undef LC_OUTER
+            if (ctx->flag_reduce && ctx->flag_reduce(ctx->flag_reduce_user, O.clo, (size_t)A.nx) != 0) goto reduce_failed;
             hipLaunchKernelGGL((outer_hi_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O);
+            if (ctx->flag_reduce && ctx->flag_reduce(ctx->flag_reduce_user, O.chi, (size_t)A.nx) != 0) goto reduce_failed;
         }
         if (A.traj_x)
             hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O,
                                A.traj_x + (size_t)(s + 1) * n, A.traj_y + (size_t)(s + 1) * n, 0);
     }
     if (sub) hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.x_out, A.y_out, 0);
-    const hipError_t le = hipGetLastError();
-    (void)hipFreeAsync(e, st);
-    (void)hipFreeAsync(flags, st);
-    LC_HIP_CHECK(le);
+    {
+        const hipError_t le = hipGetLastError();
+        (void)hipFreeAsync(e, st);
+        (void)hipFreeAsync(flags, st);
+        LC_HIP_CHECK(le);
+    }
     ctx->last_advect_kernel = "outer_substep_kernel";
     return LC_OK;
+reduce_failed:
+    (void)hipFreeAsync(e, st);
+    (void)hipFreeAsync(flags, st);
+    lc_set_error("lc_advect: the flag all-reduce of LC_X_CLAMP_REFERENCE_OUTER failed (lc_ctx_set_flag_allreduce callback returned non-zero)");
+    return LC_ERCCL;
 }
 
 template <typename T>
@@ -2383,6 +2396,12 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     if (outer) {
         unsigned moved = 0;
         hipError_t e1 = hipGetLastError();
+        // row-sharded: "did a parcel leave the box ANYWHERE" -- every rank must take the same path below
+        if (e1 == hipSuccess && ctx->flag_reduce && ctx->flag_reduce(ctx->flag_reduce_user, clamp_flag, 1) != 0) {
+            (void)hipFreeAsync(clamp_flag, ctx->stream);
+            lc_set_error("lc_advect: the flag all-reduce of LC_X_CLAMP_REFERENCE_OUTER failed (lc_ctx_set_flag_allreduce callback returned non-zero)");
+            return LC_ERCCL;
+        }
         if (e1 == hipSuccess) e1 = hipMemcpyAsync(&moved, clamp_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
         if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
         (void)hipFreeAsync(clamp_flag, ctx->stream);
@@ -2545,9 +2564,9 @@ extern "C" int lc_advect_from(lc_ctx *ctx, const void *packed_lin, const void *p
                row0 + ny, ny_global);
     LC_REQUIRE(settls_order >= 0, "lc_advect: SETTLS_order must be >= 0");
     LC_REQUIRE(cyclic_x >= LC_X_CLAMP_POINT && cyclic_x <= LC_X_CLAMP_REFERENCE_OUTER, "lc_advect: bad cyclic_x %d", cyclic_x);
-    if (cyclic_x == LC_X_CLAMP_REFERENCE_OUTER && (row0 != 0 || ny != ny_global)) {
-        lc_set_error("lc_advect: LC_X_CLAMP_REFERENCE_OUTER couples every seed row after every sub-step and cannot be "
-                     "row-sharded (rows [%d,%d) of %d)", row0, row0 + ny, ny_global);
+    if (cyclic_x == LC_X_CLAMP_REFERENCE_OUTER && (row0 != 0 || ny != ny_global) && !ctx->flag_reduce) {
+        lc_set_error("lc_advect: LC_X_CLAMP_REFERENCE_OUTER couples every seed row through the offending columns: a row "
+                     "block (rows [%d,%d) of %d) needs lc_ctx_set_flag_allreduce", row0, row0 + ny, ny_global);
         return LC_EUNSUPPORTED;
     }
     LC_REQUIRE(t0 >= 0 && nsteps >= 0 && t0 + nsteps <= nt - 1, "lc_advect: steps [%d,%d) need levels up to %d, have %d",

@@ -56,6 +56,8 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     if (const char *ev = getenv("LCS_LEVEL_CHUNK")) c->level_chunk = atoi(ev) > 0 ? atoi(ev) : 0;  // read once, here
     c->patch_mode = -1;
     if (const char *ev = getenv("LCS_PATCH_MODE")) c->patch_mode = (ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : -1;  // read once, here
+    c->flag_reduce = nullptr;
+    c->flag_reduce_user = nullptr;
     c->lds_tiles_init = c->lds_tiles;
     c->sigma_march_init = c->sigma_march;
     c->last_advect_kernel = "";
@@ -76,6 +78,13 @@ extern "C" int lc_ctx_set_sigma_march(lc_ctx *ctx, int on) {
     LC_REQUIRE(ctx, "lc_ctx_set_sigma_march: null context");
     LC_REQUIRE(on >= -1 && on <= 1, "lc_ctx_set_sigma_march: on must be -1, 0 or 1");
     ctx->sigma_march = on < 0 ? ctx->sigma_march_init : on;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_set_flag_allreduce(lc_ctx *ctx, lc_flag_allreduce_fn fn, void *user) {
+    LC_REQUIRE(ctx, "lc_ctx_set_flag_allreduce: null context");
+    ctx->flag_reduce = fn;
+    ctx->flag_reduce_user = user;
     return LC_OK;
 }
 

@@ -24,11 +24,13 @@ typedef struct {
     char internal[128];
 } ncclUniqueId;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclUint32 = 3, ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclMax = 2 } ncclRedOp_t;
 
 struct lc_comm {
     ncclComm_t comm;
     int nranks, rank;
+    lc_ctx *ctx;  // the context lc_comm_create was given (its stream carries lc_comm_flag_allreduce)
 };
 
 namespace {
@@ -44,6 +46,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -79,6 +82,7 @@ bool load_rccl() {
     LC_SYM(GroupEnd, "ncclGroupEnd")
     LC_SYM(Send, "ncclSend")
     LC_SYM(Recv, "ncclRecv")
+    LC_SYM(AllReduce, "ncclAllReduce")
     LC_SYM(GetErrorString, "ncclGetErrorString")
 #undef LC_SYM
     g_rccl = r;
@@ -114,7 +118,7 @@ extern "C" int lc_comm_create(lc_ctx *ctx, int nranks, int rank, const void *id,
     LC_HIP_CHECK(hipSetDevice(ctx->device));
     ncclUniqueId uid;
     __builtin_memcpy(&uid, id, sizeof(uid));
-    lc_comm *c = new lc_comm{nullptr, nranks, rank};
+    lc_comm *c = new lc_comm{nullptr, nranks, rank, ctx};
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);
     if (r != ncclSuccess) {
         lc_set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
@@ -139,6 +143,15 @@ extern "C" int lc_comm_count(const lc_comm *comm, int *nranks_out, int *rank_out
     LC_RCCL_CHECK(g_rccl.CommUserRank(comm->comm, &r));
     if (nranks_out) *nranks_out = n;
     if (rank_out) *rank_out = r;
+    return LC_OK;
+}
+
+extern "C" int lc_comm_flag_allreduce(void *comm_, void *flags_dev, size_t count) {
+    lc_comm *comm = (lc_comm *)comm_;
+    LC_REQUIRE(comm && comm->comm && comm->ctx && g_rccl.handle, "lc_comm_flag_allreduce: null communicator");
+    LC_REQUIRE(flags_dev || count == 0, "lc_comm_flag_allreduce: null buffer");
+    if (comm->nranks == 1 || count == 0) return LC_OK;
+    LC_RCCL_CHECK(g_rccl.AllReduce(flags_dev, flags_dev, count, ncclUint32, ncclMax, comm->comm, comm->ctx->stream));
     return LC_OK;
 }
 

@@ -27,14 +27,16 @@ _LAYOUTS = {"reference": _capi.LC_LAYOUT_REFERENCE, "physical": _capi.LC_LAYOUT_
 
 
 def x_boundary_mode(cyclic_xboundary, noncyclic_clamp=None, whole_grid=True) -> int:
-    """lc_advect's ``cyclic_x`` (enum lc_xboundary).  ``cyclic_xboundary=False`` defaults to the reference's own
-    outer-product clamp (``noncyclic_clamp='reference_outer'``, LCS/trajectory.py:96-97, Q9) whenever the call
-    covers the whole seed grid; a row-sharded call cannot (the rule couples all rows) and takes ``'pointwise'``,
-    which differs from the reference only if a parcel leaves the longitude range."""
+    """lc_advect's ``cyclic_x`` (enum lc_xboundary).  ``cyclic_xboundary=False`` means the reference's own
+    outer-product clamp (``noncyclic_clamp='reference_outer'``, LCS/trajectory.py:96-97, Q9).  The rule couples all
+    seed rows through the offending columns, so a call on a row block (``whole_grid=False``) is only possible with a
+    flag all-reduce over the ranks (:meth:`Engine.set_flag_allreduce`, which ``sharded_lcs`` installs) -- without one
+    lc_advect refuses it; nothing is silently replaced by the per-point clamp (``noncyclic_clamp='pointwise'`` asks
+    for that one explicitly; it differs from the reference only if a parcel leaves the longitude range)."""
     if cyclic_xboundary:
         return _capi.LC_X_CYCLIC
     if noncyclic_clamp is None:
-        noncyclic_clamp = "reference_outer" if whole_grid else "pointwise"
+        noncyclic_clamp = "reference_outer"
     if noncyclic_clamp not in ("pointwise", "reference_outer"):
         raise ValueError(f"noncyclic_clamp {noncyclic_clamp!r}: 'pointwise' or 'reference_outer'")
     return _capi.LC_X_CLAMP_REFERENCE_OUTER if noncyclic_clamp == "reference_outer" else _capi.LC_X_CLAMP_POINT
@@ -112,6 +114,45 @@ class Engine:
         """Run every advect call as consecutive launches of at most ``levels`` time levels (0: one launch).  Results are
         bit-identical; it shapes the launches only (``lc_ctx_set_level_chunk``)."""
         _capi.check(self.lib.lc_ctx_set_level_chunk(self.ctx, int(levels)), self.lib)
+
+    def set_flag_allreduce(self, group=None, comm=None, enable=True):
+        """Row-sharded grids with the reference's non-cyclic clamp (``LC_X_CLAMP_REFERENCE_OUTER``): install the
+        MAX all-reduce of the offending-column flags over the ranks that share the seed grid
+        (``lc_ctx_set_flag_allreduce``).  ``comm``: the C ABI's RCCL communicator (``lc_comm_flag_allreduce``);
+        otherwise ``torch.distributed`` over ``group`` (nccl = RCCL reduces the device buffer in place on the current
+        stream; gloo, used when rehearsing on one GPU, goes through the host).  ``enable=False`` removes it."""
+        if not enable:
+            _capi.check(self.lib.lc_ctx_set_flag_allreduce(self.ctx, None, None), self.lib)
+            self._flag_cb = None
+            return
+        if comm is not None:
+            fn = C.cast(self.lib.lc_comm_flag_allreduce, C.c_void_p)
+            _capi.check(self.lib.lc_ctx_set_flag_allreduce(self.ctx, fn, comm), self.lib)
+            self._flag_cb = None
+            return
+        torch = self.torch
+        import torch.distributed as dist
+
+        class _DeviceWords:     # a raw device pointer as a tensor, through the CUDA array interface
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+        def reduce(_user, ptr, count):
+            try:
+                t = torch.as_tensor(_DeviceWords(ptr, count), device=self.device)     # the flags are 0 / 1: int32 max is the OR
+                if dist.get_backend(group) == "gloo":
+                    h = t.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                return 0
+            except Exception:     # an exception must not unwind through the C frames of lc_advect
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._flag_cb = _capi.FLAG_ALLREDUCE_FN(reduce)      # kept alive for as long as the context may call it
+        _capi.check(self.lib.lc_ctx_set_flag_allreduce(self.ctx, C.cast(self._flag_cb, C.c_void_p), None), self.lib)
 
     def last_advect_kernel(self) -> str:
         """Name of the kernel the last :meth:`advect` call launched (as a profiler shows it)."""

@@ -125,13 +125,19 @@ def halo_exchange(x, y, rank: int, world: int, ny_global: int, lo: int, hi: int,
 
 def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, world: int, SETTLS_order=0,
                 interp_order=1, cyclic_xboundary=True, t0=0, nsteps=None, fd_fp32_cast=True,
-                tensor_layout="reference", group=None, redundant_halo=False, native_halo=False):
+                tensor_layout="reference", group=None, redundant_halo=False, native_halo=False, noncyclic_clamp=None):
     """This rank's rows of (sigma, x_dep, y_dep) for a row-sharded seed grid.
 
     ``redundant_halo=True`` advects the halo rows locally instead of exchanging them
     (0.1 % extra work at 4096 rows/GPU); the results are bit-identical and the
     tests use it to check the exchange.  ``native_halo=True`` exchanges through the C ABI
     (``lc_halo_exchange``, RCCL directly) instead of ``torch.distributed`` point-to-point.
+
+    ``cyclic_xboundary=False`` is the reference's outer-product longitude clamp (LCS/trajectory.py:96-97, Q9), which
+    couples all seed rows through the offending columns: the ranks OR their column flags after every sub-step
+    (``Engine.set_flag_allreduce``: a MAX all-reduce of ``nx`` flags, over the same transport as the halo), so the
+    sharded result equals the unsharded one and the reference's.  Collective: every rank must make the call.
+    ``noncyclic_clamp='pointwise'`` asks for the per-point clamp instead (no communication, not the reference's rule).
     """
     import numpy as np
     seed_lat_global = np.asarray(seed_lat_global, dtype=field.dtype)
@@ -139,19 +145,27 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
     nyg = seed_lat_global.size
     lo, hi = row_partition(nyg, world, rank)
     n_lo, n_hi = halo_rows(nyg, lo, hi)
-    if redundant_halo:
-        a, b = lo - n_lo, hi + n_hi
-        x_ext, y_ext = engine.advect(field, seed_lat_global[a:b], seed_lon, timestep, SETTLS_order, interp_order,
-                                     cyclic_xboundary, t0, nsteps, row0=a, ny_global=nyg)
-        in_row0 = a
-        x, y = x_ext[n_lo:n_lo + hi - lo], y_ext[n_lo:n_lo + hi - lo]
-    else:
-        x_ext, y_ext = engine.advect(field, seed_lat_global[lo:hi], seed_lon, timestep, SETTLS_order, interp_order,
-                                     cyclic_xboundary, t0, nsteps, row0=lo, ny_global=nyg, halo=(n_lo, n_hi))
-        comm = native_comm(engine, rank, world, group) if (native_halo and world > 1) else None
-        halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world, group, engine=engine, comm=comm)
-        in_row0 = lo - n_lo
-        x, y = x_ext[n_lo:n_lo + hi - lo], y_ext[n_lo:n_lo + hi - lo]
+    comm = native_comm(engine, rank, world, group) if (native_halo and world > 1) else None
+    outer = (not cyclic_xboundary) and noncyclic_clamp in (None, "reference_outer") and world > 1
+    if outer:   # the reference's clamp on a row block: the ranks share their offending-column flags
+        engine.set_flag_allreduce(group=group, comm=comm)
+    try:
+        if redundant_halo:
+            a, b = lo - n_lo, hi + n_hi
+            x_ext, y_ext = engine.advect(field, seed_lat_global[a:b], seed_lon, timestep, SETTLS_order, interp_order,
+                                         cyclic_xboundary, t0, nsteps, row0=a, ny_global=nyg, noncyclic_clamp=noncyclic_clamp)
+            in_row0 = a
+            x, y = x_ext[n_lo:n_lo + hi - lo], y_ext[n_lo:n_lo + hi - lo]
+        else:
+            x_ext, y_ext = engine.advect(field, seed_lat_global[lo:hi], seed_lon, timestep, SETTLS_order, interp_order,
+                                         cyclic_xboundary, t0, nsteps, row0=lo, ny_global=nyg, halo=(n_lo, n_hi),
+                                         noncyclic_clamp=noncyclic_clamp)
+            halo_exchange_into(x_ext, y_ext, n_lo, n_hi, rank, world, group, engine=engine, comm=comm)
+            in_row0 = lo - n_lo
+            x, y = x_ext[n_lo:n_lo + hi - lo], y_ext[n_lo:n_lo + hi - lo]
+    finally:
+        if outer:
+            engine.set_flag_allreduce(enable=False)
     dlat = float(seed_lat_global[1] - seed_lat_global[0])
     dlon = float(seed_lon[1] - seed_lon[0])
     sig = engine.sigma(x_ext, y_ext, seed_lat_global[in_row0:in_row0 + x_ext.shape[0]], dlat, dlon, ny_global=nyg,

@@ -107,13 +107,14 @@ def test_new_entry_points_validate_before_touching_a_device(lib):
 
 
 def test_x_boundary_mode_defaults():
-    """cyclic_xboundary=False means the reference's own outer-product clamp (Q9) whenever the call covers the whole
-    seed grid; a row-sharded call falls back to the per-point clamp; explicit choices are honoured."""
+    """cyclic_xboundary=False means the reference's own outer-product clamp (Q9), for a row block too (lc_advect then
+    needs the flag all-reduce of the sharded driver and refuses the call without it: nothing falls back silently to
+    the per-point clamp); explicit choices are honoured."""
     from lagrangiancoherence_amd.engine import x_boundary_mode
     assert x_boundary_mode(True) == _capi.LC_X_CYCLIC == 1
     assert x_boundary_mode(False) == _capi.LC_X_CLAMP_REFERENCE_OUTER == 2
-    assert x_boundary_mode(False, whole_grid=False) == _capi.LC_X_CLAMP_POINT == 0
-    assert x_boundary_mode(False, "pointwise") == 0 and x_boundary_mode(False, "reference_outer", whole_grid=False) == 2
+    assert x_boundary_mode(False, whole_grid=False) == _capi.LC_X_CLAMP_REFERENCE_OUTER
+    assert x_boundary_mode(False, "pointwise") == _capi.LC_X_CLAMP_POINT == 0 and x_boundary_mode(False, "reference_outer", whole_grid=False) == 2
     with pytest.raises(ValueError):
         x_boundary_mode(False, "nearest")
 

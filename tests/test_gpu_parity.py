@@ -191,11 +191,29 @@ def test_advect_noncyclic_reference_outer_float32_and_fast_path(eng, O):
     assert eng.last_advect_kernel() != "outer_substep_kernel"
     xb, yb = eng.advect(f2, lat, lon, 7200.0, 2, 1, False, noncyclic_clamp="pointwise")
     assert np.array_equal(_np(xa), _np(xb)) and np.array_equal(_np(ya), _np(yb))
-    # the rule couples every row: a row-sharded call cannot offer it and says so
-    with pytest.raises(ValueError, match="row-sharded"):
-        eng.advect(f2, lat[2:9], lon, 7200.0, 2, 1, False, row0=2, ny_global=lat.size, noncyclic_clamp="reference_outer")
-    xs, _ = eng.advect(f2, lat[2:9], lon, 7200.0, 2, 1, False, row0=2, ny_global=lat.size)   # default: per point
+    # the rule couples every row through the offending columns: a call on a row block needs the flag all-reduce of the
+    # sharded driver (Engine.set_flag_allreduce) and is refused without it -- no silent per-point fallback
+    for clamp in (None, "reference_outer"):
+        with pytest.raises(ValueError, match="lc_ctx_set_flag_allreduce"):
+            eng.advect(f2, lat[2:9], lon, 7200.0, 2, 1, False, row0=2, ny_global=lat.size, noncyclic_clamp=clamp)
+    xs, _ = eng.advect(f2, lat[2:9], lon, 7200.0, 2, 1, False, row0=2, ny_global=lat.size, noncyclic_clamp="pointwise")
     assert np.array_equal(_np(xs), _np(xb)[2:9])
+    # with a reducer in place (here a stand-in for one rank holding every row block in turn: the flags of the whole grid
+    # come from the unsharded run) the row-block call runs the same sub-step path
+    import ctypes as C
+    from lagrangiancoherence_amd import _capi
+    calls = []
+    cb = _capi.FLAG_ALLREDUCE_FN(lambda user, ptr, n: (calls.append(int(n)), 0)[1])
+    _capi.check(eng.lib.lc_ctx_set_flag_allreduce(eng.ctx, C.cast(cb, C.c_void_p), None), eng.lib)
+    try:
+        xw, yw = eng.advect(f, lat, lon, 7200.0, 2, 1, False)          # whole grid through the hook: 1 + 2 per sub-step calls
+        assert eng.last_advect_kernel() == "outer_substep_kernel"
+        nsub = (u.shape[0] - 1) * 3
+        assert calls == [1] + [lon.size] * (2 * nsub)
+    finally:
+        eng.set_flag_allreduce(enable=False)
+    xr0, yr0 = eng.advect(f, lat, lon, 7200.0, 2, 1, False)
+    assert np.array_equal(_np(xw), _np(xr0)) and np.array_equal(_np(yw), _np(yr0))
 
 
 def test_kat_zero_wind_and_uniform_wind(eng):

@@ -134,3 +134,66 @@ def test_native_rccl_halo_exchange_two_gpus():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _outer_worker(rank, world, port, dtype_name, q):
+    """cyclic_xboundary=False on a row-sharded grid with parcels that DO leave the longitude box: the reference's
+    outer-product clamp (LCS/trajectory.py:96-97, Q9) couples all rows through the offending columns, which the ranks
+    OR after every sub-step (Engine.set_flag_allreduce, here over gloo through the host)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from lagrangiancoherence_amd import sharded
+        from lagrangiancoherence_amd.engine import Engine
+        from oracle import lcs_oracle as O
+        torch.cuda.set_device(0)
+        eng = Engine(0)
+        dtype = np.dtype(dtype_name)
+        rng = np.random.default_rng(5)
+        ny, nx, nt = 41, 56, 5
+        lat = np.linspace(-40, 40, ny).astype(dtype)
+        lon = np.linspace(-60, 50, nx).astype(dtype)               # a regional box
+        u = (30 + 25 * rng.standard_normal((nt, ny, nx))).astype(dtype)   # strong zonal wind: parcels cross both edges
+        v = (8 * rng.standard_normal((nt, ny, nx))).astype(dtype)
+        f = eng.prepare_field(u, v, lat, lon, 1)
+        kw = dict(SETTLS_order=2, interp_order=1, cyclic_xboundary=False)
+        full = eng.lcs(f, lat, lon, 7200.0, **kw)
+        moved = eng.last_advect_kernel() == "outer_substep_kernel"
+        out = sharded.sharded_lcs(eng, f, lat, lon, 7200.0, rank, world, **kw)
+        red = sharded.sharded_lcs(eng, f, lat, lon, 7200.0, rank, world, redundant_halo=True, **kw)
+        pt = sharded.sharded_lcs(eng, f, lat, lon, 7200.0, rank, world, noncyclic_clamp="pointwise", **kw)
+        lo, hi = out["rows"]
+        ok = moved and torch.equal(out["x_dep"], full["x_dep"][lo:hi]) and torch.equal(out["y_dep"], full["y_dep"][lo:hi]) \
+            and torch.equal(out["sigma"], full["sigma"][lo:hi]) and torch.equal(red["sigma"], out["sigma"])
+        differs = not torch.equal(pt["x_dep"], out["x_dep"])       # the per-point clamp is NOT the reference's rule here
+        msg = "ok" if ok else f"mismatch rows {lo}:{hi} (sub-step path taken: {moved})"
+        if ok and dtype == np.float64 and rank == 0:               # ... and the reference's rule is what the oracle computes
+            xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=7200.0, SETTLS_order=2, interp_order=1,
+                                          cyclic_xboundary=False, noncyclic_clamp="reference_outer")
+            if np.abs(full["x_dep"].cpu().numpy() - xo).max() > 1e-9:
+                msg = "unsharded result is not the oracle's"
+        q.put((rank, msg, differs))
+        eng.close()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), False))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dtype", [(2, "float64"), (3, "float32")])
+def test_sharded_noncyclic_reference_clamp_equals_unsharded(world, dtype):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_outer_worker, args=(r, world, port, dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg, _ in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+    assert any(d for _, _, d in res)       # on some rank the per-point clamp gives different departure points
