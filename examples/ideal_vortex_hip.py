@@ -17,7 +17,8 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from LagrangianCoherence.LCS import LCS, trajectory  # noqa: E402
-from lagrangiancoherence_amd import flows, labelled  # noqa: E402
+from lagrangiancoherence_amd import flows  # noqa: E402
+from tests import labelled  # noqa: E402
 
 
 def dataset():

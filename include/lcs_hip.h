@@ -173,12 +173,19 @@ int lc_regrid_common_grid(lc_ctx *ctx, const void *src_dev, int dtype, int nt, i
                           double *out_dev);
 
 /* lc_spectral_truncate replaces LCS/LCS.py:115-118: windspharm `VectorWind(u, v).truncate(f, truncation=T)`
- * = spherical-harmonic analysis on SPHEREPACK's equally spaced grid (theta_i = i pi / (nlat-1)), triangular
- * truncation n <= T, synthesis.  f, out: [nbatch][nlat][nlon] in `dtype`, latitude ASCENDING; computed in
- * float64.  Operators are built on the host once per (nlat, nlon, T) and cached on the context.  T <= 31.
- * Restates the published algorithm (Swarztrauber 1979); not pinned against pyspharm. */
+ * = spherical-harmonic analysis, triangular truncation n <= T, synthesis.  gridtype is what windspharm's grid
+ * inspection finds: LC_GRID_REGULAR = SPHEREPACK's equally spaced grid (theta_i = i pi / (nlat-1); shaes/shses),
+ * LC_GRID_GAUSSIAN = Gauss-Legendre latitudes (shags/shsgs: Gaussian quadrature).  f, out: [nbatch][nlat][nlon] in
+ * `dtype`, latitude ASCENDING; computed in float64.  Operators are built on the host once per (nlat, nlon, T,
+ * gridtype) and cached on the context.  Any T <= min(nlat-1, (nlon-1)/2).  Restates the published algorithm
+ * (Swarztrauber 1979); not pinned against pyspharm. */
+enum lc_gridtype { LC_GRID_REGULAR = 0, LC_GRID_GAUSSIAN = 1 };
+/* windspharm's latitude inspection (what VectorWind does with the grid it is handed, LCS/LCS.py:116): equally spaced
+ * global latitudes -> LC_GRID_REGULAR, Gaussian latitudes -> LC_GRID_GAUSSIAN (both to 5e-4 degrees), anything else
+ * LC_EINVAL with windspharm's message.  lat_ascending: host doubles.  No device work. */
+int lc_inspect_gridtype(const double *lat_ascending, int nlat, int *gridtype_out);
 int lc_spectral_truncate(lc_ctx *ctx, const void *f_dev, int dtype, int nbatch, int nlat, int nlon,
-                         int truncation, void *out_dev);
+                         int truncation, int gridtype, void *out_dev);
 
 /* ---- K1: parcel advection ------------------------------------------------
  * Replaces trajectory.parcel_propagation (LCS/trajectory.py:8-144) together
@@ -352,8 +359,8 @@ int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, int dtype,
 /* ---- the reference's default global call form in one call, torch-free -------
  * LCS(...)(ds, isglobal=True) (LCS/LCS.py:105-157, examples/ideal_vortex.py:280-287) on host arrays:
  * [interp_to_common_grid: lc_regrid_common_grid of u and v onto lc_common_grid's grid, float64]
- * -> [truncation >= 0: lc_spectral_truncate at that wavenumber; the latitudes must pass windspharm's
- * equally-spaced-global inspection] -> lc_field_pack -> lc_advect (cyclic, seeds = grid nodes, all nt-1 steps)
+ * -> [truncation >= 0: lc_spectral_truncate at that wavenumber on the grid type lc_inspect_gridtype finds (equally
+ * spaced global or Gaussian latitudes; anything else is refused as windspharm refuses it)] -> lc_field_pack -> lc_advect (cyclic, seeds = grid nodes, all nt-1 steps)
  * -> [gauss_sigma > 0: lc_gaussian_filter] -> lc_sigma.
  * Outputs [ny_o * nx_o] on the host, any may be NULL: ny_o x nx_o = 360 x 721 and float64 when
  * interp_to_common_grid, else ny_f x nx_f in `dtype`.  Synchronous. */

@@ -15,6 +15,7 @@ LC_F32, LC_F64, LC_F64_WIND_F32 = 0, 1, 2
 LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM, LC_ERCCL = 0, -1, -2, -3, -4, -5
 LC_LAYOUT_REFERENCE, LC_LAYOUT_PHYSICAL = 0, 1
 LC_X_CLAMP_POINT, LC_X_CYCLIC, LC_X_CLAMP_REFERENCE_OUTER = 0, 1, 2
+LC_GRID_REGULAR, LC_GRID_GAUSSIAN = 0, 1
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 
@@ -41,7 +42,8 @@ PROTOTYPES = {
     "lc_field_pack": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lc_field_extrapolate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lc_regrid_common_grid": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
-    "lc_spectral_truncate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "lc_spectral_truncate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "lc_inspect_gridtype": (_i, [_vp, _i, C.POINTER(_i)]),
     "lc_advect": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i,
                        _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lc_advect_from": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i, _vp, _vp,

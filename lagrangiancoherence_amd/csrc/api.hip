@@ -457,19 +457,8 @@ extern "C" int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v
         lc_common_grid(nullptr, nullptr, lat.data(), lon.data());
         wdtype = LC_F64;
     }
-    if (truncation >= 0) {
-        // windspharm's grid inspection (equally spaced, global): LCS.py:116 via VectorWind
-        const double d0 = lat[1] - lat[0];
-        const double first = ny % 2 ? -90.0 : -90.0 + 90.0 / ny;
-        for (int i = 0; i < ny; ++i) {
-            const double want = ny % 2 ? -90.0 + 180.0 * i / (ny - 1) : first + (180.0 - 180.0 / ny) * i / (ny - 1);
-            if ((i && std::fabs((lat[i] - lat[i - 1]) - d0) > 5e-4) || std::fabs(lat[i] - want) > 5e-4) {
-                lc_set_error("lc_lcs_global_host: truncation needs equally spaced global latitudes (row %d is %g, expected %g)",
-                             i, lat[i], want);
-                return LC_EINVAL;
-            }
-        }
-    }
+    int gridtype = LC_GRID_REGULAR;
+    if (truncation >= 0) LC_TRY(lc_inspect_gridtype(lat.data(), ny, &gridtype));  // windspharm's grid inspection, LCS.py:116 via VectorWind
     const size_t es = wdtype == LC_F32 ? 4 : 8;
     const size_t nw = (size_t)nt * ny * nx, sbytes = (size_t)ny * nx * es;
     DevBuf uin, vin, ur, vr, ut, vt, lin, cub, ext, slat, slon, x, y, sig, gx, gy, gtmp;
@@ -491,8 +480,8 @@ extern "C" int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v
     if (truncation >= 0) {
         LC_TRY(ut.alloc(nw * es));
         LC_TRY(vt.alloc(nw * es));
-        LC_TRY(lc_spectral_truncate(ctx, uw, wdtype, nt, ny, nx, truncation, ut.p));
-        LC_TRY(lc_spectral_truncate(ctx, vw, wdtype, nt, ny, nx, truncation, vt.p));
+        LC_TRY(lc_spectral_truncate(ctx, uw, wdtype, nt, ny, nx, truncation, gridtype, ut.p));
+        LC_TRY(lc_spectral_truncate(ctx, vw, wdtype, nt, ny, nx, truncation, gridtype, vt.p));
         uw = ut.p;
         vw = vt.p;
     }

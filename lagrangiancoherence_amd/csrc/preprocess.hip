@@ -23,7 +23,7 @@
 #include "lcs_common.h"
 
 struct lc_trunc_cache {
-    int nlat = 0, nlon = 0, T = -1;
+    int nlat = 0, nlon = 0, T = -1, gridtype = -1;
     double *P = nullptr;   // [T+1][nlat][nlat]
     double *F = nullptr;   // [nlon][2(T+1)]   forward:  cos | sin
     double *G = nullptr;   // [2(T+1)][nlon]   inverse weights
@@ -158,7 +158,33 @@ void gauss_legendre(int n, std::vector<double> &x, std::vector<double> &w) {
     }
 }
 
-// P[m] (row-major nlat x nlat, row 0 = north pole) for m = 0..T
+// Gaussian grid (windspharm gridtype 'gaussian' -> SPHEREPACK shags/shsgs): the rows sit on the Gauss-Legendre nodes
+// x_i = sin(lat_i) and the analysis is that quadrature, a^m_n = sum_j w_j Pbar^m_n(x_j) g_m(x_j) -- exact for
+// band-limited fields -- so P[m][i][j] = sum_{n=m..T} Pbar^m_n(x_i) Pbar^m_n(x_j) w_j.
+void build_projectors_gaussian(int nlat, int T, std::vector<double> &P) {
+    std::vector<double> x, w, S;
+    gauss_legendre(nlat, x, w);                 // ascending in x = south -> north
+    std::vector<double> xd(nlat), wd(nlat);     // row 0 = northernmost
+    for (int i = 0; i < nlat; ++i) {
+        xd[i] = x[nlat - 1 - i];
+        wd[i] = w[nlat - 1 - i];
+    }
+    P.assign((size_t)(T + 1) * nlat * nlat, 0.0);
+    for (int m = 0; m <= T; ++m) {
+        const int nn = T - m + 1;
+        legendre_normalized(m, T, xd, S);       // (nn, nlat)
+        double *Pm = P.data() + (size_t)m * nlat * nlat;
+        for (int i = 0; i < nlat; ++i)
+            for (int a = 0; a < nn; ++a) {
+                const double s = S[(size_t)a * nlat + i];
+                const double *Sa = S.data() + (size_t)a * nlat;
+                double *Pr = Pm + (size_t)i * nlat;
+                for (int j = 0; j < nlat; ++j) Pr[j] += s * Sa[j] * wd[j];
+            }
+    }
+}
+
+// P[m] (row-major nlat x nlat, row 0 = north pole) for m = 0..T, SPHEREPACK's equally spaced grid
 void build_projectors(int nlat, int T, std::vector<double> &P) {
     const int N = nlat - 1;
     const double pi = 3.14159265358979323846;
@@ -231,12 +257,14 @@ __global__ void __launch_bounds__(256) dft_forward_kernel(const T *__restrict__ 
         s_row[e] = v;
     }
     __syncthreads();
-    const int r = threadIdx.x / 64, c = threadIdx.x % 64;
-    if (c >= C || row0 + r >= nrows_total) return;
+    const int r = threadIdx.x / 64;
+    if (row0 + r >= nrows_total) return;
     const double *g = s_row + (size_t)r * nlon;
-    double acc = 0.0;
-    for (int j = 0; j < nlon; ++j) acc = fma(g[j], F[(size_t)j * C + c], acc);
-    X[(size_t)(row0 + r) * C + c] = acc;
+    for (int c = threadIdx.x % 64; c < C; c += 64) {  // any truncation: the wave walks the 2 (T + 1) columns 64 at a time
+        double acc = 0.0;
+        for (int j = 0; j < nlon; ++j) acc = fma(g[j], F[(size_t)j * C + c], acc);
+        X[(size_t)(row0 + r) * C + c] = acc;
+    }
 }
 
 // H[b][i][c] = sum_j P[m(c)][i][j] X[b][j][c]: per m one (nlat x nlat) . (nlat x 2 nb) product, 32 x 32 tiles
@@ -278,9 +306,9 @@ __global__ void __launch_bounds__(256) project_kernel(const double *__restrict__
 template <typename T>
 __global__ void __launch_bounds__(256) dft_inverse_kernel(const double *__restrict__ H, int nlat, int nlon, int C,
                                                            const double *__restrict__ G, T *__restrict__ out) {
-    __shared__ double sh[128];
+    extern __shared__ double sh[];  // C spectral coefficients of the row
     const int row = blockIdx.x;  // (b, i)
-    if ((int)threadIdx.x < C) sh[threadIdx.x] = H[(size_t)row * C + threadIdx.x];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) sh[c] = H[(size_t)row * C + c];
     __syncthreads();
     const int b = row / nlat, i = row - b * nlat;
     T *dst = out + ((size_t)b * nlat + (nlat - 1 - i)) * nlon;
@@ -291,15 +319,18 @@ __global__ void __launch_bounds__(256) dft_inverse_kernel(const double *__restri
     }
 }
 
-int ensure_operators(lc_ctx *ctx, int nlat, int nlon, int T) {
+int ensure_operators(lc_ctx *ctx, int nlat, int nlon, int T, int gridtype) {
     lc_trunc_cache *c = ctx->trunc;
-    if (c && c->nlat == nlat && c->nlon == nlon && c->T == T) return LC_OK;
+    if (c && c->nlat == nlat && c->nlon == nlon && c->T == T && c->gridtype == gridtype) return LC_OK;
     lc_trunc_cache_free(c);
     ctx->trunc = nullptr;
     c = new lc_trunc_cache;
     const int T1 = T + 1, C = 2 * T1;
     std::vector<double> P, F((size_t)nlon * C), G((size_t)C * nlon);
-    build_projectors(nlat, T, P);
+    if (gridtype == LC_GRID_GAUSSIAN)
+        build_projectors_gaussian(nlat, T, P);
+    else
+        build_projectors(nlat, T, P);
     const double pi = 3.14159265358979323846;
     for (int j = 0; j < nlon; ++j)
         for (int m = 0; m < T1; ++m) {
@@ -324,6 +355,7 @@ int ensure_operators(lc_ctx *ctx, int nlat, int nlon, int T) {
     c->nlat = nlat;
     c->nlon = nlon;
     c->T = T;
+    c->gridtype = gridtype;
     ctx->trunc = c;
     return LC_OK;
 }
@@ -341,7 +373,7 @@ int truncate_impl(lc_ctx *ctx, const T *f, int nb, int nlat, int nlon, int Tr, T
                        (size_t)DFT_ROWS * nlon * sizeof(double), st, f, rows, nlat, nlon, C, ctx->trunc->F, X);
     hipLaunchKernelGGL(project_kernel, dim3((2 * nb + PT - 1) / PT, (nlat + PT - 1) / PT, T1), dim3(256), 0, st,
                        ctx->trunc->P, X, nb, nlat, T1, H);
-    hipLaunchKernelGGL((dft_inverse_kernel<T>), dim3(rows), dim3(256), 0, st, H, nlat, nlon, C, ctx->trunc->G, out);
+    hipLaunchKernelGGL((dft_inverse_kernel<T>), dim3(rows), dim3(256), (size_t)C * sizeof(double), st, H, nlat, nlon, C, ctx->trunc->G, out);
     const hipError_t le = hipGetLastError();
     (void)hipFreeAsync(X, st);
     LC_HIP_CHECK(le);
@@ -417,24 +449,62 @@ extern "C" int lc_regrid_common_grid(lc_ctx *ctx, const void *src_dev, int dtype
     return LC_OK;
 }
 
+// windspharm's grid inspection (windspharm/tools? `inspect_gridtype`, reached from VectorWind at LCS/LCS.py:116):
+// latitudes equally spaced to 5e-4 degrees must equal the global equally spaced grid of that size (poles included for
+// an odd count, half a spacing away from them for an even one) -> 'regular'; otherwise they must equal the Gaussian
+// latitudes of that size to 5e-4 degrees -> 'gaussian'; anything else is an error.  Host arithmetic only.
+extern "C" int lc_inspect_gridtype(const double *lat_ascending, int nlat, int *gridtype_out) {
+    LC_REQUIRE(lat_ascending && gridtype_out && nlat >= 3, "lc_inspect_gridtype: bad arguments");
+    const double tol = 5e-4, d0 = std::fabs(lat_ascending[1] - lat_ascending[0]);
+    bool equal = true;
+    for (int i = 1; i < nlat; ++i) equal = equal && std::fabs(std::fabs(lat_ascending[i] - lat_ascending[i - 1]) - d0) < tol;
+    if (equal) {
+        const double first = nlat % 2 ? -90.0 : -90.0 + 90.0 / nlat, last = -first;
+        for (int i = 0; i < nlat; ++i) {
+            const double want = first + (last - first) * i / (nlat - 1);
+            if (std::fabs(lat_ascending[i] - want) > tol) {
+                lc_set_error("equally-spaced latitudes are invalid (they may be non-global): row %d is %g, a global grid of %d rows has %g",
+                             i, lat_ascending[i], nlat, want);
+                return LC_EINVAL;
+            }
+        }
+        *gridtype_out = LC_GRID_REGULAR;
+        return LC_OK;
+    }
+    std::vector<double> x, w;
+    gauss_legendre(nlat, x, w);  // ascending
+    for (int i = 0; i < nlat; ++i) {
+        const double want = std::asin(x[i]) * 180.0 / 3.14159265358979323846;
+        if (std::fabs(lat_ascending[i] - want) > tol) {
+            lc_set_error("latitudes are neither equally-spaced or Gaussian (row %d is %g, the Gaussian grid of %d rows has %g)", i,
+                         lat_ascending[i], nlat, want);
+            return LC_EINVAL;
+        }
+    }
+    *gridtype_out = LC_GRID_GAUSSIAN;
+    return LC_OK;
+}
+
 extern "C" int lc_spectral_truncate(lc_ctx *ctx, const void *f_dev, int dtype, int nbatch, int nlat, int nlon, int truncation,
-                                    void *out_dev) {
+                                    int gridtype, void *out_dev) {
     LC_REQUIRE(ctx, "lc_spectral_truncate: null context");
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_spectral_truncate: bad dtype %d", dtype);
     LC_REQUIRE(f_dev && out_dev, "lc_spectral_truncate: null pointer");
     LC_REQUIRE(nbatch >= 1 && nlat >= 3 && nlon >= 4, "lc_spectral_truncate: bad sizes");
     LC_REQUIRE(truncation >= 0, "lc_spectral_truncate: truncation must be >= 0");
-    if (truncation > nlat - 1 || truncation > (nlon - 1) / 2 || 2 * (truncation + 1) > 64) {
-        lc_set_error("lc_spectral_truncate: truncation %d too high for a %dx%d grid (and this build keeps 2(T+1) <= 64)",
-                     truncation, nlat, nlon);
-        return truncation > 31 ? LC_EUNSUPPORTED : LC_EINVAL;
+    LC_REQUIRE(gridtype == LC_GRID_REGULAR || gridtype == LC_GRID_GAUSSIAN, "lc_spectral_truncate: bad gridtype %d", gridtype);
+    LC_REQUIRE(truncation <= nlat - 1 && truncation <= (nlon - 1) / 2, "lc_spectral_truncate: truncation %d too high for a %dx%d grid",
+               truncation, nlat, nlon);
+    if ((size_t)2 * (truncation + 1) * sizeof(double) > 48 * 1024) {  // a row's coefficients sit in LDS in the inverse DFT
+        lc_set_error("lc_spectral_truncate: truncation %d exceeds this build's limit of %d", truncation, 48 * 1024 / 16 - 1);
+        return LC_EUNSUPPORTED;
     }
     if ((size_t)DFT_ROWS * nlon * sizeof(double) > 64 * 1024) {  // the forward DFT stages DFT_ROWS field rows in LDS
         lc_set_error("lc_spectral_truncate: %d longitudes exceed this build's limit of %d", nlon, 64 * 1024 / (DFT_ROWS * 8));
         return LC_EUNSUPPORTED;
     }
     LC_HIP_CHECK(hipSetDevice(ctx->device));
-    const int s = ensure_operators(ctx, nlat, nlon, truncation);
+    const int s = ensure_operators(ctx, nlat, nlon, truncation, gridtype);
     if (s != LC_OK) return s;
     if (dtype == LC_F32) return truncate_impl<float>(ctx, (const float *)f_dev, nbatch, nlat, nlon, truncation, (float *)out_dev);
     return truncate_impl<double>(ctx, (const double *)f_dev, nbatch, nlat, nlon, truncation, (double *)out_dev);

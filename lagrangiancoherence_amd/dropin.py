@@ -6,9 +6,9 @@ Same names, positional order, defaults and return conventions as
     LagrangianCoherence.LCS.LCS.flowmap_gradient          LCS/LCS.py:171-225
     LagrangianCoherence.LCS.trajectory.parcel_propagation LCS/trajectory.py:8-144
 
-xarray in, xarray out.  Where xarray is not installed (this image) the same code
-accepts and returns `labelled.DataArray` stand-ins; the adapter touches only
-``dims``, ``values``, coordinates and ``name``.  All arithmetic happens in the
+xarray in, xarray out.  The adapter touches only ``dims``, ``values``, coordinates and ``name`` and returns
+results in the class of its inputs, so where xarray is not installed (this image) the same code runs on any
+duck-typed labelled array (the tests use the stand-in of tests/labelled.py; nothing here imports it).  All arithmetic happens in the
 HIP library; this file is argument handling only.
 
 Deliberate differences from the reference (all outside the arithmetic):
@@ -27,7 +27,6 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import labelled
 from .engine import Engine, common_dtype
 
 __all__ = ["LCS", "parcel_propagation", "flowmap_gradient", "get_engine"]
@@ -54,7 +53,28 @@ def _make(like, data, dims, coords, name=None):
     if _is_xarray(like):
         import xarray as xr
         return xr.DataArray(data, dims=dims, coords=coords, name=name)
-    return labelled.DataArray(data, dims, coords, name)
+    # any other labelled-array class: results come back in the class they came in (constructor (data, dims, coords,
+    # name); the tests' xarray-free stand-in, tests/labelled.py, is one)
+    return type(like)(data, dims, coords, name)
+
+
+def _resample_linear(da, dim, freq):
+    """``da.resample({dim: freq}).interpolate('linear')`` (LCS/LCS.py:89-90) for a labelled array that is not an
+    xarray object: the new time axis is pandas' resampling index of the old one (what xarray's grouper calls
+    ``full_index``), the values go through ``scipy.interpolate.interp1d(kind='linear', bounds_error=False)`` on the
+    times as float64 nanoseconds since the first one -- the two kernels xarray itself delegates to."""
+    import pandas as pd
+    from scipy.interpolate import interp1d
+    t = pd.DatetimeIndex(np.asarray(da.coords[dim]))
+    full = pd.Series(np.arange(t.size), index=t).resample(freq).asfreq().index
+    t0 = t.values.astype("datetime64[ns]").min()
+    x = (t.values.astype("datetime64[ns]") - t0).astype("int64").astype(np.float64)
+    xn = (full.values.astype("datetime64[ns]") - t0).astype("int64").astype(np.float64)
+    ax = list(da.dims).index(dim)
+    vals = interp1d(x, np.asarray(da.values), kind="linear", axis=ax, bounds_error=False, assume_sorted=True)(xn)
+    coords = dict(da.coords)
+    coords[dim] = full.values
+    return type(da)(vals, da.dims, coords, getattr(da, "name", None))
 
 
 def _coord(da, dim):
@@ -196,8 +216,8 @@ class LCS:
                 u = u.resample({timedim: resample}).interpolate('linear')
                 v = v.resample({timedim: resample}).interpolate('linear')
             else:
-                u = labelled.resample_linear(u, timedim, resample)
-                v = labelled.resample_linear(v, timedim, resample)
+                u = _resample_linear(u, timedim, resample)
+                v = _resample_linear(v, timedim, resample)
             timestep = np.sign(timestep) * (u[timedim].values[1] - u[timedim].values[0]) \
                 .astype('timedelta64[s]').astype('float')
         assert set(u.dims) == set(v.dims), "u and v dims are different"                     # LCS.py:95
@@ -214,9 +234,9 @@ class LCS:
                 vv, _, _ = preprocess.regrid_common_grid(eng, vv, lat, lon)
                 lat, lon = lat_new, lon_new
             if truncation is not None:                                     # LCS.py:115-118
-                preprocess.check_regular_global_lat(lat)
-                uu = preprocess.spectral_truncate(eng, uu, truncation)
-                vv = preprocess.spectral_truncate(eng, vv, truncation)
+                gridtype = preprocess.inspect_gridtype(lat)              # windspharm's: equally spaced global, or Gaussian
+                uu = preprocess.spectral_truncate(eng, uu, truncation, gridtype)
+                vv = preprocess.spectral_truncate(eng, vv, truncation, gridtype)
             cyclic_xboundary = True                                        # LCS.py:119-120
             self.subdomain = None
         else:

@@ -273,9 +273,10 @@ class Engine:
                                                    p(c[2]), int(c[2].size), p(c[3]), int(c[3].size), self._ptr(out)), self.lib)
         return out
 
-    def spectral_truncate(self, f, T=20):
+    def spectral_truncate(self, f, T=20, gridtype="regular"):
         """Triangular truncation at total wavenumber T of fields (..., nlat, nlon), latitude ascending, on
-        SPHEREPACK's equally spaced grid (LCS/LCS.py:115-118).  Same shape and dtype back (device tensor)."""
+        SPHEREPACK's equally spaced grid or (``gridtype='gaussian'``) on Gaussian latitudes (LCS/LCS.py:115-118).
+        Same shape and dtype back (device tensor)."""
         dtype = common_dtype(f)
         fd = self.to_device(f, dtype)
         shape = tuple(int(s) for s in fd.shape)
@@ -283,7 +284,8 @@ class Engine:
         nb = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
         out = self._empty(shape, dtype)
         self._use_current_stream()
-        _capi.check(self.lib.lc_spectral_truncate(self.ctx, self._ptr(fd), _NP2LC[dtype], nb, nlat, nlon, int(T),
+        gt = {"regular": _capi.LC_GRID_REGULAR, "gaussian": _capi.LC_GRID_GAUSSIAN}[gridtype]
+        _capi.check(self.lib.lc_spectral_truncate(self.ctx, self._ptr(fd), _NP2LC[dtype], nb, nlat, nlon, int(T), gt,
                                                   self._ptr(out)), self.lib)
         return out
 

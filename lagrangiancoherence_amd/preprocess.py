@@ -20,7 +20,8 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["COMMON_LATS", "COMMON_LONS", "regrid_common_grid", "spectral_truncate", "check_regular_global_lat"]
+__all__ = ["COMMON_LATS", "COMMON_LONS", "regrid_common_grid", "spectral_truncate", "inspect_gridtype",
+           "check_regular_global_lat"]
 
 COMMON_LATS = np.linspace(-89.75, 89.75, 180 * 2)        # LCS.py:107
 COMMON_LONS = np.linspace(-180, 179.5, 360 * 2 + 1)      # LCS.py:108
@@ -34,23 +35,29 @@ def regrid_common_grid(engine, u, lat, lon, lats=COMMON_LATS, lons=COMMON_LONS):
     return engine.regrid(u, lat, lon, lats, lons), lats, lons
 
 
+def inspect_gridtype(lat):
+    """windspharm's grid inspection (``VectorWind`` at LCS/LCS.py:116): ``'regular'`` for equally spaced global
+    latitudes (an even count half a spacing away from the poles, an odd count on them), ``'gaussian'`` for Gaussian
+    latitudes, ``ValueError`` with windspharm's message otherwise.  Any order; ``lc_inspect_gridtype`` does the work."""
+    import ctypes as C
+    from . import _capi
+    lib = _capi.load()
+    a = np.ascontiguousarray(np.sort(np.asarray(lat, dtype=np.float64)))
+    gt = C.c_int()
+    _capi.check(lib.lc_inspect_gridtype(a.ctypes.data_as(C.c_void_p), int(a.size), C.byref(gt)), lib)
+    return "gaussian" if gt.value == _capi.LC_GRID_GAUSSIAN else "regular"
+
+
 def check_regular_global_lat(lat):
-    """windspharm's grid inspection for equally spaced latitudes (``windspharm.tools``): an even count
-    must sit at +-(90 - delta/2) ..., an odd count at the poles and equator."""
-    lat = np.asarray(lat, dtype=np.float64)
-    n = lat.size
-    d = np.abs(np.diff(lat))
-    if not (np.abs(d - d[0]) < 5e-4).all():
-        raise ValueError("latitudes are neither equally-spaced or Gaussian (Gaussian grids are not supported here)")
-    ref = np.linspace(90, -90, n) if n % 2 else np.linspace(90 - 90.0 / n, -90 + 90.0 / n, n)
-    if not np.allclose(np.sort(lat)[::-1], ref, atol=5e-4):
-        raise ValueError("Invalid equally-spaced latitudes (they may be non-global)")
+    """Kept for callers of the earlier name: raises unless :func:`inspect_gridtype` accepts the latitudes."""
+    inspect_gridtype(lat)
 
 
-def spectral_truncate(engine, f, T=20):
+def spectral_truncate(engine, f, T=20, gridtype="regular"):
     """f: (..., nlat, nlon) array or device tensor, latitude ASCENDING.  Returns a device tensor of the
-    same shape and dtype: the triangular-T truncation on the same grid."""
+    same shape and dtype: the triangular-T truncation on the same grid (``gridtype``: what
+    :func:`inspect_gridtype` says of the latitudes)."""
     nlat, nlon = int(f.shape[-2]), int(f.shape[-1])
     if T > nlat - 1 or T > (nlon - 1) // 2:
         raise ValueError(f"truncation {T} too high for a {nlat}x{nlon} grid")
-    return engine.spectral_truncate(f, T)
+    return engine.spectral_truncate(f, T, gridtype)

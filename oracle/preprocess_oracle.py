@@ -31,7 +31,8 @@ import pandas as pd
 from scipy.interpolate import interp1d
 
 __all__ = ["COMMON_LATS", "COMMON_LONS", "regrid_common_grid", "legendre_normalized", "truncation_operators",
-           "spectral_truncate"]
+           "truncation_operators_gaussian", "gaussian_latitudes", "spectral_truncate", "spectral_truncate_quadrature",
+           "spectral_truncate_lstsq"]
 
 COMMON_LATS = np.linspace(-89.75, 89.75, 180 * 2)        # LCS.py:107
 COMMON_LONS = np.linspace(-180, 179.5, 360 * 2 + 1)      # LCS.py:108
@@ -100,16 +101,94 @@ def truncation_operators(nlat, T):
     return ops
 
 
-def spectral_truncate(f, T=20):
+def gaussian_latitudes(nlat):
+    """Gaussian latitudes (degrees, ASCENDING) and weights of an nlat-row grid: asin of the Gauss-Legendre nodes."""
+    x, w = np.polynomial.legendre.leggauss(nlat)
+    return np.degrees(np.arcsin(x)), w
+
+
+def truncation_operators_gaussian(nlat, T):
+    """windspharm gridtype 'gaussian' (SPHEREPACK shags / shsgs): analysis by Gauss-Legendre quadrature on the grid's
+    own nodes, a^m_n = sum_j w_j Pbar^m_n(x_j) g_m(x_j), synthesis on the same nodes.  Rows north -> south."""
+    x, w = np.polynomial.legendre.leggauss(nlat)
+    x, w = x[::-1], w[::-1]
+    ops = []
+    for m in range(T + 1):
+        P = legendre_normalized(m, T, x)                            # (n, i)
+        ops.append(P.T @ (P * w[None, :]))
+    return ops
+
+
+def spectral_truncate(f, T=20, gridtype="regular"):
     """f: (..., nlat, nlon) with latitude ASCENDING (south -> north), as everywhere in this repo.
     Returns the T-truncated field on the same grid.  windspharm reorders to north -> south internally
-    and gives the result back on the field's own coordinates."""
+    and gives the result back on the field's own coordinates.  ``gridtype``: 'regular' (SPHEREPACK's equally
+    spaced grid) or 'gaussian' -- what windspharm's inspection of the latitudes decides."""
     f = np.asarray(f, dtype=np.float64)
     nlat, nlon = f.shape[-2:]
     g = f[..., ::-1, :]                                             # north -> south
     F = np.fft.rfft(g, axis=-1)                                     # zonal Fourier coefficients
-    ops = truncation_operators(nlat, T)
+    ops = truncation_operators_gaussian(nlat, T) if gridtype == "gaussian" else truncation_operators(nlat, T)
     out = np.zeros_like(F)
     for m in range(min(T, F.shape[-1] - 1) + 1):
         out[..., :, m] = np.einsum("ij,...j->...i", ops[m], F[..., :, m])
+    return np.fft.irfft(out, n=nlon, axis=-1)[..., ::-1, :]
+
+
+# ------------------------------------------------------------------------------------------------
+# Two INDEPENDENT formulations of the same truncation, written from other sources than the operator above.  They do
+# not pin it against pyspharm (nothing can, here) -- they bound how far a correct equally-spaced analysis can be from
+# it: all three agree to rounding on band-limited fields (degree <= nlat - 1 - T), and differ on anything else only by
+# how each aliases the content the grid cannot represent.  tests/test_preprocess.py reports that difference on the
+# regridded config-1 wind and on a non-band-limited field as the aliasing uncertainty of row f2.
+# ------------------------------------------------------------------------------------------------
+def _clenshaw_curtis_weights(nlat):
+    """Weights w_i with sum_i w_i f(theta_i) = integral_0^pi f(theta) sin(theta) dtheta exactly for every cosine
+    polynomial f of degree <= N = nlat - 1 on theta_i = i pi / N (Clenshaw & Curtis 1960; the quadrature behind the
+    Driscoll-Healy / SHTns regular-grid transforms)."""
+    N = nlat - 1
+    i = np.arange(nlat)
+    w = np.zeros(nlat)
+    for k in range(0, N + 1, 2):                                    # integral cos(k theta) sin(theta) = 2 / (1 - k^2), k even
+        c = (2.0 / N) * np.cos(k * i * np.pi / N)
+        c[[0, -1]] *= 0.5
+        w += (0.5 if k in (0, N) else 1.0) * c * 2.0 / (1.0 - k * k)
+    return w
+
+
+def spectral_truncate_quadrature(f, T=20):
+    """Formulation 2 (discrete quadrature): a^m_n = sum_i w_i Pbar^m_n(cos theta_i) g_m(theta_i) with the
+    Clenshaw-Curtis weights of the equally spaced grid -- exact while g_m Pbar^m_n is a cosine polynomial of degree
+    <= nlat - 1, i.e. for fields band-limited to degree nlat - 1 - T; beyond that it aliases differently from the
+    exact integral of the interpolant that SPHEREPACK's Z functions (and ``spectral_truncate``) evaluate."""
+    f = np.asarray(f, dtype=np.float64)
+    nlat, nlon = f.shape[-2:]
+    theta = np.arange(nlat) * np.pi / (nlat - 1)
+    w = _clenshaw_curtis_weights(nlat)
+    F = np.fft.rfft(f[..., ::-1, :], axis=-1)
+    out = np.zeros_like(F)
+    for m in range(min(T, F.shape[-1] - 1) + 1):
+        P = legendre_normalized(m, T, np.cos(theta))               # (n, i)
+        a = np.einsum("ni,...i->...n", P * w[None, :], F[..., :, m])
+        out[..., :, m] = np.einsum("ni,...n->...i", P, a)
+    return np.fft.irfft(out, n=nlon, axis=-1)[..., ::-1, :]
+
+
+def spectral_truncate_lstsq(f, T=20):
+    """Formulation 3 (least squares): per zonal wavenumber m the coefficients a^m_n, n = m..T, that minimise the
+    area-weighted misfit sum_i sin(theta_i) |g_m(theta_i) - sum_n a_n Pbar^m_n(cos theta_i)|^2 on the grid rows (the
+    poles carry no area and no weight) -- the explicit fit of Y^m_n, n <= T, solved with numpy.linalg.lstsq."""
+    f = np.asarray(f, dtype=np.float64)
+    nlat, nlon = f.shape[-2:]
+    theta = np.arange(nlat) * np.pi / (nlat - 1)
+    sw = np.sqrt(np.sin(theta))
+    F = np.fft.rfft(f[..., ::-1, :], axis=-1)
+    out = np.zeros_like(F)
+    lead = F.shape[:-2]
+    for m in range(min(T, F.shape[-1] - 1) + 1):
+        P = legendre_normalized(m, T, np.cos(theta))               # (n, i)
+        A = (P * sw[None, :]).T                                    # (i, n)
+        rhs = (F[..., :, m] * sw).reshape(-1, nlat).T              # (i, batch)
+        coef = np.linalg.lstsq(A, rhs, rcond=None)[0]              # (n, batch)
+        out[..., :, m] = (P.T @ coef).T.reshape(lead + (nlat,))
     return np.fft.irfft(out, n=nlon, axis=-1)[..., ::-1, :]

@@ -1,11 +1,10 @@
-"""A very small labelled-array container, used ONLY where xarray is not installed.
+"""TEST SUPPORT -- a very small labelled-array container for machines without xarray.
 
-The drop-in surface (`dropin.py`) is xarray-in / xarray-out like the reference.
-This image has no xarray, so the same code path is exercised in the tests with
-these stand-ins: they carry exactly what the adapter reads (``dims``, ``values``,
-per-dimension coordinates, scalar coordinates, ``name``) and nothing else.  When
-xarray is importable the adapter builds real ``xarray.DataArray`` objects and this
-module is not involved.
+The drop-in surface (`lagrangiancoherence_amd/dropin.py`) is xarray-in / xarray-out like the reference.  This image
+has no xarray, so the tests exercise the same adapter code with these stand-ins: they carry exactly what the adapter
+reads (``dims``, ``values``, per-dimension coordinates, scalar coordinates, ``name``) and nothing else.  The adapter
+knows nothing of this module: it returns results in the class of what it was given (``type(input)(data, dims, coords,
+name)``), or real ``xarray.DataArray`` objects for xarray inputs.  Not part of the product package.
 """
 from __future__ import annotations
 
@@ -83,22 +82,9 @@ class DataArray:
 
 
 def resample_linear(da, dim, freq):
-    """``da.resample({dim: freq}).interpolate('linear')`` (LCS/LCS.py:89-90) for a labelled array: the new time
-    axis is pandas' resampling index of the old one (what xarray's grouper calls ``full_index``), the values go
-    through ``scipy.interpolate.interp1d(kind='linear', bounds_error=False)`` on the times as float64 nanoseconds
-    since the first one -- the two kernels xarray itself delegates to."""
-    import pandas as pd
-    from scipy.interpolate import interp1d
-    t = pd.DatetimeIndex(np.asarray(da.coords[dim]))
-    full = pd.Series(np.arange(t.size), index=t).resample(freq).asfreq().index
-    t0 = t.values.astype("datetime64[ns]").min()
-    x = (t.values.astype("datetime64[ns]") - t0).astype("int64").astype(np.float64)
-    xn = (full.values.astype("datetime64[ns]") - t0).astype("int64").astype(np.float64)
-    ax = da.dims.index(dim)
-    vals = interp1d(x, da.values, kind="linear", axis=ax, bounds_error=False, assume_sorted=True)(xn)
-    coords = dict(da.coords)
-    coords[dim] = full.values
-    return DataArray(vals, da.dims, coords, da.name)
+    """``da.resample({dim: freq}).interpolate('linear')`` for a stand-in: the drop-in's own helper (dropin._resample_linear)."""
+    from lagrangiancoherence_amd.dropin import _resample_linear
+    return _resample_linear(da, dim, freq)
 
 
 class Dataset:

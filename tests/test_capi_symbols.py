@@ -100,7 +100,7 @@ def test_common_grid_is_numpy_linspace(lib):
 def test_new_entry_points_validate_before_touching_a_device(lib):
     import ctypes as C
     assert lib.lc_regrid_common_grid(None, None, 0, 1, 2, 2, None, None, None, 1, None, 1, None) == _capi.LC_EINVAL
-    assert lib.lc_spectral_truncate(None, None, 0, 1, 8, 16, 4, None) == _capi.LC_EINVAL
+    assert lib.lc_spectral_truncate(None, None, 0, 1, 8, 16, 4, 0, None) == _capi.LC_EINVAL
     assert lib.lc_lcs_global_host(None, None, None, 0, 2, 4, 4, None, None, 1, 20, -900.0, 4, 3, 0.0, 1, 0,
                                   None, None, None) == _capi.LC_EINVAL
     assert b"null context" in lib.lc_last_error()

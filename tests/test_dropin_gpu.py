@@ -9,7 +9,8 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from lagrangiancoherence_amd import flows, labelled
+from lagrangiancoherence_amd import flows
+from tests import labelled
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")

@@ -12,7 +12,8 @@ import pandas as pd
 import pytest
 import torch
 
-from lagrangiancoherence_amd import dropin, flows, labelled
+from lagrangiancoherence_amd import dropin, flows
+from tests import labelled
 from lagrangiancoherence_amd.engine import common_dtype
 from oracle import lcs_oracle as O
 

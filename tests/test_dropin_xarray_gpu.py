@@ -1,6 +1,6 @@
 """The drop-in surface on REAL xarray objects (examples/ideal_vortex.py:262-288).  xarray is not installed in the
 build image nor on the GPU boxes of this pool, so everywhere else the adapter is exercised with
-`lagrangiancoherence_amd.labelled` stand-ins; this file runs wherever `import xarray` works and is skipped
+`tests/labelled.py` stand-ins; this file runs wherever `import xarray` works and is skipped
 otherwise.  Every call is made twice -- xarray objects and labelled stand-ins over the same numbers -- and must
 return the same values with xarray's own types, dims and coordinates."""
 import numpy as np
@@ -9,7 +9,8 @@ import pytest
 xr = pytest.importorskip("xarray")
 pd = pytest.importorskip("pandas")
 
-from lagrangiancoherence_amd import flows, labelled  # noqa: E402
+from lagrangiancoherence_amd import flows  # noqa: E402
+from tests import labelled  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 

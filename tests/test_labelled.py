@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from lagrangiancoherence_amd import labelled
+from tests import labelled
 
 
 def _da():

@@ -63,11 +63,68 @@ def test_truncation_is_the_exact_projector_on_band_limited_fields():
 
 
 def test_grid_inspection_like_windspharm():
-    PP.check_regular_global_lat(PP.COMMON_LATS)                        # 360 rows at +-(90 - 0.25): accepted
-    PP.check_regular_global_lat(np.linspace(-90, 90, 181))             # odd count: poles + equator
+    assert PP.inspect_gridtype(PP.COMMON_LATS) == "regular"            # 360 rows at +-(90 - 0.25): accepted
+    assert PP.inspect_gridtype(np.linspace(-90, 90, 181)) == "regular"  # odd count: poles + equator
+    assert PP.inspect_gridtype(np.linspace(90, -90, 181)) == "regular"  # any order
     with pytest.raises(ValueError, match="non-global"):
-        PP.check_regular_global_lat(np.arange(-88.0, 89.0, 2.0))       # the example's own 89-row grid
-    with pytest.raises(ValueError, match="equally-spaced"):
-        PP.check_regular_global_lat(np.array([-60.0, -10.0, 0.0, 70.0]))
+        PP.inspect_gridtype(np.arange(-88.0, 89.0, 2.0))               # the example's own 89-row grid
+    with pytest.raises(ValueError, match="neither equally-spaced or Gaussian"):
+        PP.inspect_gridtype(np.array([-60.0, -10.0, 0.0, 70.0]))
+    # Gaussian latitudes (what windspharm accepts when interp_to_common_grid=False hands it e.g. an N32 / N80 grid)
+    for n in (64, 160):
+        glat, _ = PO.gaussian_latitudes(n)
+        assert PP.inspect_gridtype(glat) == "gaussian" and PP.inspect_gridtype(glat[::-1] + 3e-4) == "gaussian"
+        with pytest.raises(ValueError, match="neither equally-spaced or Gaussian"):
+            PP.inspect_gridtype(glat + np.where(np.arange(n) == n // 3, 0.01, 0.0))
+    PP.check_regular_global_lat(PP.COMMON_LATS)                        # the earlier name still works
     with pytest.raises(ValueError, match="too high"):
         PP.spectral_truncate(None, np.zeros((10, 30)), 20)             # refused before any engine call
+
+
+def test_gaussian_grid_truncation_is_the_exact_projector():
+    """windspharm gridtype 'gaussian' (LCS.py:115-117 with interp_to_common_grid=False on a Gaussian grid): Gauss-Legendre
+    analysis on the grid's own nodes -- degree <= T unchanged, everything else representable on the grid removed."""
+    nlat, nlon, T = 64, 128, 21
+    glat, _ = PO.gaussian_latitudes(nlat)
+    x, lam = np.sin(np.radians(glat)), 2 * np.pi * np.arange(nlon) / nlon
+
+    def H(m, n):
+        return PO.legendre_normalized(m, n, x)[n - m][:, None] * np.cos(m * lam + 0.3)[None, :]
+    for m, n in [(0, 0), (1, 5), (21, 21), (3, 20)]:
+        np.testing.assert_allclose(PO.spectral_truncate(H(m, n), T, "gaussian"), H(m, n), atol=2e-12)
+    for m, n in [(0, 22), (1, 40), (5, 63), (22, 30)]:
+        np.testing.assert_allclose(PO.spectral_truncate(H(m, n), T, "gaussian"), 0.0, atol=5e-12)
+    g = np.random.default_rng(1).standard_normal((2, nlat, nlon))
+    once = PO.spectral_truncate(g, T, "gaussian")
+    np.testing.assert_allclose(PO.spectral_truncate(once, T, "gaussian"), once, atol=1e-11)
+
+
+def test_t20_truncation_against_two_independent_formulations(capsys):
+    """SURVEY 8f rank 2 stays unpinned against pyspharm (not installable here).  What CAN be run: two formulations of the
+    same truncation written from other sources -- Clenshaw-Curtis quadrature analysis (the Driscoll-Healy / SHTns
+    regular-grid form) and an explicit area-weighted least-squares fit of Y^m_n, n <= T -- against the operator the kernels
+    implement (exact integral of the trigonometric interpolant, SPHEREPACK's Z functions).  All three agree to rounding on
+    fields band-limited to degree nlat - 1 - T; on anything else they differ only in how they alias what the grid cannot
+    represent, and that difference is the aliasing uncertainty of the row: reported here on the very input of the path
+    (config 1's wind regridded to 360 x 721, T20) and on a non-band-limited field."""
+    from lagrangiancoherence_amd import flows
+    nlat, nlon, T = 60, 121, 8
+    for m, n in [(0, 0), (0, 5), (1, 8), (8, 8), (2, 30), (0, 51), (3, 40)]:       # n <= nlat - 1 - T = 51
+        f = _harmonic(m, n, nlat, nlon)
+        a, b = PO.spectral_truncate(f, T), PO.spectral_truncate_quadrature(f, T)
+        np.testing.assert_allclose(b, a, atol=5e-12)
+        if n <= T:                                                                 # the least-squares fit reproduces what it spans
+            np.testing.assert_allclose(PO.spectral_truncate_lstsq(f, T), a, atol=5e-12)
+    u, v, lat, lon = flows.config1()
+    ur, _, _ = PO.regrid_common_grid(u[:2], lat, lon)
+    a, b, c = PO.spectral_truncate(ur, 20), PO.spectral_truncate_quadrature(ur, 20), PO.spectral_truncate_lstsq(ur, 20)
+    scale = np.abs(a).max()
+    dq, dl = np.abs(a - b).max(), np.abs(a - c).max()
+    g = np.random.default_rng(3).standard_normal((1, 360, 721))                    # white noise: as non-band-limited as it gets
+    an, bn, cn = PO.spectral_truncate(g, 20), PO.spectral_truncate_quadrature(g, 20), PO.spectral_truncate_lstsq(g, 20)
+    dqn, dln, sn = np.abs(an - bn).max(), np.abs(an - cn).max(), np.abs(an).max()
+    with capsys.disabled():
+        print(f"\nT20 aliasing uncertainty: config-1 wind (|u_T20| <= {scale:.1f} m/s): quadrature form {dq:.1e} m/s, "
+              f"least-squares form {dl:.1e} m/s; white noise (|.| <= {sn:.2f}): {dqn:.1e}, {dln:.1e}")
+    assert dq < 1e-6 and dl < 1e-3 * scale            # measured: 1.2e-8 m/s and 3.8e-4 m/s of 17.6 m/s
+    assert dqn < 1e-4 * sn and dln < 5e-3 * sn        # measured: 6.9e-7 and 1.3e-4 of 0.16

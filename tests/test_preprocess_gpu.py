@@ -98,13 +98,33 @@ def test_truncation_kernels_match_oracle_on_the_reference_grid(eng):
         np.testing.assert_allclose(PP.spectral_truncate(eng, f2, 12).cpu().numpy(), PO.spectral_truncate(f2, 12), atol=5e-13)
     np.testing.assert_allclose(PP.spectral_truncate(eng, f[0], 20).cpu().numpy(), ref[0], rtol=0, atol=5e-13)
     with pytest.raises(ValueError):
-        eng.spectral_truncate(np.zeros((40, 90)), 40)                  # 2(T+1) <= 64 in this build
+        eng.spectral_truncate(np.zeros((40, 90)), 45)                  # T > (nlon - 1) / 2
+    # truncations beyond 31 (T42, T63 ... what windspharm accepts): the kernels walk the spectral columns 64 at a time
+    f3 = rng.standard_normal((2, 96, 192))
+    for T in (42, 63):
+        np.testing.assert_allclose(PP.spectral_truncate(eng, f3, T).cpu().numpy(), PO.spectral_truncate(f3, T), atol=2e-12)
+
+
+def test_truncation_on_gaussian_latitudes(eng):
+    """windspharm gridtype 'gaussian' (LCS.py:115-117 when interp_to_common_grid=False hands it a Gaussian grid)."""
+    rng = np.random.default_rng(7)
+    nlat, nlon = 64, 128
+    glat, _ = PO.gaussian_latitudes(nlat)
+    assert PP.inspect_gridtype(glat) == "gaussian"
+    f = rng.standard_normal((3, nlat, nlon))
+    for T in (21, 42):
+        got = PP.spectral_truncate(eng, f, T, "gaussian").cpu().numpy()
+        np.testing.assert_allclose(got, PO.spectral_truncate(f, T, "gaussian"), atol=2e-12)
+        np.testing.assert_allclose(PP.spectral_truncate(eng, got, T, "gaussian").cpu().numpy(), got, atol=1e-11)   # idempotent
+    # the same rows read as SPHEREPACK's equally spaced grid give another field: the grid type matters
+    assert np.abs(PP.spectral_truncate(eng, f, 21, "regular").cpu().numpy() - PO.spectral_truncate(f, 21, "gaussian")).max() > 1e-3
 
 
 def test_global_host_route_equals_the_dropin_and_the_oracle():
     """lc_lcs_global_host (torch-free: host arrays in, host arrays out) = the drop-in's LCS(...)(ds, isglobal=True):
     regrid, T20, cubic interpolation, cyclic (LCS.py:105-157); and both against the oracle's composition."""
-    from lagrangiancoherence_amd import flows, labelled
+    from lagrangiancoherence_amd import flows
+    from tests import labelled
     from lagrangiancoherence_amd.engine import lcs_global_host
     from LagrangianCoherence.LCS.LCS import LCS
     from oracle import lcs_oracle as O
@@ -127,5 +147,5 @@ def test_global_host_route_equals_the_dropin_and_the_oracle():
     o2 = lcs_global_host(u.astype(np.float32), v.astype(np.float32), lat, lon, -21600.0, SETTLS_order=4, interp_order=1,
                          interp_to_common_grid=False, truncation=None)
     assert o2["sigma"].shape == (89, 180) and o2["sigma"].dtype == np.float32 and np.isfinite(o2["sigma"]).all()
-    with pytest.raises(ValueError, match="equally spaced global"):      # windspharm refuses the 89-row grid
+    with pytest.raises(ValueError, match="non-global"):                 # windspharm refuses the 89-row grid
         lcs_global_host(u, v, lat, lon, -21600.0, interp_to_common_grid=False, truncation=20)

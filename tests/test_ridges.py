@@ -95,7 +95,8 @@ def test_ridge_classify_kernel_vs_numpy_eig():
 @pytest.mark.gpu
 def test_find_ridges_drop_in_vs_oracle():
     from LagrangianCoherence.LCS.tools import find_ridges_spherical_hessian
-    from lagrangiancoherence_amd import flows, labelled
+    from lagrangiancoherence_amd import flows
+    from tests import labelled
     from lagrangiancoherence_amd.dropin import get_engine
     u, v, lat, lon = flows.config1()
     eng = get_engine()
@@ -137,7 +138,7 @@ def test_find_ridges_regional_branch_vs_oracle():
     """find_ridges_spherical_hessian(isglobal=False) (LCS/tools.py:52-55,77-81): every derivative takes the regional
     longitude stencil (one-sided on the two first / last columns, tools.py:229-244) instead of the cyclic one."""
     from LagrangianCoherence.LCS.tools import find_ridges_spherical_hessian
-    from lagrangiancoherence_amd import labelled
+    from tests import labelled
     lat = np.linspace(-30, 30, 61)
     lon = np.linspace(-80, -20, 91)                                              # a regional box: nothing to wrap
     LON, LAT = np.meshgrid(lon, lat)

@@ -31,14 +31,25 @@ class OracleEngine:
         self.args = (u, v, lat, lon)
         self.slat, self.slon = seed_lat_global, seed_lon
 
+    reducer = None       # what set_flag_allreduce last installed: ("on", group, comm) or None
+    log = ()
+
+    def set_flag_allreduce(self, group=None, comm=None, enable=True):
+        self.reducer = ("on", group, comm) if enable else None
+        self.log = self.log + (("install" if enable else "remove"),)
+
     def advect(self, field, seed_lat, seed_lon, timestep, SETTLS_order, interp_order, cyclic, t0, nsteps, row0=0,
-               ny_global=None, halo=None):
+               ny_global=None, halo=None, noncyclic_clamp=None):
         from oracle import lcs_oracle as O
         u, v, lat, lon = self.args
         assert ny_global == self.slat.size and np.array_equal(seed_lat, self.slat[row0:row0 + len(seed_lat)])
+        if not cyclic and noncyclic_clamp in (None, "reference_outer") and len(seed_lat) != ny_global:
+            # the real lc_advect refuses the reference's clamp on a row block without the ranks' flag all-reduce
+            assert self.reducer is not None, "row block with the reference's non-cyclic clamp but no flag all-reduce"
         x, y = O.parcel_propagation(u, v, lat, lon, timestep=timestep, SETTLS_order=SETTLS_order,
                                     interp_order=interp_order, cyclic_xboundary=cyclic, seed_lat=self.slat,
-                                    seed_lon=self.slon, t0=t0, nsteps=nsteps)
+                                    seed_lon=self.slon, t0=t0, nsteps=nsteps,
+                                    **({} if cyclic else {"noncyclic_clamp": noncyclic_clamp or "reference_outer"}))
         n = len(seed_lat)
         n_lo, n_hi = halo if halo else (0, 0)
         xe = torch.full((n_lo + n + n_hi, x.shape[1]), float("nan"), dtype=torch.float64)
@@ -97,6 +108,24 @@ def _worker(rank, world, port, ny, q):
         out2 = sharded.sharded_lcs(eng, _Field(), slat, slon, -3600.0, rank, world, SETTLS_order=2, interp_order=1,
                                    redundant_halo=True)
         assert np.array_equal(out2["sigma"].numpy(), out["sigma"].numpy())
+        assert eng.log == ()                       # cyclic: no flag all-reduce is ever installed
+        # 4. cyclic_xboundary=False (the reference's DEFAULT call form): the reference's outer-product clamp couples the
+        # rows through the offending columns, so the sharded driver must install the ranks' flag all-reduce around the
+        # advection (the real lc_advect refuses a row block without it; the stand-in asserts the same) and remove it
+        # afterwards; the result equals the unsharded oracle's with that clamp.  'pointwise' needs no communication.
+        u2 = u + 60.0                              # strong westerlies: parcels leave the longitude box
+        eng2 = OracleEngine(u2, v, lat, lon, slat, slon)
+        out3 = sharded.sharded_lcs(eng2, _Field(), slat, slon, 3600.0, rank, world, SETTLS_order=2, interp_order=1,
+                                   cyclic_xboundary=False)
+        x3, _ = O.parcel_propagation(u2, v, lat, lon, timestep=3600.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=False,
+                                     seed_lat=slat, seed_lon=slon, noncyclic_clamp="reference_outer")
+        xp, _ = O.parcel_propagation(u2, v, lat, lon, timestep=3600.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=False,
+                                     seed_lat=slat, seed_lon=slon, noncyclic_clamp="pointwise")
+        assert not np.array_equal(x3, xp), "test flow too weak: no parcel left the box"
+        assert np.array_equal(out3["x_dep"].numpy(), x3[lo:hi]) and eng2.log == ("install", "remove") and eng2.reducer is None
+        out4 = sharded.sharded_lcs(eng2, _Field(), slat, slon, 3600.0, rank, world, SETTLS_order=2, interp_order=1,
+                                   cyclic_xboundary=False, noncyclic_clamp="pointwise")
+        assert np.array_equal(out4["x_dep"].numpy(), xp[lo:hi]) and eng2.log == ("install", "remove")
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
