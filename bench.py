@@ -41,6 +41,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# environment variables that change which kernel runs or how it is launched without changing its name
+KERNEL_KNOBS = ("LCS_LIB", "LCS_LDS_TILES", "LCS_XCD_CHUNK_ROWS", "LCS_TILE_ORDER", "LCS_POLE_BLOCKS", "LCS_FIR_PREFILTER",
+                "LCS_SIGMA_MARCH", "LCS_LEVEL_CHUNK", "LCS_PATCH_MODE", "LCS_ENSEMBLE_CHUNK", "LCS_MEMBER_STREAMS", "LCS_NATIVE_HALO")
+
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_VECTOR_TFLOPS = 157.3   # same guide: peak FP32 vector
 FP64_VECTOR_TFLOPS = 78.6
@@ -290,7 +294,7 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {ny}x{nx} seeds = field nodes, moving ideal vortex, {nt} levels, "
                                f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order,
-                   "fuse_levels": bool(args.fuse_levels)},
+                   "fuse_levels": bool(args.fuse_levels), "build_id": csrc},
         "kernel_ms": ms,
         "roofline": roofline(eng.last_advect_kernel(), "valu", pts, ms["advect"], K, order, 8, 8, bool(args.fuse_levels),
                              comp, wl, csrc),
@@ -355,7 +359,17 @@ def main():
     from lagrangiancoherence_amd.build import csrc_hash
     from lagrangiancoherence_amd.engine import Engine
 
-    csrc = csrc_hash()
+    # Counter replay is tied to the BINARY that runs and to its launch configuration: lc_build_id() (the source hash the
+    # library was built from, plus any experiment -D flags) must equal the hash a profile summary is stamped with, and no
+    # kernel-shaping knob may be set; otherwise replayed fields are null.  The knobs and the library path go into the line.
+    from lagrangiancoherence_amd import _capi
+    lib = _capi.load()
+    build_id = lib.lc_build_id().decode()
+    knobs = {k: os.environ[k] for k in KERNEL_KNOBS if k in os.environ}
+    csrc = build_id if not knobs and "+" not in build_id else build_id + "|" + ",".join(f"{k}={v}" for k, v in sorted(knobs.items()))
+    if build_id.split("+")[0] != csrc_hash():
+        sys.stderr.write(f"bench.py: note: the library in use was built from sources {build_id!r}, the working tree is "
+                         f"{csrc_hash()!r} (rebuild with python -m lagrangiancoherence_amd.build)\n")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -645,6 +659,7 @@ def main():
             **({"wind_scale": args.wind_scale} if args.wind_scale != 1.0 else {}),
             **({"field": [fny, fnx]} if args.field else {}),
             **({"return_traj": True} if args.traj else {}),
+            "build_id": build_id, **({"knobs": knobs} if knobs else {}),
             "step": "pack + fused advect + halo exchange + sigma" + (" per member" if wk == "c5" else "")
                     + "; u/v/seeds resident in HBM"
                     + (f"; members advected in level-major order, {ens_chunk} levels per launch, continuing in place "

@@ -80,6 +80,11 @@ enum lc_tensor_layout {
 /* ---- library / context ------------------------------------------------- */
 int lc_version(void);
 const char *lc_last_error(void);
+/* What this binary was built from: the hash of the kernel sources + this header (comments and white space stripped;
+ * lagrangiancoherence_amd/build.py csrc_hash), followed by "+<flags>" when it is an experiment build with extra -D
+ * flags; "unstamped" for a build that bypassed build.py.  A benchmark replays committed profiler counters only for
+ * the binary they were measured on. */
+const char *lc_build_id(void);
 
 /* One context per device; distinct contexts may be used from distinct host
  * threads.  The context owns one HIP stream unless lc_ctx_set_stream lends it
@@ -114,11 +119,12 @@ int lc_ctx_set_sigma_march(lc_ctx *ctx, int on);
 typedef int (*lc_flag_allreduce_fn)(void *user, void *flags_dev, size_t count);
 int lc_ctx_set_flag_allreduce(lc_ctx *ctx, lc_flag_allreduce_fn fn, void *user);
 /* lc_advect / lc_advect_from run a series of nsteps time levels as consecutive launches of at most `levels` levels,
- * each continuing from the positions the previous one stored (0 = one launch, the default).  Results are bit-identical
- * whatever the value; it shapes the launches only (workgroups of one launch stay within `levels` levels of each other,
- * so their tiles of the wind images meet in L2 / the Infinity Cache -- sparse seed grids, long series).  The
- * environment variable LCS_LEVEL_CHUNK sets the initial value, read ONCE in lc_ctx_create.  No reference counterpart
- * (the reference's loop over time levels is LCS/trajectory.py:80-126). */
+ * each continuing from the positions the previous one stored (0 = one launch; -1 = by size, the default: 32 levels
+ * per launch from 2^22 seeds per call upwards).  Results are bit-identical whatever the value; it shapes the launches
+ * only (workgroups of one launch stay within `levels` levels of each other, so their tiles of the wind images meet in
+ * L2 / the Infinity Cache, and the launch's tail is one chunk long: long series and sparse seed grids gain 7-17 %).
+ * The environment variable LCS_LEVEL_CHUNK sets the initial value, read ONCE in lc_ctx_create.  No reference
+ * counterpart (the reference's loop over time levels is LCS/trajectory.py:80-126). */
 int lc_ctx_set_level_chunk(lc_ctx *ctx, int levels);
 /* Name of the kernel the context's last lc_advect call launched (static string, "" before the first call);
  * what a profiler shows, so a benchmark labels its numbers with the kernel that actually ran. */

@@ -23,6 +23,7 @@ _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 PROTOTYPES = {
     "lc_version": (_i, []),
     "lc_last_error": (C.c_char_p, []),
+    "lc_build_id": (C.c_char_p, []),
     "lc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "lc_ctx_destroy": (_i, [_vp]),
     "lc_ctx_set_stream": (_i, [_vp, _vp]),

@@ -78,8 +78,12 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), out
     library and selected at run time with ``LCS_LIB=<path>`` (see ``_capi.load``)."""
     if out is None and not force and not needs_build():
         return LIB
+    # the library carries the hash of the sources it was built from and the experiment flags it was built with
+    # (lc_build_id()): a benchmark ties replayed counters to the BINARY that ran, not to the working tree
+    build_id = csrc_hash() + ("" if not extra_flags else "+" + " ".join(sorted(extra_flags)))
     cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", *extra_flags,
+           f'-DLCS_BUILD_ID="{build_id}"',
            "-o", out or LIB, *[os.path.join(CSRC, s) for s in SOURCES], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

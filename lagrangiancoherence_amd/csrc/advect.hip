@@ -2375,7 +2375,13 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // series (sparse seed grids: DESIGN 4) -- and the launch's tail is one chunk long.  Positions at a level's end are
     // the kernels' whole state (the latitude clamp is applied before they are stored), so chunked == unchunked, bit
     // for bit.
-    const int chunk = ctx->level_chunk > 0 ? ctx->level_chunk : (nsteps > 0 ? nsteps : 1);
+    // Default (level_chunk < 0): 32 levels per launch from 2^22 seeds per call upwards -- measured on MI355X against one
+    // launch (profiles/r03): C3 96 steps 6.55 -> 6.46 ms, 200 steps 15.0 -> 13.9, C4 (8192^2 x 384) 100.2 -> 93.0, order 3
+    // 16.1 -> 15.8, one member of C5 (2048^2 x 200) +17 %; chunks of 16 / 24 / 48 / 64 within 1 % of 32.  Smaller grids
+    // run out of workgroups at the end of every launch and keep the single launch.
+    const int auto_chunk = (long long)ny * nx >= (1ll << 22) ? 32 : 0;
+    const int want_chunk = ctx->level_chunk < 0 ? auto_chunk : ctx->level_chunk;
+    const int chunk = want_chunk > 0 ? want_chunk : (nsteps > 0 ? nsteps : 1);
     const size_t plane_elems = (size_t)ny * nx;
     for (int s0 = 0; s0 == 0 || s0 < nsteps; s0 += chunk) {
         AdvectArgs<T> C = A;

@@ -18,6 +18,10 @@ void lc_set_error(const char *fmt, ...) {
 
 extern "C" const char *lc_last_error(void) { return g_err; }
 extern "C" int lc_version(void) { return LC_VERSION; }
+#ifndef LCS_BUILD_ID
+#define LCS_BUILD_ID "unstamped"
+#endif
+extern "C" const char *lc_build_id(void) { return LCS_BUILD_ID; }
 
 extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     LC_REQUIRE(out, "lc_ctx_create: null out pointer");
@@ -52,8 +56,8 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     if (const char *ev = getenv("LCS_FIR_PREFILTER")) c->fir_prefilter = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);  // read once, here
     c->sigma_march = 2;  // by size
     if (const char *ev = getenv("LCS_SIGMA_MARCH")) c->sigma_march = ev[0] == '0' ? 0 : (ev[0] == '1' ? 1 : 2);  // read once, here
-    c->level_chunk = 0;
-    if (const char *ev = getenv("LCS_LEVEL_CHUNK")) c->level_chunk = atoi(ev) > 0 ? atoi(ev) : 0;  // read once, here
+    c->level_chunk = -1;  // by size (advect.hip: 32 levels per launch from 2^22 seeds per call)
+    if (const char *ev = getenv("LCS_LEVEL_CHUNK")) c->level_chunk = atoi(ev) >= 0 ? atoi(ev) : -1;  // read once, here
     c->patch_mode = -1;
     if (const char *ev = getenv("LCS_PATCH_MODE")) c->patch_mode = (ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : -1;  // read once, here
     c->flag_reduce = nullptr;
@@ -90,7 +94,7 @@ extern "C" int lc_ctx_set_flag_allreduce(lc_ctx *ctx, lc_flag_allreduce_fn fn, v
 
 extern "C" int lc_ctx_set_level_chunk(lc_ctx *ctx, int levels) {
     LC_REQUIRE(ctx, "lc_ctx_set_level_chunk: null context");
-    LC_REQUIRE(levels >= 0, "lc_ctx_set_level_chunk: levels must be >= 0 (0 = one launch for the whole series)");
+    LC_REQUIRE(levels >= -1, "lc_ctx_set_level_chunk: levels must be >= -1 (0 = one launch for the whole series, -1 = by size)");
     ctx->level_chunk = levels;
     return LC_OK;
 }

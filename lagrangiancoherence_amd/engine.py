@@ -111,8 +111,9 @@ class Engine:
         _capi.check(self.lib.lc_ctx_set_sigma_march(self.ctx, int(on)), self.lib)
 
     def set_level_chunk(self, levels: int):
-        """Run every advect call as consecutive launches of at most ``levels`` time levels (0: one launch).  Results are
-        bit-identical; it shapes the launches only (``lc_ctx_set_level_chunk``)."""
+        """Run every advect call as consecutive launches of at most ``levels`` time levels (0: one launch; -1: by size,
+        the default -- 32 levels from 2^22 seeds per call).  Results are bit-identical; it shapes the launches only
+        (``lc_ctx_set_level_chunk``)."""
         _capi.check(self.lib.lc_ctx_set_level_chunk(self.ctx, int(levels)), self.lib)
 
     def set_flag_allreduce(self, group=None, comm=None, enable=True):

@@ -16,7 +16,17 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lagrangiancoherence_amd.build import csrc_hash  # noqa: E402  (stamps the summary with the sources it was measured on)
+from lagrangiancoherence_amd.build import csrc_hash  # noqa: E402
+
+
+def stamp(run):
+    """What the summary is stamped with: the build id of the LIBRARY that ran (config.build_id of the run's own bench
+    line, = lc_build_id()), so that bench.py replays these counters only for that binary; runs recorded before the
+    library carried an id fall back to the hash of the working tree's sources."""
+    try:
+        return json.load(open(os.path.join(run, "bench_stdout.json")))["config"]["build_id"]
+    except Exception:
+        return csrc_hash()
 
 
 def short(name):
@@ -57,7 +67,7 @@ def main():
             d["hbm_bytes_per_launch"] = (2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024
         if k in stats:
             d["avg_ms_kernel_trace"] = stats[k]
-    json.dump({"workload": workload, "csrc_hash": csrc_hash(), "kernels": pmc,
+    json.dump({"workload": workload, "csrc_hash": stamp(run), "kernels": pmc,
                "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts half)"},
               open(out + "_pmc_traffic.json", "w"), indent=1, sort_keys=True)
     print(json.dumps(pmc, indent=1))

@@ -22,7 +22,17 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lagrangiancoherence_amd.build import csrc_hash  # noqa: E402  (stamps the summary with the sources it was measured on)
+from lagrangiancoherence_amd.build import csrc_hash  # noqa: E402
+
+
+def stamp(run):
+    """What the summary is stamped with: the build id of the LIBRARY that ran (config.build_id of the run's own bench
+    line, = lc_build_id()), so that bench.py replays these counters only for that binary; runs recorded before the
+    library carried an id fall back to the hash of the working tree's sources."""
+    try:
+        return json.load(open(os.path.join(run, "bench_stdout.json")))["config"]["build_id"]
+    except Exception:
+        return csrc_hash()
 
 CUS = 256
 
@@ -63,7 +73,7 @@ def main():
                 "l2_hit_frac": (c.get("TCC_HIT_sum", 0) / (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))) if c.get("TCC_HIT_sum") else None,
             }
         kernels[k] = {**c, "derived": der}
-    json.dump({"workload": workload, "csrc_hash": csrc_hash(), "kernels": kernels,
+    json.dump({"workload": workload, "csrc_hash": stamp(run), "kernels": kernels,
                "note": "rocprofv3 --pmc passes (counter sets in profiles/README.md) over bench.py --steps 1 --warmup 0; "
                        "per-launch averages; GRBM_GUI_ACTIVE is summed over 8 XCDs"},
               open(out + "_pmc_sq_tcp.json", "w"), indent=1, sort_keys=True)

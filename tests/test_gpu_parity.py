@@ -760,10 +760,10 @@ def test_level_chunks_do_not_change_results(eng, order, lds, traj):
             for a, b in zip(ref, got):
                 assert bool((a == b).all()), (chunk, tuple(a.shape))
     finally:
-        eng.set_level_chunk(0)
+        eng.set_level_chunk(-1)
         eng.set_lds_tiles(-1)
     with pytest.raises(ValueError):
-        eng.set_level_chunk(-1)
+        eng.set_level_chunk(-2)
 
 
 @pytest.mark.parametrize("order", [1, 3])
