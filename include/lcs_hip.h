@@ -64,8 +64,11 @@ enum lc_xboundary {
     LC_X_CYCLIC = 1,      /* cyclic_xboundary=True: wrap hard-coded to +-180 with Python's floor-mod (Q7)          */
     /* cyclic_xboundary=False exactly as the reference computes it: `positions_x[np.where(x < x_min)] = x_min` on a
      * DataArray is orthogonal indexing, so every (row, col) in the cross product of offending rows and offending
-     * columns is set (trajectory.py:96-97, 122-123).  lc_advect runs the fused kernel first and, only
-     * if a parcel really left the box, re-runs sub-step by sub-step with that rule (synchronous in this mode).
+     * columns is set (trajectory.py:96-97, 122-123).  lc_advect runs the fused kernel in chunks of 16 time
+     * levels, reads a "clamp fired" flag back after each (the call is SYNCHRONOUS in this mode: one stream
+     * synchronisation per chunk) and, from the chunk in which a parcel first left the box, continues sub-step by
+     * sub-step with that rule (2 (K+1) launches per time level, positions in global memory) from the positions saved
+     * before that chunk; if no parcel ever leaves, the fused result stands.
      * The rule couples every seed row through the offending COLUMNS: a call on a row block (row0 != 0 or
      * ny != ny_global) needs lc_ctx_set_flag_allreduce, through which the ranks of a row-sharded grid OR their
      * column flags after every sub-step; without it such a call is refused. */

@@ -2193,7 +2193,9 @@ __global__ void outer_store_kernel(const AdvectArgs<T> A, const OuterArgs<T> O, 
 }
 
 template <typename T>
-int advect_outer_impl(lc_ctx *ctx, AdvectArgs<T> A) {
+int advect_outer_impl(lc_ctx *ctx, AdvectArgs<T> A, int s_begin = 0, const T *x0 = nullptr, const T *y0 = nullptr) {
+    // s_begin, x0, y0: restart at step s_begin from these positions (the state the fused kernel saved before the chunk
+    // of levels in which a parcel first left the box); 0 / NULL: from the seed grid
     hipStream_t st = ctx->stream;
     const size_t n = (size_t)A.ny * A.nx;
     const size_t nflag = 2 * ((size_t)A.ny + A.nx);
@@ -2211,10 +2213,15 @@ int advect_outer_impl(lc_ctx *ctx, AdvectArgs<T> A) {
     O.y = A.y_out;
     O.eu = e;
     O.ev = e + n;
-    hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.x_out, A.y_out, 1);
-    if (A.traj_x) hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.traj_x, A.traj_y, 1);
+    if (x0) {
+        (void)hipMemcpyAsync(A.x_out, x0, n * sizeof(T), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(A.y_out, y0, n * sizeof(T), hipMemcpyDeviceToDevice, st);
+    } else {
+        hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.x_out, A.y_out, 1);
+        if (A.traj_x) hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.traj_x, A.traj_y, 1);
+    }
     int sub = 0;
-    for (int s = 0; s < A.nsteps; ++s) {
+    for (int s = s_begin; s < A.nsteps; ++s) {
         for (int k = 0; k <= A.K; ++k, ++sub) {
             unsigned *cur = flags + (size_t)(sub & 1) * nflag, *prev = flags + (size_t)((sub & 1) ^ 1) * nflag;
             (void)hipMemsetAsync(cur, 0, nflag * sizeof(unsigned), st);
@@ -2243,7 +2250,7 @@ int advect_outer_impl(lc_ctx *ctx, AdvectArgs<T> A) {
             hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O,
                                A.traj_x + (size_t)(s + 1) * n, A.traj_y + (size_t)(s + 1) * n, 0);
     }
-    if (sub) hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.x_out, A.y_out, 0);
+    if (sub) hipLaunchKernelGGL((outer_store_kernel<T>), dim3(blocks), dim3(256), 0, st, A, O, A.x_out, A.y_out, 0);  // the last sub-step's flags applied
     {
         const hipError_t le = hipGetLastError();
         (void)hipFreeAsync(e, st);
@@ -2381,8 +2388,17 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // run out of workgroups at the end of every launch and keep the single launch.
     const int auto_chunk = (long long)ny * nx >= (1ll << 22) ? 32 : 0;
     const int want_chunk = ctx->level_chunk < 0 ? auto_chunk : ctx->level_chunk;
-    const int chunk = want_chunk > 0 ? want_chunk : (nsteps > 0 ? nsteps : 1);
+    // LC_X_CLAMP_REFERENCE_OUTER: chunks of 16 levels whatever the size, the clamp flag read back after each, the
+    // positions before each chunk kept -- so the sub-step path restarts at the chunk in which a parcel first left the
+    // box instead of at t0 (regional domains: parcels leave routinely; the fused work thrown away is one chunk)
+    const int chunk = outer ? (want_chunk > 0 ? want_chunk : 16) : (want_chunk > 0 ? want_chunk : (nsteps > 0 ? nsteps : 1));
     const size_t plane_elems = (size_t)ny * nx;
+    T *saved = nullptr;   // [2][ny*nx]: positions at the start of the current chunk (outer mode, from the second chunk on)
+    int restart = -1;
+    auto flag_error = [&]() {
+        lc_set_error("lc_advect: the flag all-reduce of LC_X_CLAMP_REFERENCE_OUTER failed (lc_ctx_set_flag_allreduce callback returned non-zero)");
+        return LC_ERCCL;
+    };
     for (int s0 = 0; s0 == 0 || s0 < nsteps; s0 += chunk) {
         AdvectArgs<T> C = A;
         C.t0 = t0 + s0;
@@ -2395,28 +2411,46 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 C.traj_x = A.traj_x + (size_t)s0 * plane_elems;
                 C.traj_y = A.traj_y + (size_t)s0 * plane_elems;
             }
+            if (outer) {
+                if (!saved && hipMallocAsync((void **)&saved, 2 * plane_elems * sizeof(T), ctx->stream) != hipSuccess) saved = nullptr;
+                if (saved) {
+                    (void)hipMemcpyAsync(saved, A.x_out, plane_elems * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
+                    (void)hipMemcpyAsync(saved + plane_elems, A.y_out, plane_elems * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
+                }
+            }
         }
         launch(C);
+        if (outer) {
+            unsigned moved = 0;
+            hipError_t e1 = hipGetLastError();
+            // row-sharded: "did a parcel leave the box ANYWHERE" -- every rank must take the same path below
+            const bool red_fail = e1 == hipSuccess && ctx->flag_reduce && ctx->flag_reduce(ctx->flag_reduce_user, clamp_flag, 1) != 0;
+            if (e1 == hipSuccess && !red_fail) e1 = hipMemcpyAsync(&moved, clamp_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+            if (e1 == hipSuccess && !red_fail) e1 = hipStreamSynchronize(ctx->stream);
+            if (red_fail || e1 != hipSuccess) {
+                (void)hipFreeAsync(clamp_flag, ctx->stream);
+                if (saved) (void)hipFreeAsync(saved, ctx->stream);
+                if (red_fail) return flag_error();
+                LC_HIP_CHECK(e1);
+            }
+            if (moved) {
+                restart = (s0 > 0 && !saved) ? 0 : s0;   // (no room for the saved positions: from the seed grid, as before)
+                break;
+            }
+        }
     }
     ctx->last_advect_kernel = name;
     if (outer) {
-        unsigned moved = 0;
-        hipError_t e1 = hipGetLastError();
-        // row-sharded: "did a parcel leave the box ANYWHERE" -- every rank must take the same path below
-        if (e1 == hipSuccess && ctx->flag_reduce && ctx->flag_reduce(ctx->flag_reduce_user, clamp_flag, 1) != 0) {
-            (void)hipFreeAsync(clamp_flag, ctx->stream);
-            lc_set_error("lc_advect: the flag all-reduce of LC_X_CLAMP_REFERENCE_OUTER failed (lc_ctx_set_flag_allreduce callback returned non-zero)");
-            return LC_ERCCL;
-        }
-        if (e1 == hipSuccess) e1 = hipMemcpyAsync(&moved, clamp_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
-        if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
         (void)hipFreeAsync(clamp_flag, ctx->stream);
-        LC_HIP_CHECK(e1);
         A.clamp_flag = nullptr;
-        if (moved) {
+        int rc = LC_OK;
+        if (restart >= 0) {
             A.ext = nullptr;  // the exact path keeps the reference's two-sample form
-            return advect_outer_impl<T>(ctx, A);
+            rc = advect_outer_impl<T>(ctx, A, restart, restart > 0 ? saved : (const T *)A.x_start,
+                                      restart > 0 ? saved + plane_elems : (const T *)A.y_start);
         }
+        if (saved) (void)hipFreeAsync(saved, ctx->stream);
+        if (rc != LC_OK) return rc;
     }
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;

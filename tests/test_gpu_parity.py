@@ -166,6 +166,29 @@ def test_advect_noncyclic_reference_outer_clamp(eng, O, order, K):
     assert np.array_equal(_np(x), _np(tx)[-1]) and np.array_equal(_np(y), _np(ty)[-1])
 
 
+@pytest.mark.parametrize("fuse", [False, True])
+def test_advect_noncyclic_reference_outer_restarts_at_the_chunk_where_a_parcel_first_leaves(eng, O, fuse):
+    """A long regional series whose parcels stay inside the box for the first 21 levels: the fused kernel runs in chunks
+    of 16 levels with the clamp flag read back after each, and the sub-step path (the reference's outer-product rule)
+    restarts from the positions saved before the SECOND chunk instead of from the seed grid -- same answer as the oracle
+    running the rule from the start, trajectories included."""
+    u, v, lat, lon = _rand_field(9, nt=40, ny=19, nx=27, scale=3.0)
+    u[:21] *= 0.02                      # nearly at rest, then a strong zonal flow pushes parcels out of both edges
+    u[21:] = u[21:] * 10 + 40.0
+    f = eng.prepare_field(u, v, lat, lon, 1, fuse_levels=fuse)
+    kw = dict(timestep=3600.0, SETTLS_order=1, interp_order=1, cyclic_xboundary=False)
+    x, y, tx, ty = eng.advect(f, lat, lon, 3600.0, 1, 1, False, return_traj=True)
+    assert eng.last_advect_kernel() == "outer_substep_kernel"
+    xr_, yr_ = O.parcel_propagation(u, v, lat, lon, noncyclic_clamp="reference_outer", return_traj=True, **kw)
+    xp_, _ = O.parcel_propagation(u, v, lat, lon, noncyclic_clamp="pointwise", **kw)
+    assert np.abs(xr_[-1] - xp_).max() > 1.0        # the two clamps really differ on this flow
+    np.testing.assert_allclose(_np(tx), xr_, rtol=0, atol=POS_ATOL64)
+    np.testing.assert_allclose(_np(ty), yr_, rtol=0, atol=POS_ATOL64)
+    assert np.array_equal(_np(x), _np(tx)[-1]) and np.array_equal(_np(y), _np(ty)[-1])
+    # nothing had left the box by the end of the first chunk (level 16): that is where the restart positions come from
+    assert (np.abs(xr_[16]) <= np.abs(lon).max()).all()
+
+
 def test_advect_noncyclic_reference_outer_float32_and_fast_path(eng, O):
     # float32: same band as the float32 oracle against float64
     u, v, lat, lon = _rand_field(5, nt=4, scale=60.0, dtype=np.float32)
