@@ -109,8 +109,12 @@ def stamped_counters(kernel: str, workload: dict, csrc: str):
     return out
 
 
-def roofline(kernel, bound, pts_per_launch, launches_ms, K, order, s_p, s_f, fused, compulsory_bytes, workload, csrc):
-    """The roofline object of one advect launch (per GPU).  `launches_ms`: mean HIP-event duration of one launch."""
+def roofline(kernel, bound, pts_per_launch, launches_ms, K, order, s_p, s_f, fused, compulsory_bytes, workload, csrc, n_kernel=1):
+    """The roofline object of ONE advect kernel launch (per GPU).  `launches_ms`: mean HIP-event duration of one lc_advect
+    call, which is `n_kernel` consecutive launches of the same kernel (level chunks): particle-timesteps, bytes and time
+    are divided by it, so `kernel_ms` is what a profiler's per-kernel average shows; rates and fractions do not change."""
+    n_kernel = max(int(n_kernel), 1)
+    pts_per_launch, launches_ms, compulsory_bytes = pts_per_launch / n_kernel, launches_ms / n_kernel, compulsory_bytes / n_kernel
     sec = launches_ms / 1e3
     fl = flops_pts(K, order, fused)
     peak = FP32_VECTOR_TFLOPS if s_p == 4 else FP64_VECTOR_TFLOPS
@@ -120,7 +124,7 @@ def roofline(kernel, bound, pts_per_launch, launches_ms, K, order, s_p, s_f, fus
     tr = st.get("traffic")
     return {
         "bound": bound, "kernel": kernel, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-        "flops_per_particle_timestep": fl, "kernel_ms": launches_ms,
+        "flops_per_particle_timestep": fl, "kernel_ms": launches_ms, "kernel_launches_per_advect": n_kernel,
         "traffic": tr,
         "algorithmic_GBps": pts_per_launch * by / sec / 1e9, "algorithmic_bytes_per_particle_timestep": by,
         "hbm": {"peak_GBps": HBM_PEAK_GBPS, "compulsory_bytes": compulsory_bytes,
@@ -296,8 +300,8 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
                                f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order,
                    "fuse_levels": bool(args.fuse_levels), "build_id": csrc},
         "kernel_ms": ms,
-        "roofline": roofline(eng.last_advect_kernel(), "valu", pts, ms["advect"], K, order, 8, 8, bool(args.fuse_levels),
-                             comp, wl, csrc),
+        "roofline": roofline(eng.last_advect_kernel(), "tcp", pts, ms["advect"], K, order, 8, 8,
+                             bool(args.fuse_levels), comp, wl, csrc, eng.last_advect_launches()),
     }
     if not args.no_cpu_baseline:
         from oracle import lcs_oracle as O
@@ -672,7 +676,8 @@ def main():
         "ftle_mcells_per_s": (hi - lo) * nx * n_launch * world / (ms["sigma"] / 1e3) / 1e6,
         "kernel_ms": ms,
         "roofline": {**roofline(advect_kernel, "valu" if "lds" in advect_kernel else "tcp", pts_launch, adv_ms, K, order,
-                                s_p, s_f, True, comp, wl, csrc),
+                                s_p, s_f, True, comp, wl, csrc,
+                                -(-nsteps // ens_chunk) if level_major else eng.last_advect_launches()),
                      "measured_copy_peak_GBps": copy_gbps},
         "roofline_sigma": {
             "bound": "hbm", "kernel": eng.last_sigma_kernel(), "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,

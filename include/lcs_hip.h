@@ -132,6 +132,9 @@ int lc_ctx_set_level_chunk(lc_ctx *ctx, int levels);
 /* Name of the kernel the context's last lc_advect call launched (static string, "" before the first call);
  * what a profiler shows, so a benchmark labels its numbers with the kernel that actually ran. */
 const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx);
+/* Kernel launches that call made (level chunks: lc_ctx_set_level_chunk); a benchmark divides its event time by it to
+ * quote the duration of ONE launch, the figure a profiler's per-kernel average shows. */
+int lc_ctx_last_advect_launches(const lc_ctx *ctx);
 /* The same for the context's last lc_sigma / lc_flowmap_gradient call. */
 const char *lc_ctx_last_sigma_kernel(const lc_ctx *ctx);
 

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "lc_ctx_set_level_chunk": (_i, [_vp, _i]),
     "lc_ctx_set_flag_allreduce": (_i, [_vp, _vp, _vp]),
     "lc_ctx_last_advect_kernel": (C.c_char_p, [_vp]),
+    "lc_ctx_last_advect_launches": (_i, [_vp]),
     "lc_ctx_last_sigma_kernel": (C.c_char_p, [_vp]),
     "lc_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "lc_free": (_i, [_vp, _vp]),

@@ -2393,6 +2393,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // box instead of at t0 (regional domains: parcels leave routinely; the fused work thrown away is one chunk)
     const int chunk = outer ? (want_chunk > 0 ? want_chunk : 16) : (want_chunk > 0 ? want_chunk : (nsteps > 0 ? nsteps : 1));
     const size_t plane_elems = (size_t)ny * nx;
+    int n_launches = 0;
     T *saved = nullptr;   // [2][ny*nx]: positions at the start of the current chunk (outer mode, from the second chunk on)
     int restart = -1;
     auto flag_error = [&]() {
@@ -2420,6 +2421,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
             }
         }
         launch(C);
+        ++n_launches;
         if (outer) {
             unsigned moved = 0;
             hipError_t e1 = hipGetLastError();
@@ -2440,6 +2442,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         }
     }
     ctx->last_advect_kernel = name;
+    ctx->last_advect_launches = n_launches;
     if (outer) {
         (void)hipFreeAsync(clamp_flag, ctx->stream);
         A.clamp_flag = nullptr;

@@ -65,6 +65,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->lds_tiles_init = c->lds_tiles;
     c->sigma_march_init = c->sigma_march;
     c->last_advect_kernel = "";
+    c->last_advect_launches = 0;
     c->last_sigma_kernel = "";
     c->trunc = nullptr;
     *out = c;
@@ -100,6 +101,7 @@ extern "C" int lc_ctx_set_level_chunk(lc_ctx *ctx, int levels) {
 }
 
 extern "C" const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_advect_kernel : ""; }
+extern "C" int lc_ctx_last_advect_launches(const lc_ctx *ctx) { return ctx ? ctx->last_advect_launches : 0; }
 extern "C" const char *lc_ctx_last_sigma_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_sigma_kernel : ""; }
 
 extern "C" int lc_ctx_destroy(lc_ctx *ctx) {

@@ -25,6 +25,7 @@ struct lc_ctx {
     int patch_mode;      // two-seed advect kernel, seeds of a wave / form of the trajectory stores: -1 by call (default: whole-line stores through LDS with trajectories, tall patches without), 0 tall, 1 wide, 2 lines (LCS_PATCH_MODE at creation; advect.hip enum Patch)
     lc_flag_allreduce_fn flag_reduce;  // NULL, or the caller's max-all-reduce over the ranks of a row-sharded grid (lc_ctx_set_flag_allreduce)
     void *flag_reduce_user;
+    int last_advect_launches;  // kernel launches the last lc_advect made (level chunks)
     const char *last_advect_kernel;
     const char *last_sigma_kernel;
     lc_trunc_cache *trunc;

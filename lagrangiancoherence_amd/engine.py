@@ -159,6 +159,10 @@ class Engine:
         """Name of the kernel the last :meth:`advect` call launched (as a profiler shows it)."""
         return self.lib.lc_ctx_last_advect_kernel(self.ctx).decode()
 
+    def last_advect_launches(self) -> int:
+        """Kernel launches the last :meth:`advect` call made (level chunks)."""
+        return int(self.lib.lc_ctx_last_advect_launches(self.ctx))
+
     TWO_SEED_MIN = 1 << 23   # seeds per call from which lc_advect's default is the two-seeds-per-lane kernel
 
     class _Concurrent:
