@@ -666,9 +666,9 @@ def main():
             "build_id": build_id, **({"knobs": knobs} if knobs else {}),
             "step": "pack + fused advect + halo exchange + sigma" + (" per member" if wk == "c5" else "")
                     + "; u/v/seeds resident in HBM"
-                    + (f"; members advected in level-major order, {ens_chunk} levels per launch, continuing in place "
-                       f"(lc_advect_from), launches alternating between {nstreams} HIP streams; kernel_ms.advect = the "
-                       "ensemble's wall time" if level_major else
+                    + (f"; members advected in level-major order, {ens_chunk} levels per launch, ONE launch per chunk over all "
+                       "of a rank's members (lc_advect_batch), continuing in place; kernel_ms.advect = the ensemble's "
+                       "wall time" if level_major else
                        f"; independent members alternate between {nstreams} HIP streams (kernel_ms advect/halo/sigma = "
                        "members x one member run alone; members_overlapped_wall = what they take together)" if side else ""),
         },

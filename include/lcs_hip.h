@@ -261,6 +261,26 @@ int lc_advect_from(lc_ctx *ctx, const void *packed_lin, const void *packed_cub,
                    int t0, int nsteps,
                    void *x_out, void *y_out, void *traj_x, void *traj_y);
 
+/* lc_advect_from for an ENSEMBLE of n_members start times over one seed grid and one wind series, in one launch per
+ * level chunk: member m integrates nsteps steps from time level t0 + m * t0_stride (BASELINE config 5: stride 1) and
+ * keeps its positions in the m-th [ny*nx] plane of x_start / x_out ([n_members][ny*nx]; x_start NULL = every member
+ * starts on the seed grid; in place allowed).  With lc_ctx_set_level_chunk(c) the members advance together c levels
+ * at a time (level-major order), so the launches of a chunk share all but a few of their time levels in the caches
+ * and a launch is n_members times deeper than a member's own (no tail of idle compute units between members).  Each
+ * member's result is, bit for bit, what lc_advect(t0 + m * t0_stride) gives.  traj_x / traj_y must be NULL and
+ * cyclic_x must not be LC_X_CLAMP_REFERENCE_OUTER when n_members > 1.  No reference counterpart: there the caller
+ * loops over start times (LCS/trajectory.py:80 consumes one series). */
+int lc_advect_batch(lc_ctx *ctx, const void *packed_lin, const void *packed_cub,
+                    const void *packed_ext, int dtype,
+                    int nt, int ny_f, int nx_f,
+                    double lat_min, double lat_max, double lon_min, double lon_max,
+                    const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx,
+                    int row0, int ny_global,
+                    const void *x_start, const void *y_start,
+                    double timestep, int settls_order, int interp_order, int cyclic_x,
+                    int t0, int nsteps, int n_members, int t0_stride,
+                    void *x_out, void *y_out, void *traj_x, void *traj_y);
+
 /* One interpolation pass on its own: tools.xr_map_coordinates (LCS/tools.py:11-41) for the
  * u and v fields of time level `level` at the given positions (degrees), same index
  * scale, row classes and boundary modes as inside lc_advect.  pos_x/pos_y/out_u/out_v

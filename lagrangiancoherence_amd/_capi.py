@@ -50,6 +50,8 @@ PROTOTYPES = {
                        _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lc_advect_from": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i, _vp, _vp,
                             _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lc_advect_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i, _vp, _vp,
+                             _d, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lc_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lc_sigma": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _d, _d, _i, _i, _i, _i, _vp]),
     "lc_flowmap_gradient": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _d, _d, _i, _vp]),

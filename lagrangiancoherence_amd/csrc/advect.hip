@@ -53,6 +53,8 @@ struct AdvectArgs {
     int wind_f32;  // double instantiation only: the wind is float32-valued -> numpy's promotion rules (Q10)
     T *x_out, *y_out, *traj_x, *traj_y;
     const T *x_start, *y_start;  // NULL: start from the seed grid; else [ny*nx] positions to continue from (lc_advect_from)
+    int n_members, member_t0_stride;  // lc_advect_batch: blockIdx.y = member; member m starts at time level t0 + m * stride ...
+    size_t member_plane;         // ... and reads / writes positions at x_start / x_out + m * member_plane (elements)
     int traj_skip0;              // 1: traj entry 0 (the start positions) is already in place (a later chunk of one call)
     int traj_pair_ok, out_pair_ok;  // two-seed kernel, PATCH_WIDE: nx even and traj / out bases 8-byte aligned (paired stores)
     int traj_line_ok;            // two-seed kernel, PATCH_LINES: nx % 4 == 0 and traj bases 16-byte aligned (whole-line stores)
@@ -91,6 +93,8 @@ __device__ __forceinline__ int xcd_tile_id(const AdvectArgs<T> &A) {
     }
     return d;
 }
+template <typename T>
+static inline unsigned nmem(const AdvectArgs<T> &A) { return A.n_members > 1 ? (unsigned)A.n_members : 1u; }  // grid.y of an advect launch
 static inline int xcd_grid(int ntiles, int chunk) {
     if (chunk <= 0) return ((ntiles + 7) / 8) * 8;
     const int nch = (ntiles + chunk - 1) / chunk;
@@ -111,6 +115,25 @@ __device__ __forceinline__ T start_x(const AdvectArgs<T> &A, int iy, int ix) {
 template <typename T>
 __device__ __forceinline__ T start_y(const AdvectArgs<T> &A, int iy, int ix) {
     return A.y_start ? A.y_start[(size_t)iy * A.nx + ix] : A.seed_lat[iy];
+}
+
+// lc_advect_batch: the arguments as ensemble member blockIdx.y sees them (a no-op for every other call: gridDim.y == 1).
+// Members share the seed grid and the wind series; member m integrates from time level t0 + m * member_t0_stride and
+// keeps its positions in the m-th plane of x_start / x_out.  Wave-uniform scalar arithmetic, once per workgroup.
+template <typename T>
+__device__ __forceinline__ AdvectArgs<T> for_member(const AdvectArgs<T> &A0) {
+    AdvectArgs<T> A = A0;
+    if (A0.n_members > 1) {
+        const size_t off = (size_t)blockIdx.y * A0.member_plane;
+        A.t0 = A0.t0 + (int)blockIdx.y * A0.member_t0_stride;
+        A.x_out = A0.x_out + off;
+        A.y_out = A0.y_out + off;
+        if (A0.x_start) {
+            A.x_start = A0.x_start + off;
+            A.y_start = A0.y_start + off;
+        }
+    }
+    return A;
 }
 
 template <typename T>
@@ -896,8 +919,9 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
 #if LCS_LDS_NUM_SGPR > 0
     __attribute__((amdgpu_num_sgpr(LCS_LDS_NUM_SGPR)))
 #endif
-    advect_lds_kernel(const AdvectArgs<float> A) {
+    advect_lds_kernel(const AdvectArgs<float> A0) {
 #pragma clang fp contract(fast)
+    const AdvectArgs<float> A = for_member(A0);
     const int K = KFIX >= 0 ? KFIX : A.K;  // KFIX: SETTLS_order known at compile time (the iteration loop unrolls)
     typedef TileGeom<ORDER> G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
@@ -1206,8 +1230,9 @@ constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byt
 
 template <int KFIX, bool CYCLIC, int MODE>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2_NUM_SGPR)))
-    advect_lds2_kernel(const AdvectArgs<float> A) {
+    advect_lds2_kernel(const AdvectArgs<float> A0) {
 #pragma clang fp contract(fast)
+    const AdvectArgs<float> A = for_member(A0);
     constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES;
     constexpr int ORDER = 1;
     const int K = KFIX >= 0 ? KFIX : A.K;
@@ -1661,8 +1686,9 @@ struct PatchLanes {  // the lane's SPL seeds: where they are in the grid, their 
 #define LCS_LDS2_O3_MINWAVES 5
 #endif
 template <int KFIX, bool CYCLIC, int MODE>
-__global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_kernel(const AdvectArgs<float> A) {
+__global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_kernel(const AdvectArgs<float> A0) {
 #pragma clang fp contract(fast)
+    const AdvectArgs<float> A = for_member(A0);
     constexpr int ORDER = 3;
     constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES;
     const int K = KFIX >= 0 ? KFIX : A.K;
@@ -1837,7 +1863,7 @@ struct LdsLaunch<float, ORDER> {
         // two seeds per lane pays once the launch is many rounds of workgroups deep; below ~8 M seeds the one-seed kernel's
         // twice as many waves fill the machine better (4096 x 512 seeds, one GPU's share of C3 split 8 ways: +24 %;
         // measured cross-over between 2896^2 and 3500^2).  mode 1 / 2 force either (tests, A/B); 3 = by size.
-        const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny >= (1ll << 23));
+        const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny * (long long)nmem(A) >= (1ll << 23));
         if (ORDER == 1 && two_seed && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16) {
             // two seeds per lane; a workgroup covers 8 x 64 seeds (PATCH_TALL), 16 x 32 (PATCH_WIDE) or 32 x 16 (PATCH_LINES)
             const int mode = A.patch_mode >= 0 ? A.patch_mode : (A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 ? PATCH_LINES : PATCH_TALL);
@@ -1855,7 +1881,7 @@ struct LdsLaunch<float, ORDER> {
             const int g2 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
 #define LC_LDS2(KF, CY, MD, NAME)                                                                      \
     {                                                                                                  \
-        hipLaunchKernelGGL((advect_lds2_kernel<KF, CY, MD>), dim3(g2), dim3(BLOCK), 0, st, A);         \
+        hipLaunchKernelGGL((advect_lds2_kernel<KF, CY, MD>), dim3(g2, nmem(A)), dim3(BLOCK), 0, st, A);         \
         return NAME;                                                                                   \
     }
             if (mode == PATCH_LINES) {
@@ -1892,7 +1918,7 @@ struct LdsLaunch<float, ORDER> {
             const int g2 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
 #define LC_LDS2O3(KF, CY, MD, NAME)                                                                       \
     {                                                                                                     \
-        hipLaunchKernelGGL((advect_lds2_o3_kernel<KF, CY, MD>), dim3(g2), dim3(BLOCK), 0, st, A);         \
+        hipLaunchKernelGGL((advect_lds2_o3_kernel<KF, CY, MD>), dim3(g2, nmem(A)), dim3(BLOCK), 0, st, A);         \
         return NAME;                                                                                      \
     }
             if (mode == PATCH_LINES) {
@@ -1921,16 +1947,16 @@ struct LdsLaunch<float, ORDER> {
         if (A.K == 0) return nullptr;
         // K = 4 is the setting the reference's example and drivers use
         if (A.K == 4 && A.cyclic) {
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, true>), dim3(grid), dim3(BLOCK), 0, st, A);
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
             return ORDER == 3 ? "advect_lds_kernel<3, 4, true>" : "advect_lds_kernel<1, 4, true>";
         } else if (A.K == 4) {
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, false>), dim3(grid), dim3(BLOCK), 0, st, A);
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
             return ORDER == 3 ? "advect_lds_kernel<3, 4, false>" : "advect_lds_kernel<1, 4, false>";
         } else if (A.cyclic) {
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, true>), dim3(grid), dim3(BLOCK), 0, st, A);
+            hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
             return ORDER == 3 ? "advect_lds_kernel<3, -1, true>" : "advect_lds_kernel<1, -1, true>";
         }
-        hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, false>), dim3(grid), dim3(BLOCK), 0, st, A);
+        hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
         return ORDER == 3 ? "advect_lds_kernel<3, -1, false>" : "advect_lds_kernel<1, -1, false>";
     }
 };
@@ -2033,7 +2059,8 @@ struct InteriorPath<float, ORDER, FUSED> {
 // double, order 1 sits at 69 VGPRs (7 waves per SIMD); asking for 8 costs nothing measurable per wave and
 // lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
 template <typename T, int ORDER, bool FUSED>
-__device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A) {
+__device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A0) {
+    const AdvectArgs<T> A = for_member(A0);
     if (pole_block(A)) return;
     const int tile = xcd_tile_id(A);  // tile rows dealt to the XCDs cyclically (see xcd_tile_id)
     if (tile >= A.ntiles) return;
@@ -2066,7 +2093,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) ad
 template <typename T, int ORDER>
 struct DirectLaunch {
     static const char *launch(const AdvectArgs<T> &A, int grid, hipStream_t st) {
-        hipLaunchKernelGGL((advect_kernel<T, ORDER>), dim3(grid), dim3(BLOCK), 0, st, A);
+        hipLaunchKernelGGL((advect_kernel<T, ORDER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
         return ORDER == 1 ? "advect_kernel<double, 1, false>" : ORDER == 2 ? "advect_kernel<double, 2, false>"
              : ORDER == 3 ? "advect_kernel<double, 3, false>" : ORDER == 4 ? "advect_kernel<double, 4, false>"
                                                                            : "advect_kernel<double, 5, false>";
@@ -2075,7 +2102,7 @@ struct DirectLaunch {
 template <int ORDER>
 struct DirectLaunch<float, ORDER> {
     static const char *launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
-        hipLaunchKernelGGL((advect_kernel_f32<ORDER>), dim3(grid), dim3(BLOCK), 0, st, A);
+        hipLaunchKernelGGL((advect_kernel_f32<ORDER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
         return ORDER == 1 ? "advect_kernel_f32<1>" : ORDER == 2 ? "advect_kernel_f32<2>" : ORDER == 3 ? "advect_kernel_f32<3>"
              : ORDER == 4 ? "advect_kernel_f32<4>" : "advect_kernel_f32<5>";
     }
@@ -2272,9 +2299,12 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
                 int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, const void *x_start,
-                const void *y_start, int wind_f32 = 0) {
+                const void *y_start, int wind_f32 = 0, int n_members = 1, int t0_stride = 0) {
     AdvectArgs<T> A{};
     A.wind_f32 = wind_f32;
+    A.n_members = n_members;
+    A.member_t0_stride = t0_stride;
+    A.member_plane = (size_t)ny * nx;
     A.x_start = (const T *)x_start;
     A.y_start = (const T *)y_start;
     A.traj_skip0 = 0;
@@ -2361,14 +2391,14 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                  : order == 4 ? DirectLaunch<T, 4>::launch(A, grid, ctx->stream) : DirectLaunch<T, 5>::launch(A, grid, ctx->stream);
         } else if (order == 3) {
             if (fused64) {
-                hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+                hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
                 name = "advect_kernel<double, 3, true>";
             } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
                 name = DirectLaunch<T, 3>::launch(A, grid, ctx->stream);
             }
         } else {
             if (fused64) {
-                hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid), dim3(BLOCK), 0, ctx->stream, A);
+                hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
                 name = "advect_kernel<double, 1, true>";
             } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
                 name = DirectLaunch<T, 1>::launch(A, grid, ctx->stream);
@@ -2386,7 +2416,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // launch (profiles/r03): C3 96 steps 6.55 -> 6.46 ms, 200 steps 15.0 -> 13.9, C4 (8192^2 x 384) 100.2 -> 93.0, order 3
     // 16.1 -> 15.8, one member of C5 (2048^2 x 200) +17 %; chunks of 16 / 24 / 48 / 64 within 1 % of 32.  Smaller grids
     // run out of workgroups at the end of every launch and keep the single launch.
-    const int auto_chunk = (long long)ny * nx >= (1ll << 22) ? 32 : 0;
+    const int auto_chunk = (long long)ny * nx * (n_members > 1 ? n_members : 1) >= (1ll << 22) ? 32 : 0;
     const int want_chunk = ctx->level_chunk < 0 ? auto_chunk : ctx->level_chunk;
     // LC_X_CLAMP_REFERENCE_OUTER: chunks of 16 levels whatever the size, the clamp flag read back after each, the
     // positions before each chunk kept -- so the sub-step path restarts at the chunk in which a parcel first left the
@@ -2584,7 +2614,27 @@ extern "C" int lc_advect_from(lc_ctx *ctx, const void *packed_lin, const void *p
                               int ny_global, const void *x_start, const void *y_start, double timestep, int settls_order,
                               int interp_order, int cyclic_x, int t0, int nsteps, void *x_out, void *y_out, void *traj_x,
                               void *traj_y) {
+    return lc_advect_batch(ctx, packed_lin, packed_cub, packed_ext, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
+                           seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, x_start, y_start, timestep, settls_order,
+                           interp_order, cyclic_x, t0, nsteps, 1, 0, x_out, y_out, traj_x, traj_y);
+}
+
+extern "C" int lc_advect_batch(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *packed_ext,
+                               int dtype, int nt, int ny_f, int nx_f, double lat_min, double lat_max, double lon_min,
+                               double lon_max, const void *seed_lat_dev, int ny, const void *seed_lon_dev, int nx, int row0,
+                               int ny_global, const void *x_start, const void *y_start, double timestep, int settls_order,
+                               int interp_order, int cyclic_x, int t0, int nsteps, int n_members, int t0_stride, void *x_out,
+                               void *y_out, void *traj_x, void *traj_y) {
     LC_REQUIRE(ctx, "lc_advect: null context");
+    LC_REQUIRE(n_members >= 1 && n_members <= 65535 && t0_stride >= 0, "lc_advect_batch: bad n_members %d / t0_stride %d", n_members,
+               t0_stride);
+    if (n_members > 1) {
+        LC_REQUIRE(!traj_x && !traj_y, "lc_advect_batch: trajectories are per member: call lc_advect for each");
+        if (cyclic_x == LC_X_CLAMP_REFERENCE_OUTER) {
+            lc_set_error("lc_advect_batch: LC_X_CLAMP_REFERENCE_OUTER is decided per member: call lc_advect for each");
+            return LC_EUNSUPPORTED;
+        }
+    }
     LC_REQUIRE((x_start == nullptr) == (y_start == nullptr), "lc_advect_from: x_start and y_start must both be set or both NULL");
     if (x_start && cyclic_x == LC_X_CLAMP_REFERENCE_OUTER) {
         lc_set_error("lc_advect_from: LC_X_CLAMP_REFERENCE_OUTER restarts from the seed grid when a parcel leaves the box "
@@ -2612,8 +2662,9 @@ extern "C" int lc_advect_from(lc_ctx *ctx, const void *packed_lin, const void *p
                      "block (rows [%d,%d) of %d) needs lc_ctx_set_flag_allreduce", row0, row0 + ny, ny_global);
         return LC_EUNSUPPORTED;
     }
-    LC_REQUIRE(t0 >= 0 && nsteps >= 0 && t0 + nsteps <= nt - 1, "lc_advect: steps [%d,%d) need levels up to %d, have %d",
-               t0, t0 + nsteps, t0 + nsteps, nt);
+    LC_REQUIRE(t0 >= 0 && nsteps >= 0 && t0 + (n_members - 1) * t0_stride + nsteps <= nt - 1,
+               "lc_advect: steps [%d,%d) need levels up to %d, have %d", t0, t0 + (n_members - 1) * t0_stride + nsteps,
+               t0 + (n_members - 1) * t0_stride + nsteps, nt);
     LC_REQUIRE(x_out && y_out, "lc_advect: null output");
     LC_REQUIRE((traj_x == nullptr) == (traj_y == nullptr), "lc_advect: traj_x and traj_y must both be set or both NULL");
     LC_REQUIRE(lat_max > lat_min && lon_max > lon_min, "lc_advect: field coordinates must be ascending");
@@ -2627,9 +2678,10 @@ extern "C" int lc_advect_from(lc_ctx *ctx, const void *packed_lin, const void *p
     if (dtype == LC_F32)
         return advect_impl<float>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
                                   seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
-                                  interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start);
+                                  interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start, 0,
+                                  n_members, t0_stride);
     return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
                                seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start,
-                               dtype == LC_F64_WIND_F32);
+                               dtype == LC_F64_WIND_F32, n_members, t0_stride);
 }

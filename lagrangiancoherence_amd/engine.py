@@ -85,6 +85,7 @@ class Engine:
         self.device = torch.device("cuda", self.device_index)
         ctx = C.c_void_p()
         _capi.check(self.lib.lc_ctx_create(self.device_index, C.byref(ctx)), self.lib)
+        self.level_chunk = -1         # what set_level_chunk was last given (-1: by size, or LCS_LEVEL_CHUNK)
         self.lds_tiles_mode = -1      # what set_lds_tiles was last given (-1: the library's default, or LCS_LDS_TILES)
         self.ctx = ctx
 
@@ -115,6 +116,7 @@ class Engine:
         the default -- 32 levels from 2^22 seeds per call).  Results are bit-identical; it shapes the launches only
         (``lc_ctx_set_level_chunk``)."""
         _capi.check(self.lib.lc_ctx_set_level_chunk(self.ctx, int(levels)), self.lib)
+        self.level_chunk = int(levels)
 
     def set_flag_allreduce(self, group=None, comm=None, enable=True):
         """Row-sharded grids with the reference's non-cyclic clamp (``LC_X_CLAMP_REFERENCE_OUTER``): install the
@@ -356,6 +358,38 @@ class Engine:
         if halo:
             x, y = x_buf, y_buf
         return (x, y, tx, ty) if return_traj else (x, y)
+
+    def advect_batch(self, field: PackedField, seed_lat, seed_lon, timestep, n_members: int, nsteps: int, SETTLS_order=0,
+                     interp_order=1, cyclic_xboundary=True, t0=0, t0_stride=1, start=None, out=None):
+        """Departure points of an ENSEMBLE of start times over one seed grid (``lc_advect_batch``): member ``m`` runs
+        ``nsteps`` steps from time level ``t0 + m * t0_stride``.  Returns ``(x, y)`` of shape ``(n_members, ny, nx)``.
+        One launch per level chunk covers every member (:meth:`set_level_chunk`); each member's result equals
+        ``advect(t0=t0 + m * t0_stride, nsteps=nsteps)`` bit for bit.  ``start`` / ``out``: ``(n_members, ny, nx)``
+        tensors to continue from / write into (may be the same)."""
+        if interp_order != 1 and field.order != interp_order:
+            raise ValueError(f"field was prepared for interp_order={field.order}")
+        if not cyclic_xboundary:
+            raise ValueError("advect_batch: the reference's non-cyclic clamp is decided per member; call advect for each")
+        dtype = field.dtype
+        slat, slon = self.to_device(seed_lat, dtype), self.to_device(seed_lon, dtype)
+        ny, nx, n = int(slat.numel()), int(slon.numel()), int(n_members)
+        want = getattr(self.torch, np.dtype(dtype).name)
+
+        def chk(t, what):
+            if tuple(t.shape) != (n, ny, nx) or t.dtype != want or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"{what} tensors must be contiguous ({n}, {ny}, {nx}) {np.dtype(dtype).name} tensors on {self.device}")
+            return t
+        x, y = (chk(t, "out") for t in out) if out is not None else (self._empty((n, ny, nx), dtype), self._empty((n, ny, nx), dtype))
+        sx, sy = (chk(t, "start") for t in start) if start is not None else (None, None)
+        self._use_current_stream()
+        _capi.check(self.lib.lc_advect_batch(
+            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order != 1 else None),
+            self._ptr(field.ext if field.order == interp_order else None),
+            _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[dtype], field.nt, field.ny_f, field.nx_f, field.lat_min,
+            field.lat_max, field.lon_min, field.lon_max, self._ptr(slat), ny, self._ptr(slon), nx, 0, ny,
+            self._ptr(sx), self._ptr(sy), float(timestep), int(SETTLS_order), int(interp_order), _capi.LC_X_CYCLIC,
+            int(t0), int(nsteps), n, int(t0_stride), self._ptr(x), self._ptr(y), None, None), self.lib)
+        return x, y
 
     def sample(self, field: PackedField, pos_x, pos_y, level=0, interp_order=1, row0=0, ny_global=None):
         """tools.xr_map_coordinates for (u, v) of one time level at positions (ny, nx) in degrees."""

@@ -180,13 +180,16 @@ ENSEMBLE_CHUNK = 8   # time levels per launch of ensemble_advect's level-major o
 def ensemble_advect(engine, field, seed_lat, seed_lon, timestep, members, nsteps: int, SETTLS_order=0, interp_order=1,
                     cyclic_xboundary=True, level_chunk=None, streams: int = 2):
     """Departure points of ensemble members (member ``e`` = start level ``t0 = e``, ``nsteps`` steps), advected in
-    LEVEL-MAJOR order: every member's first ``level_chunk`` levels, then every member's next chunk, ... each launch
-    continuing in place from the member's positions (``lc_advect_from``).  Members ``e`` and ``e+1`` of a chunk read
-    time levels ``[e + c, e + c + chunk]`` and ``[e + 1 + c, ...]`` -- all but one in common -- so consecutive launches
-    find the wind images in the Infinity Cache / L2 instead of streaming every member's whole series from HBM one
-    after the other (config 5 on one MI355X: 345 -> see DESIGN 4).  Results are bit-identical to one launch per member
-    (the loop of LCS/trajectory.py:80-126 carries only positions from level to level).  ``level_chunk=0``: member-major,
-    one launch per member.  Returns ``[(x, y), ...]`` in the order of ``members``; all streams are joined before it returns."""
+    LEVEL-MAJOR order: every member's first ``level_chunk`` levels, then every member's next chunk, ... continuing in
+    place.  Consecutive members (``members`` = ``range(a, b)``, what ``ensemble_partition`` hands a rank) go through ONE
+    launch per chunk (``lc_advect_batch``: member = blockIdx.y): members ``e`` and ``e+1`` of a chunk read time levels
+    ``[e + c, e + c + chunk]`` and ``[e + 1 + c, ...]`` -- all but one in common -- so the wind images stay in the
+    Infinity Cache / L2, and a launch is as many times deeper as there are members, so no compute unit idles at the
+    end of each member's own launch (config 5 on one MI355X: DESIGN 4).  Any other member list falls back to one launch
+    per member and chunk (``lc_advect_from``) on ``streams`` HIP streams.  Results are bit-identical to one launch per
+    member (the loop of LCS/trajectory.py:80-126 carries only positions from level to level).  ``level_chunk=0``:
+    member-major, one launch per member.  Returns ``[(x, y), ...]`` in the order of ``members``; everything is joined
+    into the current stream before it returns."""
     import numpy as np
     import torch
     members = list(members)
@@ -196,6 +199,16 @@ def ensemble_advect(engine, field, seed_lat, seed_lon, timestep, members, nsteps
     dtype = getattr(torch, np.dtype(field.dtype).name)
     ny, nx = len(seed_lat), len(seed_lon)
     slat, slon = engine.to_device(seed_lat, field.dtype), engine.to_device(seed_lon, field.dtype)
+    consecutive = len(members) > 1 and members == list(range(members[0], members[0] + len(members)))
+    if consecutive and cyclic_xboundary:
+        prev = engine.level_chunk
+        try:
+            engine.set_level_chunk(chunk)
+            x, y = engine.advect_batch(field, slat, slon, timestep, len(members), nsteps, SETTLS_order, interp_order, True,
+                                       t0=members[0], t0_stride=1)
+        finally:
+            engine.set_level_chunk(prev)
+        return [(x[i], y[i]) for i in range(len(members))]
     pos = [(torch.empty((ny, nx), dtype=dtype, device=engine.device), torch.empty((ny, nx), dtype=dtype, device=engine.device))
            for _ in members]
     cur = torch.cuda.current_stream(engine.device)

@@ -616,6 +616,18 @@ def test_ensemble_members_are_t0_windows(eng, O):
         b = sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=5, nsteps=4, SETTLS_order=2, return_dpts=True,
                                  streams=ns)
         assert a[0] == b[0] and all(bool((x == y).all()) for x, y in zip(a[1:], b[1:]))
+    # lc_advect_batch: all members through one launch per level chunk == member by member, in place continuation too
+    x1, y1 = eng.advect_batch(f, slat, slon, -1800.0, 5, 4, SETTLS_order=2, interp_order=1)
+    assert bool((x1 == a[2]).all()) and bool((y1 == a[3]).all())
+    xa, ya = eng.advect_batch(f, slat, slon, -1800.0, 5, 1, SETTLS_order=2, interp_order=1)
+    eng.advect_batch(f, slat, slon, -1800.0, 5, 3, SETTLS_order=2, interp_order=1, t0=1, start=(xa, ya), out=(xa, ya))
+    assert bool((xa == a[2]).all()) and bool((ya == a[3]).all())
+    with pytest.raises(ValueError):
+        eng.advect_batch(f, slat, slon, -1800.0, 6, 4, SETTLS_order=2)        # member 5 would need level 9 of 9
+    # members that are not consecutive start times take the per-member launches on side streams
+    got = sharded.ensemble_advect(eng, f, slat, slon, -1800.0, [0, 2, 4], 4, SETTLS_order=2, level_chunk=3)
+    for (gx, gy), e in zip(got, (0, 2, 4)):
+        assert bool((gx == a[2][e]).all()) and bool((gy == a[3][e]).all())
     # level-major order (every member's first chunk of levels, then every member's next: ensemble_advect) == member by
     # member (level_chunk=0), bit for bit, whatever the chunk and the number of streams
     for chunk, ns in ((0, 1), (1, 2), (3, 1), (3, 3), (None, 2)):
