@@ -577,7 +577,7 @@ def test_launch_geometry_does_not_change_results(dtype, order, monkeypatch):
     u, v, lat, lon = (a.astype(dtype) for a in (u, v, lat, lon))
     try:
         fa, fb = eng.prepare_field(u, v, lat, lon, order), plain.prepare_field(u, v, lat, lon, order)
-        for sny, snx in ((2 * order, 70), (2 * order + 1, 9), (75, 133), (33, 64)):
+        for sny, snx in ((2 * order, 70), (2 * order + 1, 9), (75, 133), (33, 64), (70, 96)):
             slat, slon = (a.astype(dtype) for a in flows.seed_grid(sny, snx, lat, lon))
             windows = [(0, sny)] + ([(0, sny // 2), (sny // 2, sny), (order, sny - order)] if sny > 4 * order else [])
             for lo, hi in windows:
@@ -585,6 +585,16 @@ def test_launch_geometry_does_not_change_results(dtype, order, monkeypatch):
                 xa, ya = eng.advect(fa, slat[lo:hi], slon, -3600.0, **kw)
                 xb, yb = plain.advect(fb, slat[lo:hi], slon, -3600.0, **kw)
                 assert bool((xa == xb).all()) and bool((ya == yb).all()), (sny, snx, lo, hi)
+            if dtype == np.float32 and snx % 4 == 0:
+                # trajectories too, with the two-seed kernels forced: whole-line slab stores beside pole rows that are
+                # advected by leading workgroups (default) or inside the tiles (LCS_POLE_BLOCKS=0)
+                for e_ in (eng, plain):
+                    e_.set_lds_tiles(1)
+                ta = eng.advect(fa, slat, slon, -3600.0, SETTLS_order=4, interp_order=order, return_traj=True)
+                tb = plain.advect(fb, slat, slon, -3600.0, SETTLS_order=4, interp_order=order, return_traj=True)
+                for e_ in (eng, plain):
+                    e_.set_lds_tiles(-1)
+                assert all(bool((a == b).all()) for a, b in zip(ta, tb)), (sny, snx, "traj")
     finally:
         plain.close()
         eng.close()
@@ -842,3 +852,23 @@ def test_patch_modes_of_the_two_seed_kernel_agree_bitwise(sny, snx, order, monke
             for a, b in zip(out["0" + suffix], out[flag + suffix]):
                 assert np.array_equal(a, b), (flag, suffix)
     assert np.array_equal(out["0"][0], out["0n"][0])
+
+
+@pytest.mark.parametrize("order,lds", [(1, 1), (1, 2), (1, 0), (3, 1), (3, 2)])
+def test_advect_batch_equals_member_by_member_in_every_float_kernel(eng, order, lds):
+    """lc_advect_batch (member = blockIdx.y, one launch per level chunk over all members) against one lc_advect per
+    member: bit for bit, two-seed / one-seed LDS-tile kernels and direct gathers, orders 1 and 3, with level chunks."""
+    u, v, lat, lon = flows.era5_like(nt=12, ny=60, nx=120)
+    slat, slon = flows.seed_grid(101, 144, lat, lon)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    try:
+        eng.set_lds_tiles(lds)
+        eng.set_level_chunk(3)
+        xb, yb = eng.advect_batch(f, slat, slon, -1800.0, 4, 7, SETTLS_order=4, interp_order=order, t0=1)
+        eng.set_level_chunk(0)
+        for m in range(4):
+            x, y = eng.advect(f, slat, slon, -1800.0, SETTLS_order=4, interp_order=order, t0=1 + m, nsteps=7)
+            assert bool((xb[m] == x).all()) and bool((yb[m] == y).all()), m
+    finally:
+        eng.set_level_chunk(-1)
+        eng.set_lds_tiles(-1)
