@@ -1863,7 +1863,10 @@ struct LdsLaunch<float, ORDER> {
         // two seeds per lane pays once the launch is many rounds of workgroups deep; below ~8 M seeds the one-seed kernel's
         // twice as many waves fill the machine better (4096 x 512 seeds, one GPU's share of C3 split 8 ways: +24 %;
         // measured cross-over between 2896^2 and 3500^2).  mode 1 / 2 force either (tests, A/B); 3 = by size.
-        const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny * (long long)nmem(A) >= (1ll << 23));
+        // With trajectories the two-seed kernels' whole-line stores decide earlier: 2048^2 seeds x 96 levels, order 1
+        // 3.29 against 3.78 ms, order 3 6.19 against 6.56 (without trajectories 2.60 / 2.54 and 6.31 / 5.47): from 2^22.
+        const long long two_seed_min = (A.traj_x && A.traj_line_ok && A.patch_mode < 0) ? (1ll << 22) : (1ll << 23);
+        const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny * (long long)nmem(A) >= two_seed_min);
         if (ORDER == 1 && two_seed && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16) {
             // two seeds per lane; a workgroup covers 8 x 64 seeds (PATCH_TALL), 16 x 32 (PATCH_WIDE) or 32 x 16 (PATCH_LINES)
             const int mode = A.patch_mode >= 0 ? A.patch_mode : (A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 ? PATCH_LINES : PATCH_TALL);

@@ -244,10 +244,10 @@ constexpr int DFT_ROWS = 4;   // field rows per block in the forward DFT
 // X[b][i][c] = sum_j g[b][i][j] F[j][c],  g = the field with latitude flipped to north -> south
 template <typename T>
 __global__ void __launch_bounds__(256) dft_forward_kernel(const T *__restrict__ f, int nrows_total, int nlat, int nlon, int C,
-                                                           const double *__restrict__ F, double *__restrict__ X) {
-    extern __shared__ double s_row[];  // DFT_ROWS x nlon
-    const int row0 = blockIdx.x * DFT_ROWS;
-    for (int e = threadIdx.x; e < DFT_ROWS * nlon; e += blockDim.x) {
+                                                           const double *__restrict__ F, double *__restrict__ X, int rows_per_block) {
+    extern __shared__ double s_row[];  // rows_per_block (<= DFT_ROWS: as many as fit 64 KB of LDS) x nlon
+    const int row0 = blockIdx.x * rows_per_block;
+    for (int e = threadIdx.x; e < rows_per_block * nlon; e += blockDim.x) {
         const int r = e / nlon, j = e - r * nlon, row = row0 + r;
         double v = 0.0;
         if (row < nrows_total) {
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) dft_forward_kernel(const T *__restrict__ 
     }
     __syncthreads();
     const int r = threadIdx.x / 64;
-    if (row0 + r >= nrows_total) return;
+    if (r >= rows_per_block || row0 + r >= nrows_total) return;
     const double *g = s_row + (size_t)r * nlon;
     for (int c = threadIdx.x % 64; c < C; c += 64) {  // any truncation: the wave walks the 2 (T + 1) columns 64 at a time
         double acc = 0.0;
@@ -369,8 +369,10 @@ int truncate_impl(lc_ctx *ctx, const T *f, int nb, int nlat, int nlon, int Tr, T
     LC_HIP_CHECK(hipMallocAsync((void **)&X, 2 * n * sizeof(double), st));
     H = X + n;
     const int rows = nb * nlat;
-    hipLaunchKernelGGL((dft_forward_kernel<T>), dim3((rows + DFT_ROWS - 1) / DFT_ROWS), dim3(256),
-                       (size_t)DFT_ROWS * nlon * sizeof(double), st, f, rows, nlat, nlon, C, ctx->trunc->F, X);
+    int rpb = (int)((size_t)64 * 1024 / ((size_t)nlon * sizeof(double)));  // field rows a block stages in LDS
+    rpb = rpb > DFT_ROWS ? DFT_ROWS : rpb;
+    hipLaunchKernelGGL((dft_forward_kernel<T>), dim3((rows + rpb - 1) / rpb), dim3(256),
+                       (size_t)rpb * nlon * sizeof(double), st, f, rows, nlat, nlon, C, ctx->trunc->F, X, rpb);
     hipLaunchKernelGGL(project_kernel, dim3((2 * nb + PT - 1) / PT, (nlat + PT - 1) / PT, T1), dim3(256), 0, st,
                        ctx->trunc->P, X, nb, nlat, T1, H);
     hipLaunchKernelGGL((dft_inverse_kernel<T>), dim3(rows), dim3(256), (size_t)C * sizeof(double), st, H, nlat, nlon, C, ctx->trunc->G, out);
@@ -499,8 +501,8 @@ extern "C" int lc_spectral_truncate(lc_ctx *ctx, const void *f_dev, int dtype, i
         lc_set_error("lc_spectral_truncate: truncation %d exceeds this build's limit of %d", truncation, 48 * 1024 / 16 - 1);
         return LC_EUNSUPPORTED;
     }
-    if ((size_t)DFT_ROWS * nlon * sizeof(double) > 64 * 1024) {  // the forward DFT stages DFT_ROWS field rows in LDS
-        lc_set_error("lc_spectral_truncate: %d longitudes exceed this build's limit of %d", nlon, 64 * 1024 / (DFT_ROWS * 8));
+    if ((size_t)nlon * sizeof(double) > 64 * 1024) {  // the forward DFT stages whole field rows in LDS (4 at a time where they fit)
+        lc_set_error("lc_spectral_truncate: %d longitudes exceed this build's limit of %d", nlon, 64 * 1024 / 8);
         return LC_EUNSUPPORTED;
     }
     LC_HIP_CHECK(hipSetDevice(ctx->device));

@@ -103,6 +103,9 @@ def test_truncation_kernels_match_oracle_on_the_reference_grid(eng):
     f3 = rng.standard_normal((2, 96, 192))
     for T in (42, 63):
         np.testing.assert_allclose(PP.spectral_truncate(eng, f3, T).cpu().numpy(), PO.spectral_truncate(f3, T), atol=2e-12)
+    # more than 2048 longitudes (a 0.125 degree grid): the forward DFT stages fewer rows per block
+    f4 = rng.standard_normal((1, 33, 2880))
+    np.testing.assert_allclose(PP.spectral_truncate(eng, f4, 10).cpu().numpy(), PO.spectral_truncate(f4, 10), atol=5e-12)
 
 
 def test_truncation_on_gaussian_latitudes(eng):
