@@ -1978,8 +1978,14 @@ struct LdsLaunch<float, ORDER> {
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ d2 sample_fast64(const double *__restrict__ lvl, const AdvectArgs<double> &A, double x, double y) {
-#pragma clang fp contract(fast)
+// The two halves of a fast float64 sample, shared by the direct-gather kernel and the LDS-tile kernel below so that a
+// seed's result never depends on which of the two served it: explicit operations, no contraction left to the compiler.
+struct Loc64 {
+    double tx, ty;
+    int x0, y0;  // floor of the wrapped index coordinate, clamped into the grid (memory safety for NaN / inf)
+};
+__device__ __forceinline__ Loc64 locate_fast64(const AdvectArgs<double> &A, double x, double y) {
+#pragma clang fp contract(off)
     double cx = (x - A.lon_min) * A.sx;  // subtract first: exact 0 at the grid origin
     double cy = (y - A.lat_min) * A.sy;
     const double szx = (double)(A.nx_f - 1), szy = (double)(A.ny_f - 1);
@@ -1988,15 +1994,32 @@ __device__ __forceinline__ d2 sample_fast64(const double *__restrict__ lvl, cons
         cy = wrap_coord<double>(cy, szy);
     }
     const double fx = floor(cx), fy = floor(cy);
-    const double tx = cx - fx, ty = cy - fy;
-    const int x0 = clampi((int)fx, 0, A.nx_f - 1), y0 = clampi((int)fy, 0, A.ny_f - 1);  // clamp: memory safety (NaN, inf)
-    const double *p = lvl + ((size_t)(y0 + LC_PAD_LO) * A.pitch + (x0 + LC_PAD_LO)) * 2;
+    Loc64 t;
+    t.tx = cx - fx;
+    t.ty = cy - fy;
+    t.x0 = clampi((int)fx, 0, A.nx_f - 1);
+    t.y0 = clampi((int)fy, 0, A.ny_f - 1);
+    return t;
+}
+// a = {u00, v00, u01, v01}, b = {u10, v10, u11, v11}: three fused lerps on (u, v)
+__device__ __forceinline__ d2 lerp_fast64(d4 a, d4 b, double tx, double ty) {
+#pragma clang fp contract(off)
+    d2 r0, r1, r;
+    r0.x = fma(tx, a.z - a.x, a.x);
+    r0.y = fma(tx, a.w - a.y, a.y);
+    r1.x = fma(tx, b.z - b.x, b.x);
+    r1.y = fma(tx, b.w - b.y, b.y);
+    r.x = fma(ty, r1.x - r0.x, r0.x);
+    r.y = fma(ty, r1.y - r0.y, r0.y);
+    return r;
+}
+__device__ __forceinline__ d2 sample_fast64(const double *__restrict__ lvl, const AdvectArgs<double> &A, double x, double y) {
+    const Loc64 t = locate_fast64(A, x, y);
+    const double *p = lvl + ((size_t)(t.y0 + LC_PAD_LO) * A.pitch + (t.x0 + LC_PAD_LO)) * 2;
     d4 a, b;
     __builtin_memcpy(&a, p, 32);                           // {u00, v00, u01, v01}
     __builtin_memcpy(&b, p + (size_t)A.pitch * 2, 32);     // {u10, v10, u11, v11}
-    const d2 r0 = a.xy + tx * (a.zw - a.xy);
-    const d2 r1 = b.xy + tx * (b.zw - b.xy);
-    return r0 + ty * (r1 - r0);
+    return lerp_fast64(a, b, t.tx, t.ty);
 }
 
 __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) {
@@ -2032,6 +2055,133 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
     }
     A.x_out[idx] = x;
     A.y_out[idx] = y;
+}
+
+// ======================================================================================
+// float64, order 1, fused levels, per-wave LDS tiles (config 2's size class).
+//
+// The direct kernel above issues 20 sixteen-byte gathers per wave-level and is bound by the vector L1's handling of them
+// (0.79 tag lookups per CU-cycle, VALU issuing in 43 % of the slots: profiles/r03/c2_*).  Here each WAVE stages a
+// 16 x 16-node tile of ext[t] (16-byte {u, v} nodes) with four coalesced loads per lane, anchored like the float
+// kernels' tiles, and takes the K iteration samples out of LDS with locate_fast64 / lerp_fast64 -- the same two
+// functions as the direct kernel, so results are bit-identical to it; the Euler sample stays a direct gather (img[t]
+// is another image) and a lane whose window left the tile re-samples from global memory.  8 x 8 seeds per wave, four
+// waves stacked per workgroup, no workgroup barrier.
+// ======================================================================================
+constexpr int T64_COLS = 16, T64_ROWS = 16, T64_PITCH = 17;  // nodes; rows shift 4 banks of 16 bytes
+template <int KFIX, bool CYCLIC>
+__global__ void __launch_bounds__(BLOCK) advect_lds64_kernel(const AdvectArgs<double> A0) {
+#pragma clang fp contract(off)
+    const AdvectArgs<double> A = for_member(A0);
+    const int K = KFIX >= 0 ? KFIX : A.K;
+    __shared__ __attribute__((aligned(16))) d2 s_tiles[BLOCK / 64][T64_ROWS * T64_PITCH];
+    if (pole_block(A)) return;
+    const int tile_id = xcd_tile_id(A);
+    if (tile_id >= A.ntiles) return;  // whole block
+    const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
+    const int ix = txi * TILE_W + (threadIdx.x % TILE_W);
+    const int iy = tyi * TILE_H + (threadIdx.x / TILE_W);
+    const int lane = threadIdx.x & 63;
+    d2 *tile = s_tiles[threadIdx.x >> 6];
+    bool live = ix < A.nx && iy < A.ny;
+    if (live) {
+        const int grow = A.row0 + iy;
+        if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path (Q3)
+            if (!A.pole_blocks) advect_seed<double, 1, false>(A, A.lin, iy, ix);
+            live = false;
+        }
+    }
+    if (__ballot(live) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
+    const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);  // lanes without a seed shadow a neighbour; stores masked
+    double x = start_x<double>(A, sy_i, sx_i), y = start_y<double>(A, sy_i, sx_i);
+    const double ys = A.seed_lat[sy_i];
+    const double cx_conv = 180.0 / ((3.141592653589793 * 6371000.0) * fabs(cos((ys * 3.141592653589793) / 180.0)));  // Q5
+    const double dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
+    const size_t idx = live ? (size_t)iy * A.nx + ix : 0, plane = (size_t)A.ny * A.nx;
+    if (live && A.traj_x && !A.traj_skip0) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const double *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    constexpr int CENTRE = TILE_W / 2 + TILE_W * 4;  // middle seed of the wave's 8 x 8 patch
+    // staging: one node (16 bytes) per lane, 16 lanes per tile row, 4 rows per pass, 4 passes
+    const int st_row = lane >> 4, st_col = lane & 15;
+    const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 16u;
+    double dprev_x = 0.0, dprev_y = 0.0;  // previous level's Euler displacement in index space: predicts this level's travel
+    const double kpred = 0.5 * (double)(K > 0 ? K - 1 : 0);
+    for (int s = 0; s < A.nsteps; ++s) {
+        // ---- 1. anchor the tile on the centre lane's predicted travel, issue its loads ----------------------------
+        int ox = 0, oy = 0;
+        d2 stage[4];
+        if (K > 0) {
+            const double cax = (x - A.lon_min) * A.sx + dprev_x * (1.0 + kpred), cay = (y - A.lat_min) * A.sy + dprev_y * (1.0 + kpred);
+            const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);
+            const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
+            ox = min(max(rxm + LC_PAD_LO - (T64_COLS - 2) / 2, 0), pad_cols - T64_COLS);
+            oy = min(max(rym + LC_PAD_LO - (T64_ROWS - 2) / 2, 0), pad_rows - T64_ROWS);
+            const char *src = (const char *)elv + ((size_t)oy * pad_cols + ox) * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) __builtin_memcpy(&stage[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+        }
+        // ---- 2. Euler sample: direct gather from img[t] ------------------------------------------------------------
+        const double x0p = x, y0p = y;
+        const d2 e = sample_fast64(lvl, A, x, y);       // trajectory.py:82-84
+        y = fma(A.dtcy, e.y, y);                        // :86
+        x = fma(dtcx, e.x, x);                          // :87
+        clamp_position<double>(A, x, y);                // :89-97
+        dprev_x = (x - x0p) * A.sx;
+        dprev_y = (y - y0p) * A.sy;
+        // ---- 3. tile into LDS ------------------------------------------------------------------------------------
+        int lo_x = 0x40000000, lo_y = 0x40000000, lim_x = 0, lim_y = 0;  // no tile: nothing is "inside"
+        if (K > 0) {
+            __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(r * 4 + st_row) * T64_PITCH + st_col] = stage[r];
+            __builtin_amdgcn_wave_barrier();
+            // window origins (x0, y0) the tile serves: inside it (padded origin = (y0 + 1, x0 + 1)) and in [0, n - 2]
+            const int sox = ox - LC_PAD_LO, soy = oy - LC_PAD_LO;
+            const int hx = min(sox + T64_COLS - 2, A.nx_f - 2), hy = min(soy + T64_ROWS - 2, A.ny_f - 2);
+            const int lx = max(sox, 0), ly = max(soy, 0);
+            if (hx >= lx && hy >= ly) {
+                lo_x = sox;      // tile-relative index = x0 - sox; accepted range [lx - sox, hx - sox]
+                lo_y = soy;
+                lim_x = hx;
+                lim_y = hy;
+            }
+        }
+        // ---- 4. K iterations out of LDS ---------------------------------------------------------------------------
+        for (int k = 0; k < K; ++k) {
+            const Loc64 t = locate_fast64(A, x, y);
+            const bool in_tile = t.x0 >= max(lo_x, 0) && t.x0 <= lim_x && t.y0 >= max(lo_y, 0) && t.y0 <= lim_y && lo_x != 0x40000000;
+            d4 a, b;
+            if (in_tile) {
+                const d2 *w = tile + (t.y0 - lo_y) * T64_PITCH + (t.x0 - lo_x);
+                const d2 n00 = w[0], n01 = w[1], n10 = w[T64_PITCH], n11 = w[T64_PITCH + 1];
+                a = (d4){n00.x, n00.y, n01.x, n01.y};
+                b = (d4){n10.x, n10.y, n11.x, n11.y};
+            } else {  // the window left the tile: the same taps from global memory
+                const double *p = elv + ((size_t)(t.y0 + LC_PAD_LO) * A.pitch + (t.x0 + LC_PAD_LO)) * 2;
+                __builtin_memcpy(&a, p, 32);
+                __builtin_memcpy(&b, p + (size_t)A.pitch * 2, 32);
+            }
+            const d2 d = e + lerp_fast64(a, b, t.tx, t.ty);   // e + (2 F[t] - F[t+1])(x, y)
+            y = fma(A.hdtcy, d.y, y);
+            x = fma(hdtcx, d.x, x);
+            clamp_position<double>(A, x, y);
+        }
+        if (live && A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl += A.level_elems;
+        elv += A.level_elems;
+    }
+    if (live) {
+        A.x_out[idx] = x;
+        A.y_out[idx] = y;
+    }
 }
 
 template <typename T, int ORDER, bool FUSED>
@@ -2092,6 +2242,31 @@ template <int ORDER>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) advect_kernel_f32(const AdvectArgs<float> A) {
     advect_kernel_body<float, ORDER, false>(A);
 }
+
+template <typename T>
+struct Lds64Launch {
+    static const char *launch(const AdvectArgs<T> &, int, hipStream_t, int) { return nullptr; }
+};
+template <>
+struct Lds64Launch<double> {
+    // float64, order 1, fused levels: per-wave LDS tiles unless direct gathers are forced (lc_ctx_set_lds_tiles(0)),
+    // the wind is float32-valued (numpy promotion path), K = 0, or the field is smaller than a tile
+    static const char *launch(const AdvectArgs<double> &A, int grid, hipStream_t st, int mode) {
+        if (mode == 0 || A.wind_f32 || A.K == 0 || !A.ext || A.nx_f + LC_PAD < T64_COLS || A.ny_f + LC_PAD < T64_ROWS) return nullptr;
+        if (A.K == 4 && A.cyclic) {
+            hipLaunchKernelGGL((advect_lds64_kernel<4, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+            return "advect_lds64_kernel<4, true>";
+        } else if (A.K == 4) {
+            hipLaunchKernelGGL((advect_lds64_kernel<4, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+            return "advect_lds64_kernel<4, false>";
+        } else if (A.cyclic) {
+            hipLaunchKernelGGL((advect_lds64_kernel<-1, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+            return "advect_lds64_kernel<-1, true>";
+        }
+        hipLaunchKernelGGL((advect_lds64_kernel<-1, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+        return "advect_lds64_kernel<-1, false>";
+    }
+};
 
 template <typename T, int ORDER>
 struct DirectLaunch {
@@ -2401,8 +2576,11 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
             }
         } else {
             if (fused64) {
-                hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
-                name = "advect_kernel<double, 1, true>";
+                name = Lds64Launch<T>::launch(A, grid, ctx->stream, ctx->lds_tiles);
+                if (!name) {
+                    hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
+                    name = "advect_kernel<double, 1, true>";
+                }
             } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
                 name = DirectLaunch<T, 1>::launch(A, grid, ctx->stream);
             }
