@@ -2062,15 +2062,29 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
 //
 // The direct kernel above issues 20 sixteen-byte gathers per wave-level and is bound by the vector L1's handling of them
 // (0.79 tag lookups per CU-cycle, VALU issuing in 43 % of the slots: profiles/r03/c2_*).  Here each WAVE stages a
-// 16 x 16-node tile of ext[t] (16-byte {u, v} nodes) with four coalesced loads per lane, anchored like the float
+// 16 x 12-node tile of ext[t] (16-byte {u, v} nodes; 16 / 12 / 8 rows measure 3.73 / 3.33 / 3.48 ms on config 2 against
+// 4.0 for the direct kernel; 8 waves per SIMD or fewer SGPRs: no gain) with three coalesced loads per lane, anchored like the float
 // kernels' tiles, and takes the K iteration samples out of LDS with locate_fast64 / lerp_fast64 -- the same two
 // functions as the direct kernel, so results are bit-identical to it; the Euler sample stays a direct gather (img[t]
 // is another image) and a lane whose window left the tile re-samples from global memory.  8 x 8 seeds per wave, four
 // waves stacked per workgroup, no workgroup barrier.
 // ======================================================================================
-constexpr int T64_COLS = 16, T64_ROWS = 16, T64_PITCH = 17;  // nodes; rows shift 4 banks of 16 bytes
+#ifndef LCS_T64_ROWS
+#define LCS_T64_ROWS 12
+#endif
+#ifndef LCS_LDS64_MINWAVES
+#define LCS_LDS64_MINWAVES 1
+#endif
+#ifndef LCS_LDS64_NUM_SGPR
+#define LCS_LDS64_NUM_SGPR 0
+#endif
+constexpr int T64_COLS = 16, T64_ROWS = LCS_T64_ROWS, T64_PITCH = 17;  // nodes; rows shift 4 banks of 16 bytes
 template <int KFIX, bool CYCLIC>
-__global__ void __launch_bounds__(BLOCK) advect_lds64_kernel(const AdvectArgs<double> A0) {
+__global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
+#if LCS_LDS64_NUM_SGPR > 0
+    __attribute__((amdgpu_num_sgpr(LCS_LDS64_NUM_SGPR)))
+#endif
+    advect_lds64_kernel(const AdvectArgs<double> A0) {
 #pragma clang fp contract(off)
     const AdvectArgs<double> A = for_member(A0);
     const int K = KFIX >= 0 ? KFIX : A.K;
@@ -2114,7 +2128,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_kernel(const AdvectArgs<do
     for (int s = 0; s < A.nsteps; ++s) {
         // ---- 1. anchor the tile on the centre lane's predicted travel, issue its loads ----------------------------
         int ox = 0, oy = 0;
-        d2 stage[4];
+        d2 stage[T64_ROWS / 4];
         if (K > 0) {
             const double cax = (x - A.lon_min) * A.sx + dprev_x * (1.0 + kpred), cay = (y - A.lat_min) * A.sy + dprev_y * (1.0 + kpred);
             const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);
@@ -2123,7 +2137,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_kernel(const AdvectArgs<do
             oy = min(max(rym + LC_PAD_LO - (T64_ROWS - 2) / 2, 0), pad_rows - T64_ROWS);
             const char *src = (const char *)elv + ((size_t)oy * pad_cols + ox) * 16;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) __builtin_memcpy(&stage[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+            for (int r = 0; r < T64_ROWS / 4; ++r) __builtin_memcpy(&stage[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
         }
         // ---- 2. Euler sample: direct gather from img[t] ------------------------------------------------------------
         const double x0p = x, y0p = y;
@@ -2138,7 +2152,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_kernel(const AdvectArgs<do
         if (K > 0) {
             __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(r * 4 + st_row) * T64_PITCH + st_col] = stage[r];
+            for (int r = 0; r < T64_ROWS / 4; ++r) tile[(r * 4 + st_row) * T64_PITCH + st_col] = stage[r];
             __builtin_amdgcn_wave_barrier();
             // window origins (x0, y0) the tile serves: inside it (padded origin = (y0 + 1, x0 + 1)) and in [0, n - 2]
             const int sox = ox - LC_PAD_LO, soy = oy - LC_PAD_LO;

@@ -392,6 +392,13 @@ __global__ void __launch_bounds__(64) prefilter_rows_lds_kernel(T *__restrict__ 
 // A block takes 256 consecutive nodes of one padded row of one level (grid: x chunks, padded rows, levels): no
 // integer division anywhere -- the first form, one flat index per node decomposed with two 64-bit divisions, was bound
 // by that arithmetic, not by memory (C3: 0.60 ms for 3.4 GB; config 2 in float64 with both images: 2.5 ms for 10 GB).
+// Non-temporal stores of the images (nothing reads them again before the advect kernel streams them): config 2's float64
+// pack 2.07 -> 1.95 ms, C3's 0.54 -> 0.50 (profiles/r03).  -DLCS_PACK_PLAIN: plain stores (A/B).
+#ifdef LCS_PACK_PLAIN
+#define LCS_PACK_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define LCS_PACK_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)
+#endif
 template <typename T>
 __global__ void __launch_bounds__(256) pack_fused_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ lin,
                                                          T *__restrict__ ext, int nt, int ny, int nx) {
@@ -406,14 +413,10 @@ __global__ void __launch_bounds__(256) pack_fused_kernel(const T *__restrict__ u
         for (int t = blockIdx.z; t < nt; t += gridDim.z) {
             const T *us = u + (size_t)t * plane, *vs = v + (size_t)t * plane;
             const T a = us[so], b = vs[so];
-            T *l = lin + ((size_t)t * level + po) * 2;
-            l[0] = a;
-            l[1] = b;
-            if (ext && t + 1 < nt) {
-                T *e = ext + ((size_t)t * level + po) * 2;
-                e[0] = T(2) * a - us[plane + so];
-                e[1] = T(2) * b - vs[plane + so];
-            }
+            typedef T T2 __attribute__((ext_vector_type(2)));
+            LCS_PACK_STORE((T2 *)(lin + ((size_t)t * level + po) * 2), ((T2){a, b}));
+            if (ext && t + 1 < nt)
+                LCS_PACK_STORE((T2 *)(ext + ((size_t)t * level + po) * 2), ((T2){T(2) * a - us[plane + so], T(2) * b - vs[plane + so]}));
         }
     }
 }
