@@ -444,9 +444,8 @@ __global__ void __launch_bounds__(256) pads_ext_kernel(T *__restrict__ img, T *_
                 lv[po + 1] = b;
             }
             if (t + 1 < nt) {
-                T *e = ext + (size_t)t * level * 2;
-                e[po] = T(2) * a - lv[level * 2 + so];
-                e[po + 1] = T(2) * b - lv[level * 2 + so + 1];
+                typedef T T2 __attribute__((ext_vector_type(2)));
+                LCS_PACK_STORE((T2 *)(ext + (size_t)t * level * 2 + po), ((T2){T(2) * a - lv[level * 2 + so], T(2) * b - lv[level * 2 + so + 1]}));
             }
         }
     }
