@@ -6,7 +6,7 @@ Builds the "unsteady" subtropical vortex of the example (89 x 180 nodes, 8 six-h
 the same four computations through the drop-in import paths: backward and forward trajectories with
 ``return_traj=True`` and the repelling / attracting FTLE fields ``log(sigma)/2`` of
 ``LCS(...)(ds, isglobal=True)`` (0.5 degree regrid + T20 truncation included, as in the reference's defaults).
-Uses xarray objects when xarray is installed, the built-in labelled stand-ins otherwise.
+Uses xarray objects when xarray is installed, the tests' labelled stand-ins (tests/labelled.py) otherwise.
 """
 import os
 import sys
@@ -18,7 +18,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from LagrangianCoherence.LCS import LCS, trajectory  # noqa: E402
 from lagrangiancoherence_amd import flows  # noqa: E402
-from tests import labelled  # noqa: E402
 
 
 def dataset():
@@ -30,6 +29,7 @@ def dataset():
         return xr.Dataset({'u': xr.DataArray(u.transpose(1, 2, 0), dims=dims, coords=coords),
                            'v': xr.DataArray(v.transpose(1, 2, 0), dims=dims, coords=coords)})
     except ImportError:
+        from tests import labelled          # xarray-free stand-in: the drop-in returns what it is given
         coords['time'] = coords['time'].values
         return labelled.Dataset({'u': labelled.DataArray(u.transpose(1, 2, 0), dims, coords, name='u'),
                                  'v': labelled.DataArray(v.transpose(1, 2, 0), dims, coords, name='v')})
