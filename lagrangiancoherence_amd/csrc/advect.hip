@@ -2256,6 +2256,13 @@ template <int ORDER>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) advect_kernel_f32(const AdvectArgs<float> A) {
     advect_kernel_body<float, ORDER, false>(A);
 }
+// Orders above 1 without the cap: held to 96 SGPRs the order-3 kernel spills scalars into vector registers (85 VGPRs = 5
+// waves per SIMD instead of 65 = 6 with 106 SGPRs); it is the kernel of the reference's DEFAULT arguments on float32 data
+// (SETTLS_order=0, interp_order=3).
+template <int ORDER>
+__global__ void __launch_bounds__(BLOCK) advect_kernel_f32_wide(const AdvectArgs<float> A) {
+    advect_kernel_body<float, ORDER, false>(A);
+}
 
 template <typename T>
 struct Lds64Launch {
@@ -2294,9 +2301,12 @@ struct DirectLaunch {
 template <int ORDER>
 struct DirectLaunch<float, ORDER> {
     static const char *launch(const AdvectArgs<float> &A, int grid, hipStream_t st) {
-        hipLaunchKernelGGL((advect_kernel_f32<ORDER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-        return ORDER == 1 ? "advect_kernel_f32<1>" : ORDER == 2 ? "advect_kernel_f32<2>" : ORDER == 3 ? "advect_kernel_f32<3>"
-             : ORDER == 4 ? "advect_kernel_f32<4>" : "advect_kernel_f32<5>";
+        if (ORDER == 1)
+            hipLaunchKernelGGL((advect_kernel_f32<ORDER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+        else
+            hipLaunchKernelGGL((advect_kernel_f32_wide<ORDER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+        return ORDER == 1 ? "advect_kernel_f32<1>" : ORDER == 2 ? "advect_kernel_f32_wide<2>" : ORDER == 3 ? "advect_kernel_f32_wide<3>"
+             : ORDER == 4 ? "advect_kernel_f32_wide<4>" : "advect_kernel_f32_wide<5>";
     }
 };
 
