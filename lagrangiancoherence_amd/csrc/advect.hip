@@ -1905,7 +1905,8 @@ struct LdsLaunch<float, ORDER> {
             LC_LDS2(-1, false, PATCH_TALL, "advect_lds2_kernel<-1, false, 0>")
 #undef LC_LDS2
         }
-        if (ORDER == 3 && two_seed && A.ext && A.K > 0 && A.nx_f + LC_PAD >= TileGeom<3>::COLS && A.ny_f + LC_PAD >= TileGeom<3>::ROWS) {
+        // (order 3 also with SETTLS_order = 0, the reference's default: the Euler sample alone already gains from its LDS tile)
+        if (ORDER == 3 && two_seed && (A.ext || A.K == 0) && A.nx_f + LC_PAD >= TileGeom<3>::COLS && A.ny_f + LC_PAD >= TileGeom<3>::ROWS) {
             // order 3, two seeds per lane: the same patches and patch modes as above
             const int mode = A.patch_mode >= 0 ? A.patch_mode : (A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 ? PATCH_LINES : PATCH_TALL);
             int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
@@ -1943,11 +1944,12 @@ struct LdsLaunch<float, ORDER> {
 #undef LC_LDS2O3
         }
         // the fixed-size tile must fit inside one padded time level
-        if (!A.ext || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return nullptr;
-        // SETTLS_order = 0 (the library default): one Euler sample per level and nothing to stage a tile
+        if ((!A.ext && !(ORDER == 3 && A.K == 0)) || A.nx_f + LC_PAD < TileGeom<ORDER>::COLS || A.ny_f + LC_PAD < TileGeom<ORDER>::ROWS) return nullptr;
+        // SETTLS_order = 0 (the library default) at order 1: one Euler sample per level and nothing to stage a tile
         // for -- the direct-gather kernel is the faster one (2.2 vs 2.45 ms on C3; an Euler-from-LDS variant
-        // with its tile loaded a level ahead measured 2.5 ms)
-        if (A.K == 0) return nullptr;
+        // with its tile loaded a level ahead measured 2.5 ms).  Order 3 keeps its LDS kernels: their Euler sample comes
+        // from a tile of img[t] (one coalesced load per lane instead of eight gathers).
+        if (A.K == 0 && ORDER != 3) return nullptr;
         // K = 4 is the setting the reference's example and drivers use
         if (A.K == 4 && A.cyclic) {
             hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
@@ -2621,7 +2623,11 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // launch (profiles/r03): C3 96 steps 6.55 -> 6.46 ms, 200 steps 15.0 -> 13.9, C4 (8192^2 x 384) 100.2 -> 93.0, order 3
     // 16.1 -> 15.8, one member of C5 (2048^2 x 200) +17 %; chunks of 16 / 24 / 48 / 64 within 1 % of 32.  Smaller grids
     // run out of workgroups at the end of every launch and keep the single launch.
-    const int auto_chunk = (long long)ny * nx * (n_members > 1 ? n_members : 1) >= (1ll << 22) ? 32 : 0;
+    // By SETTLS_order too (a level costs 1 + K samples; 200 steps on C3): K = 4 chunks of 32 13.9 ms against 15.0 in one
+    // launch, K = 2 chunks of 64 9.66 against 9.86 (32) / 9.91 (one launch), K = 1 one launch 7.21 against 7.59 (32),
+    // K = 0 one launch 4.77 against 5.41 (32): the lighter the level, the less a launch's spread over the levels costs.
+    const int chunk_for_k = K >= 3 ? 32 : (K == 2 ? 64 : 0);
+    const int auto_chunk = (long long)ny * nx * (n_members > 1 ? n_members : 1) >= (1ll << 22) ? chunk_for_k : 0;
     const int want_chunk = ctx->level_chunk < 0 ? auto_chunk : ctx->level_chunk;
     // LC_X_CLAMP_REFERENCE_OUTER: chunks of 16 levels whatever the size, the clamp flag read back after each, the
     // positions before each chunk kept -- so the sub-step path restarts at the chunk in which a parcel first left the
