@@ -690,10 +690,16 @@ __device__ void advect_seed_f32(const AdvectArgs<float> &A, int iy, int ix) {
 //   order 1: 16x4 11.9, 16x8 10.2, 16x16 10.2, 32x8 10.6     order 3: 16x8 22.7, 16x16 21.2, 32x8 24.3, 32x16 20.4
 template <int ORDER>
 struct TileGeom {
-    static constexpr int COLS = ORDER == 3 ? 32 : 16;   // one row = COLS/2 lanes x 16 B
-    static constexpr int ROWS = ORDER == 3 ? 16 : 8;
+#ifndef LCS_O3_COLS
+#define LCS_O3_COLS 32
+#endif
+#ifndef LCS_O3_ROWS
+#define LCS_O3_ROWS 16
+#endif
+    static constexpr int COLS = ORDER == 3 ? LCS_O3_COLS : 16;   // one row = COLS/2 lanes x 16 B
+    static constexpr int ROWS = ORDER == 3 ? LCS_O3_ROWS : 8;
 #ifndef LCS_O3_PITCH
-#define LCS_O3_PITCH (32 + 4)  // 36 nodes: the 4 x 4 window reads of neighbouring rows fall into different banks (two-seed kernel on C3: 15.45 against 15.6-15.9 ms with 34)
+#define LCS_O3_PITCH (LCS_O3_COLS + 4)  // 36 nodes: the 4 x 4 window reads of neighbouring rows fall into different banks (two-seed kernel on C3: 15.45 against 15.6-15.9 ms with 34)
 #endif
     static constexpr int PITCH = ORDER == 3 ? LCS_O3_PITCH : COLS + 2;  // rows stay 16-byte aligned
     static constexpr int LANES_PER_ROW = COLS / 2;
