@@ -300,7 +300,7 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
                                f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order,
                    "fuse_levels": bool(args.fuse_levels), "build_id": csrc},
         "kernel_ms": ms,
-        "roofline": roofline(eng.last_advect_kernel(), "tcp", pts, ms["advect"], K, order, 8, 8,
+        "roofline": roofline(eng.last_advect_kernel(), "valu" if "lds" in eng.last_advect_kernel() else "tcp", pts, ms["advect"], K, order, 8, 8,
                              bool(args.fuse_levels), comp, wl, csrc, eng.last_advect_launches()),
     }
     if not args.no_cpu_baseline:
