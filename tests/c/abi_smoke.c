@@ -16,6 +16,50 @@
 #define NY 21
 #define NX 36
 
+/* The device-pointer route from plain C: lc_malloc / lc_memcpy_*, lc_field_pack, then the time-level loop in two pieces --
+ * lc_advect over levels [0, 2) and lc_advect_from over [2, 3) from its result -- against one lc_advect over [0, 3): the
+ * loop of LCS/trajectory.py:80-126 carries only positions, so the two must agree bit for bit.  A sheared wind this time
+ * (u grows with latitude, v with longitude) so that every seed samples between nodes. */
+static int continuation_check(lc_ctx *ctx, const double *u_uniform, const double *v0, const double *lat, const double *lon) {
+    static double u[NT * NY * NX], v[NT * NY * NX], xa[NY * NX], ya[NY * NX], xb[NY * NX], yb[NY * NX];
+    (void)u_uniform;
+    (void)v0;
+    for (int t = 0; t < NT; ++t)
+        for (int j = 0; j < NY; ++j)
+            for (int i = 0; i < NX; ++i) {
+                u[(t * NY + j) * NX + i] = 5.0 + 0.3 * j + 0.7 * t;
+                v[(t * NY + j) * NX + i] = 0.2 * (i - NX / 2) - 0.1 * t;
+            }
+    const size_t fb = sizeof u, pe = lc_packed_elems(NT, NY, NX), ee = lc_packed_elems(NT - 1, NY, NX), sb = sizeof xa;
+    void *du, *dv, *lin, *ext, *dlat, *dlon, *x1, *y1, *x2, *y2;
+    int st = 0;
+    st |= lc_malloc(ctx, fb, &du) | lc_malloc(ctx, fb, &dv) | lc_malloc(ctx, pe * 8, &lin) | lc_malloc(ctx, ee * 8, &ext);
+    st |= lc_malloc(ctx, NY * 8, &dlat) | lc_malloc(ctx, NX * 8, &dlon);
+    st |= lc_malloc(ctx, sb, &x1) | lc_malloc(ctx, sb, &y1) | lc_malloc(ctx, sb, &x2) | lc_malloc(ctx, sb, &y2);
+    st |= lc_memcpy_h2d(ctx, du, u, fb) | lc_memcpy_h2d(ctx, dv, v, fb) | lc_memcpy_h2d(ctx, dlat, lat, NY * 8) |
+          lc_memcpy_h2d(ctx, dlon, lon, NX * 8);
+    st |= lc_field_pack(ctx, du, dv, LC_F64, NT, NY, NX, 1, lin, ext);
+#define ADV_ARGS lin, NULL, ext, LC_F64, NT, NY, NX, lat[0], lat[NY - 1], lon[0], lon[NX - 1], dlat, NY, dlon, NX, 0, NY
+    st |= lc_advect(ctx, ADV_ARGS, 900.0, 2, 1, LC_X_CYCLIC, 0, NT - 1, x1, y1, NULL, NULL);               /* levels [0, 3) */
+    st |= lc_advect(ctx, ADV_ARGS, 900.0, 2, 1, LC_X_CYCLIC, 0, 2, x2, y2, NULL, NULL);                    /* levels [0, 2) */
+    st |= lc_advect_from(ctx, ADV_ARGS, x2, y2, 900.0, 2, 1, LC_X_CYCLIC, 2, 1, x2, y2, NULL, NULL);       /* [2, 3), in place */
+    st |= lc_sync(ctx);
+    st |= lc_memcpy_d2h(ctx, xa, x1, sb) | lc_memcpy_d2h(ctx, ya, y1, sb) | lc_memcpy_d2h(ctx, xb, x2, sb) | lc_memcpy_d2h(ctx, yb, y2, sb);
+    if (st != LC_OK) {
+        fprintf(stderr, "device-pointer route: %d %s\n", st, lc_last_error());
+        return 1;
+    }
+    int diff = 0, moved = 0;
+    for (int k = 0; k < NY * NX; ++k) {
+        diff += xa[k] != xb[k] || ya[k] != yb[k];
+        moved += xa[k] != lon[k % NX];
+    }
+    printf("lc_build_id = %s; lc_advect_from continuation: %d differences, %d of %d seeds moved\n", lc_build_id(), diff, moved, NY * NX);
+    void *all[] = {du, dv, lin, ext, dlat, dlon, x1, y1, x2, y2};
+    for (unsigned k = 0; k < sizeof all / sizeof all[0]; ++k) lc_free(ctx, all[k]);
+    return diff != 0 || moved < NY * NX / 2;
+}
+
 int main(void) {
     static double u[NT * NY * NX], v[NT * NY * NX], lat[NY], lon[NX];
     static double sigma[NY * NX], x[NY * NX], y[NY * NX];
@@ -53,6 +97,7 @@ int main(void) {
                      NT - 1, 0.0, 1, LC_LAYOUT_REFERENCE, sigma, x, y, NULL, NULL);
     printf("interp_order=6 -> status %d (%s)\n", st, lc_last_error());
     if (st != LC_EUNSUPPORTED) ++bad;
+    bad += continuation_check(ctx, u, v, lat, lon);
     lc_ctx_destroy(ctx);
     return bad ? 1 : 0;
 }

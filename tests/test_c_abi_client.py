@@ -33,3 +33,4 @@ def test_c_client_runs_known_answer(tmp_path):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mismatches" in r.stdout and "status -2" in r.stdout
+    assert "continuation: 0 differences" in r.stdout and "lc_build_id = " in r.stdout
