@@ -920,7 +920,31 @@ __device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 
 #ifndef LCS_LDS_NUM_SGPR
 #define LCS_LDS_NUM_SGPR 0
 #endif
-template <int ORDER, int KFIX, bool CYCLIC>
+enum Patch { PATCH_TALL = 0, PATCH_WIDE = 1, PATCH_LINES = 2 };
+// The whole-line trajectory store.  Measured on C3 with return_traj (advect ms, profiles/r03): plain 9.24-9.35, nontemporal
+// (`nt`: the written lines do not push the wind tiles out of the XCD's L2) 8.27-8.29, write-through sc1 9.16-9.29,
+// sc0 sc1 9.25-9.36.  -DLCS_TRAJ_STORE_KIND=0 plain, 1 nt (default), 2 sc1, 3 sc0 sc1.
+#ifndef LCS_TRAJ_STORE_KIND
+#define LCS_TRAJ_STORE_KIND 1
+#endif
+__device__ __forceinline__ void traj_store_line(float *dst, f4 v) {
+#if LCS_TRAJ_STORE_KIND == 1
+    __builtin_nontemporal_store(v, (f4 *)dst);
+#elif LCS_TRAJ_STORE_KIND == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");  // (s_nop: the >8-byte store-data hazard the compiler cannot see inside asm)
+#elif LCS_TRAJ_STORE_KIND == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#else
+    *(f4 *)dst = v;
+#endif
+}
+#define LCS_TRAJ_STORE(dst, v) traj_store_line(dst, v)
+
+// LINES (with return_traj on grids whose rows are 16-byte aligned): the four waves of a workgroup sit side by side in
+// longitude (32 x 8 seeds) instead of stacked (8 x 32), put their positions into an LDS slab after each time level, meet at
+// one workgroup barrier, and waves 0 and 1 write the longitudes' and the latitudes' 8 rows x 32 columns as whole 128-byte
+// lines, non-temporal -- the two-seed kernels' PATCH_LINES (see there for the counters) for launches below their size.
+template <int ORDER, int KFIX, bool CYCLIC, bool LINES>
 __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
 #if LCS_LDS_NUM_SGPR > 0
     __attribute__((amdgpu_num_sgpr(LCS_LDS_NUM_SGPR)))
@@ -928,6 +952,8 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     advect_lds_kernel(const AdvectArgs<float> A0) {
 #pragma clang fp contract(fast)
     const AdvectArgs<float> A = for_member(A0);
+    constexpr int SLAB1_PITCH = 36;  // floats per slab row (32 + 4)
+    __shared__ __attribute__((aligned(16))) float s_slab1[2][2][LINES ? 8 * SLAB1_PITCH : 4];
     const int K = KFIX >= 0 ? KFIX : A.K;  // KFIX: SETTLS_order known at compile time (the iteration loop unrolls)
     typedef TileGeom<ORDER> G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
@@ -939,10 +965,10 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
-    const int ix = txi * TILE_W + (threadIdx.x % TILE_W);
-    const int iy = tyi * TILE_H + (threadIdx.x / TILE_W);
-    const int lane = threadIdx.x & 63;
-    f2 *tile = s_tiles[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ix = LINES ? txi * (TILE_W * 4) + wave * TILE_W + (lane % TILE_W) : txi * TILE_W + (threadIdx.x % TILE_W);
+    const int iy = LINES ? tyi * 8 + lane / TILE_W : tyi * TILE_H + (threadIdx.x / TILE_W);
+    f2 *tile = s_tiles[wave];
 
     bool live = ix < A.nx && iy < A.ny;
     if (live) {
@@ -952,7 +978,17 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
             live = false;
         }
     }
-    if (__ballot(live) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
+    // LINES: whole-line stores for workgroups whose 32 columns are all inside the grid; workgroup-uniform, so either all
+    // four waves meet at the level's barrier or none does (a wave without seeds then stays in the loop as a shadow)
+    const bool lines = LINES && A.traj_x && A.traj_line_ok && (txi + 1) * (TILE_W * 4) <= A.nx;
+    if (!lines && __ballot(live) == 0ull) return;  // whole wave (no workgroup barrier below unless `lines`)
+    bool sl_ok = false;
+    size_t sl_idx = 0;
+    if (lines) {
+        const int iyr = tyi * 8 + (lane >> 3), grow = A.row0 + iyr;
+        sl_ok = wave < 2 && iyr < A.ny && grow >= A.order && grow < A.ny_global - A.order;  // (pole rows: written by their own threads)
+        sl_idx = (size_t)min(iyr, A.ny - 1) * A.nx + (size_t)txi * (TILE_W * 4) + (lane & 7) * 4;
+    }
     // (longitude, latitude) in adjacent registers: index map and position update are packed operations
     const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);
     f2 p = {start_x<float>(A, sy_i, sx_i), start_y<float>(A, sy_i, sx_i)};
@@ -1135,7 +1171,15 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
             p = pn;
         }
         p.y = __builtin_amdgcn_fmed3f(p.y, A.y_min, ymax_v);  // the level's one latitude clamp (stores, next Euler sample)
-        if (live && A.traj_x) {
+        if (LINES && lines) {
+            float *sx = s_slab1[s & 1][0], *sy = s_slab1[s & 1][1];
+            const int o = (lane / TILE_W) * SLAB1_PITCH + wave * TILE_W + (lane % TILE_W);
+            sx[o] = p.x;
+            sy[o] = p.y;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // one barrier per level: two slabs alternate
+            const f4 line = *(const f4 *)(s_slab1[s & 1][wave & 1] + (lane >> 3) * SLAB1_PITCH + (lane & 7) * 4);
+            if (sl_ok) LCS_TRAJ_STORE((wave ? A.traj_y : A.traj_x) + (size_t)(s + 1) * plane + sl_idx, line);
+        } else if (live && A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = p.x;
             A.traj_y[(size_t)(s + 1) * plane + idx] = p.y;
         }
@@ -1213,25 +1257,7 @@ __device__ unsigned long long g_redo[3][3][3];  // [latitude band 0-30 / 30-60 /
 //                the waves put their positions into an LDS slab, meet at ONE workgroup barrier (two slabs alternate, so one
 //                barrier per level is enough), and every wave writes a plane of 8 rows x 32 columns with one
 //                global_store_dwordx4 per lane: whole 128-byte lines.  The default with trajectories when nx % 4 == 0.
-enum Patch { PATCH_TALL = 0, PATCH_WIDE = 1, PATCH_LINES = 2 };
-// The whole-line trajectory store.  Measured on C3 with return_traj (advect ms, profiles/r03): plain 9.24-9.35, nontemporal
-// (`nt`: the written lines do not push the wind tiles out of the XCD's L2) 8.27-8.29, write-through sc1 9.16-9.29,
-// sc0 sc1 9.25-9.36.  -DLCS_TRAJ_STORE_KIND=0 plain, 1 nt (default), 2 sc1, 3 sc0 sc1.
-#ifndef LCS_TRAJ_STORE_KIND
-#define LCS_TRAJ_STORE_KIND 1
-#endif
-__device__ __forceinline__ void traj_store_line(float *dst, f4 v) {
-#if LCS_TRAJ_STORE_KIND == 1
-    __builtin_nontemporal_store(v, (f4 *)dst);
-#elif LCS_TRAJ_STORE_KIND == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");  // (s_nop: the >8-byte store-data hazard the compiler cannot see inside asm)
-#elif LCS_TRAJ_STORE_KIND == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-#else
-    *(f4 *)dst = v;
-#endif
-}
-#define LCS_TRAJ_STORE(dst, v) traj_store_line(dst, v)
+// (enum Patch: declared above the one-seed kernel, which shares PATCH_LINES' store form)
 constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byte aligned)
 
 template <int KFIX, bool CYCLIC, int MODE>
@@ -1869,10 +1895,9 @@ struct LdsLaunch<float, ORDER> {
         // two seeds per lane pays once the launch is many rounds of workgroups deep; below ~8 M seeds the one-seed kernel's
         // twice as many waves fill the machine better (4096 x 512 seeds, one GPU's share of C3 split 8 ways: +24 %;
         // measured cross-over between 2896^2 and 3500^2).  mode 1 / 2 force either (tests, A/B); 3 = by size.
-        // With trajectories the two-seed kernels' whole-line stores decide earlier: 2048^2 seeds x 96 levels, order 1
-        // 3.29 against 3.78 ms, order 3 6.19 against 6.56 (without trajectories 2.60 / 2.54 and 6.31 / 5.47): from 2^22.
-        const long long two_seed_min = (A.traj_x && A.traj_line_ok && A.patch_mode < 0) ? (1ll << 22) : (1ll << 23);
-        const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny * (long long)nmem(A) >= two_seed_min);
+        // (with trajectories too: both families store whole lines; 2048^2 seeds x 96 levels, one seed / two seeds per lane:
+        // order 1 3.26 / 3.24 ms, order 3 5.94 / 6.42; 1024^2: 1.41 / 1.60 and 2.66 / 3.39)
+        const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny * (long long)nmem(A) >= (1ll << 23));
         if (ORDER == 1 && two_seed && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16) {
             // two seeds per lane; a workgroup covers 8 x 64 seeds (PATCH_TALL), 16 x 32 (PATCH_WIDE) or 32 x 16 (PATCH_LINES)
             const int mode = A.patch_mode >= 0 ? A.patch_mode : (A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 ? PATCH_LINES : PATCH_TALL);
@@ -1956,19 +1981,32 @@ struct LdsLaunch<float, ORDER> {
         // with its tile loaded a level ahead measured 2.5 ms).  Order 3 keeps its LDS kernels: their Euler sample comes
         // from a tile of img[t] (one coalesced load per lane instead of eight gathers).
         if (A.K == 0 && ORDER != 3) return nullptr;
-        // K = 4 is the setting the reference's example and drivers use (SURVEY 8d)
-        if (A.K == 4 && A.cyclic) {
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-            return ORDER == 3 ? "advect_lds_kernel<3, 4, true>" : "advect_lds_kernel<1, 4, true>";
-        } else if (A.K == 4) {
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, 4, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-            return ORDER == 3 ? "advect_lds_kernel<3, 4, false>" : "advect_lds_kernel<1, 4, false>";
-        } else if (A.cyclic) {
-            hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-            return ORDER == 3 ? "advect_lds_kernel<3, -1, true>" : "advect_lds_kernel<1, -1, true>";
+        // with trajectories on 16-byte aligned rows: whole-line stores (waves side by side: 32 x 8 seeds per workgroup)
+        const bool lines = A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 && A.patch_mode != PATCH_TALL && A.patch_mode != PATCH_WIDE;
+        int g1 = grid;
+        if (lines) {
+            A.ntx = (A.nx + TILE_W * 4 - 1) / (TILE_W * 4);
+            A.ntiles = A.ntx * ((A.ny + 7) / 8);
+            A.xcd_chunk = A.xcd_rows * A.ntx;
+            g1 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
         }
-        hipLaunchKernelGGL((advect_lds_kernel<ORDER, -1, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-        return ORDER == 3 ? "advect_lds_kernel<3, -1, false>" : "advect_lds_kernel<1, -1, false>";
+#define LC_LDS1(KF, CY, LN, NAME)                                                                                       \
+    {                                                                                                                   \
+        hipLaunchKernelGGL((advect_lds_kernel<ORDER, KF, CY, LN>), dim3(g1, nmem(A)), dim3(BLOCK), 0, st, A);           \
+        return NAME;                                                                                                    \
+    }
+        // K = 4 is the setting the reference's example and drivers use (SURVEY 8d)
+        if (lines) {
+            if (A.K == 4 && A.cyclic) LC_LDS1(4, true, true, ORDER == 3 ? "advect_lds_kernel<3, 4, true, lines>" : "advect_lds_kernel<1, 4, true, lines>")
+            if (A.K == 4) LC_LDS1(4, false, true, ORDER == 3 ? "advect_lds_kernel<3, 4, false, lines>" : "advect_lds_kernel<1, 4, false, lines>")
+            if (A.cyclic) LC_LDS1(-1, true, true, ORDER == 3 ? "advect_lds_kernel<3, -1, true, lines>" : "advect_lds_kernel<1, -1, true, lines>")
+            LC_LDS1(-1, false, true, ORDER == 3 ? "advect_lds_kernel<3, -1, false, lines>" : "advect_lds_kernel<1, -1, false, lines>")
+        }
+        if (A.K == 4 && A.cyclic) LC_LDS1(4, true, false, ORDER == 3 ? "advect_lds_kernel<3, 4, true>" : "advect_lds_kernel<1, 4, true>")
+        if (A.K == 4) LC_LDS1(4, false, false, ORDER == 3 ? "advect_lds_kernel<3, 4, false>" : "advect_lds_kernel<1, 4, false>")
+        if (A.cyclic) LC_LDS1(-1, true, false, ORDER == 3 ? "advect_lds_kernel<3, -1, true>" : "advect_lds_kernel<1, -1, true>")
+        LC_LDS1(-1, false, false, ORDER == 3 ? "advect_lds_kernel<3, -1, false>" : "advect_lds_kernel<1, -1, false>")
+#undef LC_LDS1
     }
 };
 
