@@ -98,11 +98,12 @@ int lc_ctx_set_stream(lc_ctx *ctx, void *hip_stream /* hipStream_t; NULL = the d
 int lc_ctx_use_own_stream(lc_ctx *ctx); /* back to the context's private stream */
 int lc_sync(lc_ctx *ctx);
 
-/* Kernel choice of lc_advect for float32 + packed_ext: -1 = what lc_ctx_create set (LCS_LDS_TILES, else the default): per-wave LDS tiles, at order 1 with two seeds
- * per lane from 2^23 seeds per call upwards and one seed per lane below (smaller launches want the waves); 1 = LDS
- * tiles, two seeds per lane at order 1 whatever the size; 2 = LDS tiles, one seed per lane at every order; 0 = direct
- * gathers.  The environment variable LCS_LDS_TILES (0/1/2) sets the initial value, read ONCE in
- * lc_ctx_create (profiling A/B; results are bit-identical either way).  No reference counterpart. */
+/* Kernel choice of lc_advect: -1 = what lc_ctx_create set (LCS_LDS_TILES, else the default): per-wave LDS tiles -- float32
+ * orders 1 and 3 with two seeds per lane from 2^23 seeds per call upwards and one seed per lane below (smaller launches
+ * want the waves), float64 order 1 with packed_ext one seed per lane; 1 = LDS tiles, two seeds per lane whatever the
+ * size; 2 = LDS tiles, one seed per lane; 0 = direct gathers (float32 and float64).  SETTLS_order = 0 takes direct
+ * gathers at order 1 and the LDS kernels at order 3.  The environment variable LCS_LDS_TILES (0/1/2) sets the initial
+ * value, read ONCE in lc_ctx_create (profiling A/B; results are bit-identical either way).  No reference counterpart. */
 int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode);
 /* Kernel choice of lc_sigma for float32 sigma-only calls on grids of even width: 1 = marching kernel (a wave walks
  * down its rows with five rows of X, Y, Z in registers and takes the x-neighbours by wavefront shuffle), 0 = the
