@@ -354,7 +354,7 @@ def main():
             if have < args.gpus:
                 raise SystemExit(f"--gpus {args.gpus}: this machine shows {have} GPU(s) (one rank per GPU; "
                                  "LCS_BENCH_BACKEND=gloo LCS_BENCH_ONE_GPU=1 rehearses the N>1 path on one)")
-        limit = float(os.environ.get("LCS_BENCH_TIMEOUT", "1500"))
+        limit = float(os.environ.get("LCS_BENCH_TIMEOUT", "900"))
         sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]], limit))
 
     import torch
