@@ -1260,8 +1260,13 @@ __device__ unsigned long long g_redo[3][3][3];  // [latitude band 0-30 / 30-60 /
 // (enum Patch: declared above the one-seed kernel, which shares PATCH_LINES' store form)
 constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byte aligned)
 
+// (65 VGPRs = 7 waves per SIMD.  Asked for 8 -- -DLCS_LDS2_MINWAVES=8 -DLCS_LDS2_NUM_SGPR=80: 57 VGPRs, 78 SGPRs, no
+// spills -- C3 measures 6.58-6.73 ms against 6.48-6.52 and config 5 302 against 299 ms: occupancy is not what either lacks.)
+#ifndef LCS_LDS2_MINWAVES
+#define LCS_LDS2_MINWAVES 1
+#endif
 template <int KFIX, bool CYCLIC, int MODE>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(LCS_LDS2_NUM_SGPR)))
+__global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgpu_num_sgpr(LCS_LDS2_NUM_SGPR)))
     advect_lds2_kernel(const AdvectArgs<float> A0) {
 #pragma clang fp contract(fast)
     const AdvectArgs<float> A = for_member(A0);
