@@ -111,3 +111,46 @@ def test_float32_kernels_agree_with_each_other_and_the_oracle(fny, fnx, nt, K, o
         dx, dy = dist(out[flag][0], xo, cyclic)[ok], np.abs(out[flag][1] - yo)[ok]
         assert np.percentile(dx, 99) < 2e-3 and np.percentile(dy, 99) < 2e-3, (flag, dx.max(), dy.max())
         assert np.median(dx) < 1e-4 and np.median(dy) < 1e-4
+
+
+@settings(max_examples=30 * _SCALE, deadline=None, derandomize=_DERAND, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(dtype=st.sampled_from(["float32", "float64"]), order=st.sampled_from([1, 3]), K=st.integers(0, 4),
+       lds=st.sampled_from([-1, 0, 1, 2]), sny=st.integers(9, 140), snx=st.integers(9, 150), nt=st.integers(4, 9),
+       split=st.integers(1, 7), chunk=st.integers(1, 5), members=st.integers(1, 3), traj=st.booleans(),
+       cyclic=st.booleans(), seed=st.integers(0, 2 ** 31 - 1))
+def test_continuation_chunks_and_batches_never_change_a_bit(dtype, order, K, lds, sny, snx, nt, split, chunk, members, traj,
+                                                              cyclic, seed):
+    """lc_advect_from / lc_ctx_set_level_chunk / lc_advect_batch on random grids, kernels, orders, K, boundary modes and
+    split points: a series advected in two pieces, in level chunks, or as one member of a batch equals the single call,
+    bit for bit, trajectories included (the loop of LCS/trajectory.py:80-126 carries only positions between levels)."""
+    from lagrangiancoherence_amd import flows
+    eng = _engine()
+    u, v, lat, lon = flows.era5_like(nt=nt, ny=36, nx=72, seed=seed)
+    slat, slon = flows.seed_grid(sny, snx, lat, lon)
+    u, v, lat, lon, slat, slon = (a.astype(dtype) for a in (u * np.float32(1.5), v, lat, lon, slat, slon))
+    f = eng.prepare_field(u, v, lat, lon, order)
+    nsteps = nt - members                       # member m starts at level m
+    split = min(split, nsteps - 1) if nsteps > 1 else 0
+    kw = dict(SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic, noncyclic_clamp="pointwise")
+    try:
+        eng.set_lds_tiles(lds)
+        eng.set_level_chunk(0)
+        ref = eng.advect(f, slat, slon, -1800.0, t0=0, nsteps=nsteps, return_traj=traj, **kw)
+        if split:
+            a = eng.advect(f, slat, slon, -1800.0, t0=0, nsteps=split, return_traj=traj, **kw)
+            b = eng.advect(f, slat, slon, -1800.0, t0=split, nsteps=nsteps - split, return_traj=traj, start=(a[0], a[1]), **kw)
+            assert bool((b[0] == ref[0]).all()) and bool((b[1] == ref[1]).all())
+            if traj:
+                assert bool((a[2] == ref[2][:split + 1]).all()) and bool((b[3] == ref[3][split:]).all())
+        eng.set_level_chunk(chunk)
+        got = eng.advect(f, slat, slon, -1800.0, t0=0, nsteps=nsteps, return_traj=traj, **kw)
+        assert all(bool((g == r).all()) for g, r in zip(got, ref))
+        if cyclic and members > 1:
+            xb, yb = eng.advect_batch(f, slat, slon, -1800.0, members, nsteps, SETTLS_order=K, interp_order=order)
+            assert bool((xb[0] == ref[0]).all()) and bool((yb[0] == ref[1]).all())
+            eng.set_level_chunk(0)
+            xm, ym = eng.advect(f, slat, slon, -1800.0, t0=members - 1, nsteps=nsteps, **kw)
+            assert bool((xb[members - 1] == xm).all()) and bool((yb[members - 1] == ym).all())
+    finally:
+        eng.set_level_chunk(-1)
+        eng.set_lds_tiles(-1)
