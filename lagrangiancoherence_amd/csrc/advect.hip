@@ -2073,6 +2073,76 @@ __device__ __forceinline__ d2 sample_fast64(const double *__restrict__ lvl, cons
     return lerp_fast64(a, b, t.tx, t.ty);
 }
 
+// Order 3 in the fast float64 form: scipy's cubic B-spline weights as polynomials in t (cubic_weights_p in double) and the
+// 16 taps as four fused row sums combined by a fused column sum.  Shared by the direct and the LDS-tile kernel (explicit
+// operations: a seed's result must not depend on which of the two served it).  `w` points at the window's first node
+// (padded (y0, x0): one node up / left of the cell), `rs` is the row stride in nodes.
+__device__ __forceinline__ void cubic_weights_fast64(double t, double (&w)[4]) {
+#pragma clang fp contract(off)
+    const double tt = t * t;
+    w[3] = tt * (t * (1.0 / 6.0));
+    w[0] = fma(tt, 0.5, fma(t, -0.5, 1.0 / 6.0)) - w[3];
+    w[1] = fma(tt, fma(t, 0.5, -1.0), 2.0 / 3.0);
+    w[2] = fma(tt, fma(t, -0.5, 0.5), fma(t, 0.5, 1.0 / 6.0));
+}
+__device__ __forceinline__ d2 cubic_taps_fast64(const d2 *w, size_t rs, const double (&wx)[4], const double (&wy)[4], d2 start) {
+#pragma clang fp contract(off)
+    d2 acc = start;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const d2 *r = w + (size_t)a * rs;
+        const d2 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+        const double rx = fma(wx[3], q3.x, fma(wx[2], q2.x, fma(wx[1], q1.x, wx[0] * q0.x)));
+        const double ry = fma(wx[3], q3.y, fma(wx[2], q2.y, fma(wx[1], q1.y, wx[0] * q0.y)));
+        acc.x = fma(wy[a], rx, acc.x);
+        acc.y = fma(wy[a], ry, acc.y);
+    }
+    return acc;
+}
+__device__ __forceinline__ d2 sample_fast64_o3(const double *__restrict__ lvl, const AdvectArgs<double> &A, double x, double y, d2 start) {
+    const Loc64 t = locate_fast64(A, x, y);
+    double wx[4], wy[4];
+    cubic_weights_fast64(t.tx, wx);
+    cubic_weights_fast64(t.ty, wy);
+    return cubic_taps_fast64((const d2 *)lvl + ((size_t)t.y0 * A.pitch + t.x0), (size_t)A.pitch, wx, wy, start);
+}
+
+__device__ void advect_seed_fast64_o3(const AdvectArgs<double> &A, int iy, int ix) {
+#pragma clang fp contract(off)
+    double x = start_x<double>(A, iy, ix), y = start_y<double>(A, iy, ix);
+    const double ys = A.seed_lat[iy];
+    const double cx_conv = 180.0 / ((3.141592653589793 * 6371000.0) * fabs(cos((ys * 3.141592653589793) / 180.0)));  // Q5
+    const double dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
+    const size_t idx = (size_t)iy * A.nx + ix, plane = (size_t)A.ny * A.nx;
+    if (A.traj_x && !A.traj_skip0) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const double *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const d2 zero = {0.0, 0.0};
+    for (int s = 0; s < A.nsteps; ++s) {
+        const d2 e = sample_fast64_o3(lvl, A, x, y, zero);   // trajectory.py:82-84
+        y = fma(A.dtcy, e.y, y);                             // :86
+        x = fma(dtcx, e.x, x);                               // :87
+        clamp_position<double>(A, x, y);                     // :89-97
+        for (int k = 0; k < A.K; ++k) {                      // :100
+            const d2 d = sample_fast64_o3(elv, A, x, y, e);  // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
+            y = fma(A.hdtcy, d.y, y);
+            x = fma(hdtcx, d.x, x);
+            clamp_position<double>(A, x, y);
+        }
+        if (A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl += A.level_elems;
+        elv += A.level_elems;
+    }
+    A.x_out[idx] = x;
+    A.y_out[idx] = y;
+}
+
 __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) {
 #pragma clang fp contract(fast)
     double x = start_x<double>(A, iy, ix), y = start_y<double>(A, iy, ix);
@@ -2249,10 +2319,128 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
     }
 }
 
+// float64, ORDER 3 (the reference's default interpolation on the reference's default dtype), fused levels, per-wave LDS
+// tiles: a 16 x 16-node tile of img[t] around the patch's current position serves the Euler sample, one of ext[t] anchored on
+// the predicted travel the K iterations; 4 x 4 windows read row by row (cubic_taps_fast64, the function the direct kernel
+// uses: bit-identical); lanes whose window left a tile take the same taps from global memory.  8 x 8 seeds per wave.
+constexpr int T64O3 = 16, T64O3_PITCH = 17;
+template <int KFIX, bool CYCLIC>
+__global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs<double> A0) {
+#pragma clang fp contract(off)
+    const AdvectArgs<double> A = for_member(A0);
+    const int K = KFIX >= 0 ? KFIX : A.K;
+    __shared__ __attribute__((aligned(16))) d2 s_tiles[BLOCK / 64][2][T64O3 * T64O3_PITCH];
+    if (pole_block(A)) return;
+    const int tile_id = xcd_tile_id(A);
+    if (tile_id >= A.ntiles) return;  // whole block
+    const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
+    const int ix = txi * TILE_W + (threadIdx.x % TILE_W);
+    const int iy = tyi * TILE_H + (threadIdx.x / TILE_W);
+    const int lane = threadIdx.x & 63;
+    d2 *etile = s_tiles[threadIdx.x >> 6][0], *gtile = s_tiles[threadIdx.x >> 6][1];
+    bool live = ix < A.nx && iy < A.ny;
+    if (live) {
+        const int grow = A.row0 + iy;
+        if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path (Q3)
+            if (!A.pole_blocks) advect_seed<double, 1, false>(A, A.lin, iy, ix);
+            live = false;
+        }
+    }
+    if (__ballot(live) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
+    const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);  // lanes without a seed shadow a neighbour; stores masked
+    double x = start_x<double>(A, sy_i, sx_i), y = start_y<double>(A, sy_i, sx_i);
+    const double ys = A.seed_lat[sy_i];
+    const double cx_conv = 180.0 / ((3.141592653589793 * 6371000.0) * fabs(cos((ys * 3.141592653589793) / 180.0)));  // Q5
+    const double dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
+    const size_t idx = live ? (size_t)iy * A.nx + ix : 0, plane = (size_t)A.ny * A.nx;
+    if (live && A.traj_x && !A.traj_skip0) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const double *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    constexpr int CENTRE = TILE_W / 2 + TILE_W * 4;  // middle seed of the wave's 8 x 8 patch
+    const int st_row = lane >> 4, st_col = lane & 15;  // staging: one node per lane, 16 lanes per tile row, 4 rows per pass
+    const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 16u;
+    const double kpred = 0.5 * (double)(K > 0 ? K - 1 : 0);
+    const d2 zero = {0.0, 0.0};
+    // window origins (padded (y0, x0)) a tile with padded origin (oy, ox) serves: [ox, ox + 16 - 4] x [oy, oy + 16 - 4]
+    auto stage_tile = [&](const double *level, int ox, int oy, d2 *tile) {
+        d2 st[T64O3 / 4];
+        const char *src = (const char *)level + ((size_t)oy * pad_cols + ox) * 16;
+#pragma unroll
+        for (int r = 0; r < T64O3 / 4; ++r) __builtin_memcpy(&st[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+        __builtin_amdgcn_wave_barrier();  // the previous level's reads of this tile are done (LDS ops of a wave are in order)
+#pragma unroll
+        for (int r = 0; r < T64O3 / 4; ++r) tile[(r * 4 + st_row) * T64O3_PITCH + st_col] = st[r];
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto sample = [&](const double *level, const d2 *tile, int ox, int oy, bool have, double px, double py, d2 start) {
+        const Loc64 t = locate_fast64(A, px, py);
+        double wx[4], wy[4];
+        cubic_weights_fast64(t.tx, wx);
+        cubic_weights_fast64(t.ty, wy);
+        const int rx = t.x0 - ox, ry = t.y0 - oy;
+        if (have && (unsigned)rx <= (unsigned)(T64O3 - 4) && (unsigned)ry <= (unsigned)(T64O3 - 4))
+            return cubic_taps_fast64(tile + ry * T64O3_PITCH + rx, (size_t)T64O3_PITCH, wx, wy, start);
+        return cubic_taps_fast64((const d2 *)level + ((size_t)t.y0 * A.pitch + t.x0), (size_t)A.pitch, wx, wy, start);
+    };
+    for (int s = 0; s < A.nsteps; ++s) {
+        // ---- 1. Euler sample out of a tile of img[t] centred on the patch's current position -------------------------
+        const double c0x = (x - A.lon_min) * A.sx, c0y = (y - A.lat_min) * A.sy;
+        const int exm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(c0x, -4.0), 1.0e9)), CENTRE);
+        const int eym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(c0y, -4.0), 1.0e9)), CENTRE);
+        const int eox = min(max(exm - (T64O3 - 4) / 2, 0), pad_cols - T64O3), eoy = min(max(eym - (T64O3 - 4) / 2, 0), pad_rows - T64O3);
+        stage_tile(lvl, eox, eoy, etile);
+        const double x0p = x, y0p = y;
+        const d2 e = sample(lvl, etile, eox, eoy, true, x, y, zero);   // trajectory.py:82-84
+        y = fma(A.dtcy, e.y, y);                                        // :86
+        x = fma(dtcx, e.x, x);                                          // :87
+        clamp_position<double>(A, x, y);                                // :89-97
+        // ---- 2. tile of ext[t] anchored on the travel this level's Euler displacement predicts -----------------------
+        int ox = 0, oy = 0;
+        if (K > 0) {
+            const double cax = c0x + (x - x0p) * A.sx * (1.0 + kpred), cay = c0y + (y - y0p) * A.sy * (1.0 + kpred);
+            const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);
+            const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
+            ox = min(max(rxm - (T64O3 - 4) / 2, 0), pad_cols - T64O3);
+            oy = min(max(rym - (T64O3 - 4) / 2, 0), pad_rows - T64O3);
+            stage_tile(elv, ox, oy, gtile);
+        }
+        // ---- 3. K iterations out of LDS ---------------------------------------------------------------------------------
+        for (int k = 0; k < K; ++k) {
+            const d2 d = sample(elv, gtile, ox, oy, true, x, y, e);   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
+            y = fma(A.hdtcy, d.y, y);
+            x = fma(hdtcx, d.x, x);
+            clamp_position<double>(A, x, y);
+        }
+        if (live && A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl += A.level_elems;
+        elv += A.level_elems;
+    }
+    if (live) {
+        A.x_out[idx] = x;
+        A.y_out[idx] = y;
+    }
+}
+
 template <typename T, int ORDER, bool FUSED>
 struct InteriorPath {
     static __device__ __forceinline__ void run(const AdvectArgs<T> &A, int iy, int ix) {
         advect_seed<T, ORDER, true, FUSED>(A, A.img, iy, ix);
+    }
+};
+template <>
+struct InteriorPath<double, 3, true> {
+    static __device__ __forceinline__ void run(const AdvectArgs<double> &A, int iy, int ix) {
+        if (A.wind_f32)
+            advect_seed<double, 3, true, true>(A, A.img, iy, ix);  // (never launched: LC_F64_WIND_F32 takes no ext)
+        else
+            advect_seed_fast64_o3(A, iy, ix);
     }
 };
 template <>
@@ -2318,6 +2506,7 @@ __global__ void __launch_bounds__(BLOCK) advect_kernel_f32_wide(const AdvectArgs
 template <typename T>
 struct Lds64Launch {
     static const char *launch(const AdvectArgs<T> &, int, hipStream_t, int) { return nullptr; }
+    static const char *launch_o3(const AdvectArgs<T> &, int, hipStream_t, int) { return nullptr; }
 };
 template <>
 struct Lds64Launch<double> {
@@ -2337,6 +2526,22 @@ struct Lds64Launch<double> {
         }
         hipLaunchKernelGGL((advect_lds64_kernel<-1, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
         return "advect_lds64_kernel<-1, false>";
+    }
+    // order 3 (SETTLS_order = 0 included: the Euler sample has its own tile)
+    static const char *launch_o3(const AdvectArgs<double> &A, int grid, hipStream_t st, int mode) {
+        if (mode == 0 || A.wind_f32 || !A.ext || A.nx_f + LC_PAD < T64O3 || A.ny_f + LC_PAD < T64O3) return nullptr;
+        if (A.K == 4 && A.cyclic) {
+            hipLaunchKernelGGL((advect_lds64_o3_kernel<4, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+            return "advect_lds64_o3_kernel<4, true>";
+        } else if (A.K == 4) {
+            hipLaunchKernelGGL((advect_lds64_o3_kernel<4, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+            return "advect_lds64_o3_kernel<4, false>";
+        } else if (A.cyclic) {
+            hipLaunchKernelGGL((advect_lds64_o3_kernel<-1, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+            return "advect_lds64_o3_kernel<-1, true>";
+        }
+        hipLaunchKernelGGL((advect_lds64_o3_kernel<-1, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+        return "advect_lds64_o3_kernel<-1, false>";
     }
 };
 
@@ -2644,8 +2849,11 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                  : order == 4 ? DirectLaunch<T, 4>::launch(A, grid, ctx->stream) : DirectLaunch<T, 5>::launch(A, grid, ctx->stream);
         } else if (order == 3) {
             if (fused64) {
-                hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
-                name = "advect_kernel<double, 3, true>";
+                name = Lds64Launch<T>::launch_o3(A, grid, ctx->stream, ctx->lds_tiles);
+                if (!name) {
+                    hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
+                    name = "advect_kernel<double, 3, true>";
+                }
             } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
                 name = DirectLaunch<T, 3>::launch(A, grid, ctx->stream);
             }

@@ -725,7 +725,7 @@ def test_float64_fused_levels_option(eng, O, order):
     xe, ye = eng.advect(f_exact, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
     assert eng.last_advect_kernel() == "advect_kernel<double, %d, false>" % order
     xf, yf = eng.advect(f_fused, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
-    assert eng.last_advect_kernel() == ("advect_lds64_kernel<4, true>" if order == 1 else "advect_kernel<double, 3, true>")
+    assert eng.last_advect_kernel() == ("advect_lds64_kernel<4, true>" if order == 1 else "advect_lds64_o3_kernel<4, true>")
     xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=order,
                                   cyclic_xboundary=True)
     for got, ref in ((xf, xo), (yf, yo)):
@@ -874,25 +874,27 @@ def test_advect_batch_equals_member_by_member_in_every_float_kernel(eng, order, 
         eng.set_lds_tiles(-1)
 
 
-@pytest.mark.parametrize("K,cyclic", [(4, True), (2, True), (4, False), (1, False)])
-def test_float64_lds_tile_and_direct_kernels_agree_bitwise(eng, O, K, cyclic):
-    """float64, order 1, fused levels: the per-wave LDS-tile kernel (default) and the direct-gather kernel
-    (lc_ctx_set_lds_tiles(0)) share locate_fast64 / lerp_fast64 -- bit-identical on a flow with jets, a seam crossing,
-    pole rows, a seed grid sparser and one denser than the field, trajectories, a row block and a continuation."""
+@pytest.mark.parametrize("order", [1, 3])
+@pytest.mark.parametrize("K,cyclic", [(4, True), (2, True), (4, False), (1, False), (0, True)])
+def test_float64_lds_tile_and_direct_kernels_agree_bitwise(eng, O, K, cyclic, order):
+    """float64, fused levels: the per-wave LDS-tile kernels (default; order 3 also at K = 0) and the direct-gather kernels
+    (lc_ctx_set_lds_tiles(0)) share locate_fast64 / lerp_fast64 / cubic_taps_fast64 -- bit-identical on a flow with jets,
+    a seam crossing, pole rows, a seed grid sparser and one denser than the field, trajectories, a row block and a
+    continuation."""
     u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
     u, v, lat, lon = (a.astype(np.float64) for a in (u * 2.0, v, lat, lon))
-    f = eng.prepare_field(u, v, lat, lon, 1)
+    f = eng.prepare_field(u, v, lat, lon, order)
     for sny, snx in ((150, 200), (40, 60), (300, 512)):
         slat, slon = (a.astype(np.float64) for a in flows.seed_grid(sny, snx, lat, lon))
         out = {}
         try:
             for mode in (-1, 0):
                 eng.set_lds_tiles(mode)
-                r = eng.advect(f, slat, slon, -1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+                r = eng.advect(f, slat, slon, -1800.0, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic,
                                noncyclic_clamp="pointwise", return_traj=True)
-                assert ("lds64" in eng.last_advect_kernel()) == (mode == -1)
+                assert ("lds64" in eng.last_advect_kernel()) == (mode == -1 and (K > 0 or order == 3))
                 lo, hi = 0, sny // 2
-                rb = eng.advect(f, slat[lo:hi], slon, -1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+                rb = eng.advect(f, slat[lo:hi], slon, -1800.0, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic,
                                 noncyclic_clamp="pointwise", row0=lo, ny_global=sny, t0=3, nsteps=5, start=(r[2][3][lo:hi], r[3][3][lo:hi]))
                 out[mode] = [_np(t) for t in r] + [_np(t) for t in rb]
         finally:
@@ -900,7 +902,7 @@ def test_float64_lds_tile_and_direct_kernels_agree_bitwise(eng, O, K, cyclic):
         for a, b in zip(out[-1], out[0]):
             assert np.array_equal(a, b), (sny, snx)
         assert np.array_equal(out[-1][4], out[-1][0][:sny // 2])       # the continued row block lands on the whole run's result
-    xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+    xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-1800.0, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic,
                                   seed_lat=slat, seed_lon=slon, noncyclic_clamp="pointwise")
     d = np.abs(out[-1][0] - xo)
     assert np.minimum(d, np.abs(d - 360)).max() < POS_ATOL64 and np.abs(out[-1][1] - yo).max() < POS_ATOL64
