@@ -55,6 +55,11 @@ struct AdvectArgs {
     const T *x_start, *y_start;  // NULL: start from the seed grid; else [ny*nx] positions to continue from (lc_advect_from)
     int n_members, member_t0_stride;  // lc_advect_batch: blockIdx.y = member; member m starts at time level t0 + m * stride ...
     size_t member_plane;         // ... and reads / writes positions at x_start / x_out + m * member_plane (elements)
+    // Member groups (two-seed kernel on an ensemble, PATCH_PAIR): blockIdx.y = a GROUP of pair_g consecutive
+    // members whose start levels lie pair_d apart; a launch walks nsteps LEVELS from t0 = level pair_l0 of the group's first
+    // member; member q steps at the levels [q pair_d, q pair_d + pair_n) of the group's window; its planes lie q pair_plane on
+    int pair_d, pair_l0, pair_n, pair_g, pair_last;  // pair_d < 0: no groups; pair_last: members of the last group (1 .. pair_g)
+    size_t pair_plane;
     int traj_skip0;              // 1: traj entry 0 (the start positions) is already in place (a later chunk of one call)
     int traj_pair_ok, out_pair_ok;  // two-seed kernel, PATCH_WIDE: nx even and traj / out bases 8-byte aligned (paired stores)
     int traj_line_ok;            // two-seed kernel, PATCH_LINES: nx % 4 == 0 and traj bases 16-byte aligned (whole-line stores)
@@ -503,6 +508,34 @@ __device__ __forceinline__ bool pole_block(const AdvectArgs<T> &A) {
     return true;
 }
 
+// Member groups (PATCH_PAIR): the arguments of member q of this workgroup's group for the launch's level window
+// -- its own steps only (the generic per-seed path of the pole rows runs member by member).
+template <typename T>
+__device__ __forceinline__ AdvectArgs<T> group_member(const AdvectArgs<T> &A, int q) {
+    AdvectArgs<T> M = A;
+    const int l0 = A.pair_l0, l1 = A.pair_l0 + A.nsteps;
+    const int lo = max(l0, q * A.pair_d), hi = min(l1, A.pair_n + q * A.pair_d);
+    M.t0 = A.t0 + (lo - l0);
+    M.nsteps = max(hi - lo, 0);
+    const size_t off = (size_t)q * A.pair_plane;
+    M.x_out = A.x_out + off;
+    M.y_out = A.y_out + off;
+    if (A.x_start) {
+        M.x_start = A.x_start + off;
+        M.y_start = A.y_start + off;
+    }
+    return M;
+}
+template <typename T>
+__device__ __forceinline__ int group_count(const AdvectArgs<T> &A) { return blockIdx.y + 1 == gridDim.y ? A.pair_last : A.pair_g; }
+template <typename T>
+__device__ __forceinline__ bool pole_block_group(const AdvectArgs<T> &A) {
+    if ((int)blockIdx.x >= A.pole_blocks) return false;
+    const int cnt = group_count(A);
+    for (int q = 0; q < cnt; ++q) pole_block(group_member(A, q));
+    return true;
+}
+
 // ======================================================================================
 // float fast path (interior rows).  Same algorithm as advect_seed<float,...>; arranged so
 // that one sample position costs the VALU as little as possible, because rocprof shows
@@ -920,7 +953,7 @@ __device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 
 #ifndef LCS_LDS_NUM_SGPR
 #define LCS_LDS_NUM_SGPR 0
 #endif
-enum Patch { PATCH_TALL = 0, PATCH_WIDE = 1, PATCH_LINES = 2 };
+enum Patch { PATCH_TALL = 0, PATCH_WIDE = 1, PATCH_LINES = 2, PATCH_PAIR = 3 };
 // The whole-line trajectory store.  Measured on C3 with return_traj (advect ms, profiles/r03): plain 9.24-9.35, nontemporal
 // (`nt`: the written lines do not push the wind tiles out of the XCD's L2) 8.27-8.29, write-through sc1 9.16-9.29,
 // sc0 sc1 9.25-9.36.  -DLCS_TRAJ_STORE_KIND=0 plain, 1 nt (default), 2 sc1, 3 sc0 sc1.
@@ -1257,6 +1290,12 @@ __device__ unsigned long long g_redo[3][3][3];  // [latitude band 0-30 / 30-60 /
 //                the waves put their positions into an LDS slab, meet at ONE workgroup barrier (two slabs alternate, so one
 //                barrier per level is enough), and every wave writes a plane of 8 rows x 32 columns with one
 //                global_store_dwordx4 per lane: whole 128-byte lines.  The default with trajectories when nx % 4 == 0.
+//   PATCH_PAIR   lc_advect_batch only: the lane's seeds are the SAME grid point in two consecutive ensemble members whose
+//                start levels lie d apart (AdvectArgs::pair_*).  A wave holds 8 x 8 grid points (the one-seed kernel's
+//                patch: a sparse seed grid -- config 5, 0.7 field cells per seed -- fits the 16 x 8-node tile where the 16
+//                rows of a tall patch do not) and walks LEVELS: at level l member q takes its step l - q d, all from the
+//                same tile of ext[l] and neighbouring lines of img[l]; at the ends of the group's window only some members
+//                move (the others' step is computed and dropped: bits of the kept positions do not change).
 // (enum Patch: declared above the one-seed kernel, which shares PATCH_LINES' store form)
 constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byte aligned)
 
@@ -1270,7 +1309,8 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     advect_lds2_kernel(const AdvectArgs<float> A0) {
 #pragma clang fp contract(fast)
     const AdvectArgs<float> A = for_member(A0);
-    constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES;
+    constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES, GROUP = MODE == PATCH_PAIR;
+    constexpr int NS = SPL;  // seeds per lane (member groups: members per lane)
     constexpr int ORDER = 1;
     const int K = KFIX >= 0 ? KFIX : A.K;
     typedef Lds2Geom G;
@@ -1285,7 +1325,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     __shared__ __attribute__((aligned(16))) f4 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
     // PATCH_LINES: two slabs (alternating by level) of the workgroup's 16 x 32 longitudes and latitudes
     __shared__ __attribute__((aligned(16))) float s_slab[2][2][LINES ? 16 * SLAB_PITCH : 4];
-    if (pole_block(A)) return;
+    if (GROUP ? pole_block_group(A) : pole_block(A)) return;
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
@@ -1293,36 +1333,44 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     // workgroup origin and the lane's first seed (see enum Patch)
     const int ix0 = WIDE ? txi * (TILE_W * SPL) + SPL * (lane % TILE_W)
                   : LINES ? txi * (TILE_W * 4) + wave * TILE_W + (lane % TILE_W) : txi * TILE_W + (lane % TILE_W);
-    const int iy0 = WIDE ? tyi * TILE_H + wave * 8 + lane / TILE_W
+    const int iy0 = (WIDE || GROUP) ? tyi * TILE_H + wave * 8 + lane / TILE_W
                   : LINES ? tyi * (8 * SPL) + lane / TILE_W : tyi * (TILE_H * SPL) + wave * (8 * SPL) + lane / TILE_W;
     f4 *tile = s_tiles[wave];
 
-    bool live[SPL];
-    f2 p[SPL], dd[SPL], hd[SPL];
-    size_t idx[SPL];
+    bool live[NS];
+    f2 p[NS], dd[NS], hd[NS];
+    size_t idx[NS];
     const size_t plane = (size_t)A.ny * A.nx;
     bool any = false;
+    const int cnt = GROUP ? group_count(A) : NS;  // member groups: members of this workgroup's group (the last one may be short)
 #pragma unroll
-    for (int q = 0; q < SPL; ++q) {
-        const int ix = ix0 + (WIDE ? q : 0), iy = iy0 + (WIDE ? 0 : 8 * q);
-        live[q] = ix < A.nx && iy < A.ny;
+    for (int q = 0; q < NS; ++q) {
+        const int ix = ix0 + (WIDE ? q : 0), iy = iy0 + ((WIDE || GROUP) ? 0 : 8 * q);
+        live[q] = ix < A.nx && iy < A.ny && q < cnt;
         if (live[q]) {
             const int grow = A.row0 + iy;
             if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path, whole integration (Q3)
-                if (!A.pole_blocks) advect_seed<float, 1, false>(A, A.lin, iy, ix);  // (else the leading workgroups did them)
+                if (!A.pole_blocks) {  // (else the leading workgroups did them)
+                    if (GROUP)
+                        advect_seed<float, 1, false>(group_member(A, q), A.lin, iy, ix);
+                    else
+                        advect_seed<float, 1, false>(A, A.lin, iy, ix);
+                }
                 live[q] = false;
             }
         }
         any |= live[q];
         // lanes without a seed shadow a neighbouring one so that they follow the same path; only their stores are masked
         const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);
-        p[q] = (f2){start_x<float>(A, sy_i, sx_i), start_y<float>(A, sy_i, sx_i)};
+        const size_t moff = (GROUP && q < cnt) ? (size_t)q * A.pair_plane : 0;  // member q's planes
+        p[q] = (f2){A.x_start ? A.x_start[moff + (size_t)sy_i * A.nx + sx_i] : A.seed_lon[sx_i],
+                    A.y_start ? A.y_start[moff + (size_t)sy_i * A.nx + sx_i] : A.seed_lat[sy_i]};
         const float ys = A.seed_lat[sy_i];  // conversion_x is a function of the SEED latitude (Q5), wherever the parcel is now
         const float cx_conv =
             180.0f / ((float)(3.141592653589793 * 6371000.0) * fabsf(cosf((ys * (float)3.141592653589793) / 180.0f)));
         dd[q] = (f2){A.dt * cx_conv, A.dtcy};        // trajectory.py:55-57,86-87
         hd[q] = (f2){A.half_dt * cx_conv, A.hdtcy};  // trajectory.py:110-112
-        idx[q] = live[q] ? (size_t)iy * A.nx + ix : 0;
+        idx[q] = live[q] ? moff + (size_t)iy * A.nx + ix : 0;
     }
     // WIDE: the lane's two positions are neighbours in memory -- one 8-byte store when both are live and 8-byte aligned
     // (nx even and an aligned base: the launcher checks, A.traj_pair_ok)
@@ -1333,7 +1381,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
             *(f2 *)(dy + off + idx[0]) = (f2){p[0].y, p[1].y};
         } else {
 #pragma unroll
-            for (int q = 0; q < SPL; ++q)
+            for (int q = 0; q < NS; ++q)
                 if (live[q]) {
                     dx[off + idx[q]] = p[q].x;
                     dy[off + idx[q]] = p[q].y;
@@ -1376,23 +1424,51 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     // per lane; the last lane of a row re-reads its own node instead (its entry c+1 is never a window origin)
     const unsigned st_next = st_off + (st_col + 2 < LT_COLS ? 16u : 0u);
     // seed 0 of the lane in the patch's middle: row 8 of 16 (tall patches), row 4 of 8 and column 8 of 16 (PATCH_WIDE)
-    constexpr int CENTRE = WIDE ? TILE_W / 2 + TILE_W * 4 : TILE_W / 2 + TILE_W * 7;
+    constexpr int CENTRE = (WIDE || GROUP) ? TILE_W / 2 + TILE_W * 4 : TILE_W / 2 + TILE_W * 7;
     const f2 zero = {0.0f, 0.0f};
     f2 dprev = {0.0f, 0.0f};
+    // member groups: level iterations of this workgroup (a short last group stops with its last member's steps)
+    const int nlev = GROUP ? min(A.nsteps, max(A.pair_n + (cnt - 1) * A.pair_d - A.pair_l0, 0)) : A.nsteps;
 #ifdef LCS_STAMPS
     long long acc_t[5] = {0, 0, 0, 0, 0}, last_t = __builtin_amdgcn_s_memtime();
     unsigned long long acc_n[3] = {0, 0, 0};
 #endif
-    for (int s = 0; s < A.nsteps; ++s) {
-        f2 c0[SPL];
+    for (int s = 0; s < nlev; ++s) {
+        f2 c0[NS];
 #pragma unroll
-        for (int q = 0; q < SPL; ++q) c0[q] = to_index(p[q]);
+        for (int q = 0; q < NS; ++q) c0[q] = to_index(p[q]);
+        // member groups: which members step at this level (wave-uniform: member q's own steps are levels [q d, q d + n) of
+        // the group's window); the others' steps are dropped below.  The tile follows the middle one of those that move.
+        bool act[NS];
+        f2 keep[NS];
+        int qa = 0;
+        if (GROUP) {
+            int qlo = NS, qhi = 0;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int l = A.pair_l0 + s - q * A.pair_d;
+                act[q] = l >= 0 && l < A.pair_n && q < cnt;
+                keep[q] = p[q];
+                if (act[q]) {
+                    qlo = min(qlo, q);
+                    qhi = q;
+                }
+            }
+            qa = min(max(NS / 2, qlo), qhi);
+        }
+        auto of_anchor = [&](const f2 (&v)[NS]) {  // v[qa], qa wave-uniform
+            f2 r = v[0];
+#pragma unroll
+            for (int q = 1; q < NS; ++q) r = (GROUP && qa == q) ? v[q] : r;
+            return r;
+        };
         // ---- 1. anchor the tile on the centre lane's predicted travel and issue its loads ------------
         int ox = 0, oy = 0;
         f4 stage[NPASS];
         f2 stage_next[NPASS];
         if (K > 0) {
-            const f2 ca = dprev * (1.0f + kpred) + c0[0];
+            // (anchoring a pair's tile half way between its two members instead: 276.4 against 276.4 ms on config 5)
+            const f2 ca = dprev * (1.0f + kpred) + of_anchor(c0);
             const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
             // (the patch's middle lies 0.09 cells above this lane on C3: no shift.  A tile anchored one row higher
             // measured 23 % instead of 19 % of wave-samples with a redo, 7.19 against 7.04 ms)
@@ -1408,10 +1484,10 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
         }
         LCS_STAMP(0)  // anchor + tile load issue
         // ---- 2. Euler samples (global gathers) ----------------------------------------------------
-        f2 e[SPL], pn[SPL];
-        bool bad[SPL], anybad = false;
+        f2 e[NS], pn[NS];
+        bool bad[NS], anybad = false;
 #pragma unroll
-        for (int q = 0; q < SPL; ++q) {
+        for (int q = 0; q < NS; ++q) {
             const TapL t = tap_of(c0[q]);
             bad[q] = ((unsigned)t.x0 > (unsigned)(A.nx_f - 2)) | ((unsigned)t.y0 > (unsigned)(A.ny_f - 2));
             e[q] = window_global<ORDER>(lvl, A, t, zero);
@@ -1421,7 +1497,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
         }
         if (anybad) {  // exact sequence for the lanes / seeds that need it
 #pragma unroll
-            for (int q = 0; q < SPL; ++q) {
+            for (int q = 0; q < NS; ++q) {
                 if (bad[q]) {
                     const TapL t = tap_of(index_coords(A, p[q]));
                     e[q] = window_global<ORDER>(lvl, A, t, zero);
@@ -1430,9 +1506,9 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
                 }
             }
         }
-        dprev = (pn[0] - p[0]) * sc;  // Euler displacement in index space (predicts the next level's travel)
+        dprev = (of_anchor(pn) - of_anchor(p)) * sc;  // Euler displacement in index space (predicts the next level's travel)
 #pragma unroll
-        for (int q = 0; q < SPL; ++q) p[q] = pn[q];
+        for (int q = 0; q < NS; ++q) p[q] = pn[q];
 #ifdef LCS_STAMPS
         asm volatile("" : : "v"(p[0].x), "v"(p[1].x));
 #endif
@@ -1479,7 +1555,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
         for (int k = 0; k < K; ++k) {
             anybad = false;
 #pragma unroll
-            for (int q = 0; q < SPL; ++q) {
+            for (int q = 0; q < NS; ++q) {
                 typedef __attribute__((address_space(3))) const f4 lds_f4;
 #ifndef LCS_LDS2_FLOAT_ADDR
                 const TapL t = tap_of(to_index(p[q]));
@@ -1549,7 +1625,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
 #endif
             if (anybad) {
 #pragma unroll
-                for (int q = 0; q < SPL; ++q) {
+                for (int q = 0; q < NS; ++q) {
                     if (bad[q]) {  // exact sequence, global gather
                         f2 pc = p[q];
                         pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
@@ -1560,14 +1636,19 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
                 }
             }
 #pragma unroll
-            for (int q = 0; q < SPL; ++q) p[q] = pn[q];
+            for (int q = 0; q < NS; ++q) p[q] = pn[q];
         }
 #pragma unroll
-        for (int q = 0; q < SPL; ++q) p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);  // the level's one latitude clamp
+        for (int q = 0; q < NS; ++q) p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);  // the level's one latitude clamp
+        if (GROUP) {  // a member outside its own steps keeps its position, bit for bit
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                if (!act[q]) p[q] = keep[q];
+        }
         if (LINES && lines) {
             float *sx = s_slab[s & 1][0], *sy = s_slab[s & 1][1];
 #pragma unroll
-            for (int q = 0; q < SPL; ++q) {
+            for (int q = 0; q < NS; ++q) {
                 const int o = (lane / TILE_W + 8 * q) * SLAB_PITCH + wave * TILE_W + (lane % TILE_W);
                 sx[o] = p[q].x;
                 sy[o] = p[q].y;
@@ -1602,7 +1683,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
         *(f2 *)(A.y_out + idx[0]) = (f2){p[0].y, p[1].y};
     } else {
 #pragma unroll
-        for (int q = 0; q < SPL; ++q) {
+        for (int q = 0; q < NS; ++q) {
             if (live[q]) {
                 A.x_out[idx[q]] = p[q].x;
                 A.y_out[idx[q]] = p[q].y;
@@ -1888,6 +1969,17 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
     L.store_final(A);
 }
 
+// Kernel family of a float32 LDS-tile launch.  Two seeds per lane pays once the launch is many rounds of workgroups deep;
+// mode (lc_ctx_set_lds_tiles) 1 / 2 force either, 3 = by size (see LdsLaunch).
+static inline bool two_seeds_per_lane(const AdvectArgs<float> &A, int mode) {
+    return mode == 1 || (mode == 3 && (long long)A.nx * A.ny * (long long)nmem(A) >= (1ll << 23));
+}
+static inline bool order1_two_seed_applies(const AdvectArgs<float> &A, int mode) {
+    return two_seeds_per_lane(A, mode) && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16;
+}
+template <typename T>
+static inline bool order1_two_seed_applies(const AdvectArgs<T> &, int) { return false; }
+
 template <typename T, int ORDER>
 struct LdsLaunch {
     static const char *launch(const AdvectArgs<T> &, int, hipStream_t, int) { return nullptr; }
@@ -1902,10 +1994,25 @@ struct LdsLaunch<float, ORDER> {
         // measured cross-over between 2896^2 and 3500^2).  mode 1 / 2 force either (tests, A/B); 3 = by size.
         // (with trajectories too: both families store whole lines; 2048^2 seeds x 96 levels, one seed / two seeds per lane:
         // order 1 3.26 / 3.24 ms, order 3 5.94 / 6.42; 1024^2: 1.41 / 1.60 and 2.66 / 3.39)
-        const bool two_seed = mode == 1 || (mode == 3 && (long long)A.nx * A.ny * (long long)nmem(A) >= (1ll << 23));
-        if (ORDER == 1 && two_seed && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16) {
+        const bool two_seed = two_seeds_per_lane(A, mode);
+        if (ORDER == 1 && A.pair_d >= 0) {
+            // an ensemble, two MEMBERS per lane (advect_impl checked order1_two_seed_applies): the one-seed kernel's 8 x 32-seed workgroups
+            A.tile_order = A.tile_order_two_seed;
+#define LC_LDS2P(KF, CY, MD, NAME)                                                                          \
+    {                                                                                                       \
+        hipLaunchKernelGGL((advect_lds2_kernel<KF, CY, MD>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);   \
+        return NAME;                                                                                        \
+    }
+            if (A.K == 4 && A.cyclic) LC_LDS2P(4, true, PATCH_PAIR, "advect_lds2_kernel<4, true, 3>")
+            if (A.K == 4) LC_LDS2P(4, false, PATCH_PAIR, "advect_lds2_kernel<4, false, 3>")
+            if (A.cyclic) LC_LDS2P(-1, true, PATCH_PAIR, "advect_lds2_kernel<-1, true, 3>")
+            LC_LDS2P(-1, false, PATCH_PAIR, "advect_lds2_kernel<-1, false, 3>")
+#undef LC_LDS2P
+        }
+        if (ORDER == 1 && order1_two_seed_applies(A, mode)) {
             // two seeds per lane; a workgroup covers 8 x 64 seeds (PATCH_TALL), 16 x 32 (PATCH_WIDE) or 32 x 16 (PATCH_LINES)
-            const int mode = A.patch_mode >= 0 ? A.patch_mode : (A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 ? PATCH_LINES : PATCH_TALL);
+            const int mode = (A.patch_mode >= 0 && A.patch_mode < PATCH_PAIR) ? A.patch_mode
+                                                                               : (A.traj_x && A.traj_line_ok && A.nx >= TILE_W * 4 ? PATCH_LINES : PATCH_TALL);
             int nty = (A.ny + TILE_H * SPL - 1) / (TILE_H * SPL);
             if (mode == PATCH_WIDE) {
                 A.ntx = (A.nx + TILE_W * SPL - 1) / (TILE_W * SPL);
@@ -2766,6 +2873,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.x_start = (const T *)x_start;
     A.y_start = (const T *)y_start;
     A.traj_skip0 = 0;
+    A.pair_d = -1;
     A.traj_pair_ok = (nx % 2 == 0) && ((size_t)traj_x % (2 * sizeof(T)) == 0) && ((size_t)traj_y % (2 * sizeof(T)) == 0);
     A.out_pair_ok = (nx % 2 == 0) && ((size_t)x_out % (2 * sizeof(T)) == 0) && ((size_t)y_out % (2 * sizeof(T)) == 0);
     A.traj_line_ok = (nx % 4 == 0) && ((size_t)traj_x % 16 == 0) && ((size_t)traj_y % 16 == 0) && sizeof(T) == 4;
@@ -2889,8 +2997,29 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // LC_X_CLAMP_REFERENCE_OUTER: chunks of 16 levels whatever the size, the clamp flag read back after each, the
     // positions before each chunk kept -- so the sub-step path restarts at the chunk in which a parcel first left the
     // box instead of at t0 (regional domains: parcels leave routinely; the fused work thrown away is one chunk)
-    const int chunk = outer ? (want_chunk > 0 ? want_chunk : 16) : (want_chunk > 0 ? want_chunk : (nsteps > 0 ? nsteps : 1));
+    const int chunk_asked = outer ? (want_chunk > 0 ? want_chunk : 16) : (want_chunk > 0 ? want_chunk : (nsteps > 0 ? nsteps : 1));
     const size_t plane_elems = (size_t)ny * nx;
+    // An ensemble through the float32 two-seed order-1 kernel: consecutive MEMBERS share a lane (PATCH_PAIR).
+    // Launches walk the group's level window [0, nsteps + (g - 1) d): member q steps at levels [q d, q d + nsteps)
+    // (d = t0_stride), so the group shares its tiles for nsteps - (g - 1) d of them; continuation in place as for any chunk.
+    int group = 0;  // members per lane: 0 (no groups) or 2
+    if (n_members > 1 && order == 1 && !outer && !traj_x && use_lds && (ctx->patch_mode < 0 || ctx->patch_mode == PATCH_PAIR) &&
+        order1_two_seed_applies(A, ctx->lds_tiles)) {
+        // (four members per lane -- 99 VGPRs, the members of a lane up to 3 d levels of travel apart -- measured 480 ms on
+        // config 5 against 280 for pairs: in the jets three steps are 6 cells, nearly every wave-sample has a lane outside the tile)
+        group = nsteps > t0_stride ? 2 : 0;
+    }
+    const int total = group ? nsteps + (group - 1) * t0_stride : nsteps;
+    if (group) {
+        A.pair_d = t0_stride;
+        A.pair_n = nsteps;
+        A.pair_plane = plane_elems;
+        A.pair_g = group;
+        A.pair_last = n_members % group ? n_members % group : group;
+        A.n_members = (n_members + group - 1) / group;
+        A.member_t0_stride = group * t0_stride;
+        A.member_plane = (size_t)group * plane_elems;
+    }
     int n_launches = 0;
     T *saved = nullptr;   // [2][ny*nx]: positions at the start of the current chunk (outer mode, from the second chunk on)
     int restart = -1;
@@ -2898,10 +3027,12 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         lc_set_error("lc_advect: the flag all-reduce of LC_X_CLAMP_REFERENCE_OUTER failed (lc_ctx_set_flag_allreduce callback returned non-zero)");
         return LC_ERCCL;
     };
-    for (int s0 = 0; s0 == 0 || s0 < nsteps; s0 += chunk) {
+    const int chunk = (!outer && want_chunk <= 0) ? (total > 0 ? total : 1) : chunk_asked;
+    for (int s0 = 0; s0 == 0 || s0 < total; s0 += chunk) {
         AdvectArgs<T> C = A;
         C.t0 = t0 + s0;
-        C.nsteps = nsteps - s0 < chunk ? nsteps - s0 : chunk;
+        C.nsteps = total - s0 < chunk ? total - s0 : chunk;
+        C.pair_l0 = s0;
         if (s0 > 0) {
             C.x_start = A.x_out;
             C.y_start = A.y_out;

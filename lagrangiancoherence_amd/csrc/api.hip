@@ -59,7 +59,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->level_chunk = -1;  // by size (advect.hip: 32 levels per launch from 2^22 seeds per call)
     if (const char *ev = getenv("LCS_LEVEL_CHUNK")) c->level_chunk = atoi(ev) >= 0 ? atoi(ev) : -1;  // read once, here
     c->patch_mode = -1;
-    if (const char *ev = getenv("LCS_PATCH_MODE")) c->patch_mode = (ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : -1;  // read once, here
+    if (const char *ev = getenv("LCS_PATCH_MODE")) c->patch_mode = (ev[0] >= '0' && ev[0] <= '3') ? ev[0] - '0' : -1;  // read once, here
     c->flag_reduce = nullptr;
     c->flag_reduce_user = nullptr;
     c->lds_tiles_init = c->lds_tiles;

@@ -387,6 +387,210 @@ __global__ void __launch_bounds__(64) prefilter_rows_lds_kernel(T *__restrict__ 
     }
 }
 
+// ======================================================================================
+// float64, order 3: each sweep as ONE read and ONE write of the image (the two kernels above read and write it
+// twice: causal march, then anticausal march over what the first wrote; config 2: 3.4 + 3.2 ms for 27 GB).
+// The anticausal recursion c[i] = z (c[i+1] - c+[i]) forgets its start value by |z| per step, |z|^32 = 5e-19: started
+// LOOKAHEAD = 32 nodes further on from the mirror formula applied there (an O(|z|) guess), it reaches the nodes that
+// are kept with an error below 5e-19 of the line's scale -- under a quarter of a double's last bit, the same argument
+// as the 64-term horizon of the causal start value.  So a line is filtered in one streaming pass: the causal march runs
+// 32 nodes ahead of the nodes being finished and only finished coefficients are written.  The last window of a line
+// starts from scipy's exact mirror formula at n-1 (bit-identical tail).  LCS_FIR_PREFILTER=0: the two-march kernels.
+// ======================================================================================
+constexpr int PS_C = 16, PS_H = 32, PS_W = PS_C + PS_H;  // latitude sweep: nodes finished per round, lookahead, register window
+
+__global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const double *__restrict__ u, const double *__restrict__ v,
+                                                                    double *__restrict__ packed, int nt, int ny, int nx) {
+    const double z = -0.26794919243112270647, gain = 6.0, zend = z / (z * z - 1.0);
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
+    const size_t lines = (size_t)nt * nx * 2;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= lines) return;
+    const size_t t = i / ((size_t)nx * 2);
+    const size_t xc = i - t * (size_t)nx * 2;  // x*2 + component
+    double *c = packed + t * level + ((size_t)LC_PAD_LO * pitch + LC_PAD_LO) * 2 + xc;
+    const size_t cs = (size_t)pitch * 2, ss = (size_t)nx;
+    const double *src = ((xc & 1) ? v : u) + t * (size_t)ny * nx + (xc >> 1);
+    const int n = ny;  // >= 64 (the launcher checks)
+    // causal start value: the first 64 terms (prefilter_line_blocked's horizon), loads 8 deep
+    double c0 = gain * src[0], zi = z;
+    for (int i0 = 1; i0 < 64; i0 += 8) {
+        double a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = src[(size_t)min(i0 + q, 63) * ss];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (i0 + q < 64) {
+                c0 += zi * (gain * a[q]);
+                zi *= z;
+            }
+        }
+    }
+    double r[PS_W];  // causal values of nodes s .. s + PS_W - 1
+    r[0] = c0;
+    {
+        double prev = c0;
+#pragma unroll
+        for (int j0 = 1; j0 < PS_W; j0 += 16) {
+            double a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = src[(size_t)min(j0 + q, PS_W - 1) * ss];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (j0 + q < PS_W) {
+                    prev = gain * a[q] + z * prev;
+                    r[j0 + q] = prev;
+                }
+            }
+        }
+    }
+    for (int s = 0;; s += PS_C) {
+        const int rem = n - s;
+        if (rem <= PS_W) {  // the window reaches the end of the line: scipy's start value at n-1, every node kept
+            const int jl = rem - 1;  // >= PS_H
+            double next = 0.0;
+#pragma unroll
+            for (int j = PS_W - 1; j >= 0; --j) {
+                if (j == jl)
+                    next = (z * r[j > 0 ? j - 1 : 0] + r[j]) * zend;
+                else
+                    next = z * (next - r[j]);
+                if (j <= jl) c[(size_t)(s + j) * cs] = next;
+            }
+            return;
+        }
+        // the next PS_C inputs, in flight during the anticausal walk
+        double a[PS_C];
+#pragma unroll
+        for (int q = 0; q < PS_C; ++q) a[q] = src[(size_t)min(s + PS_W + q, n - 1) * ss];
+        double next = (z * r[PS_W - 2] + r[PS_W - 1]) * zend;
+#pragma unroll
+        for (int j = PS_W - 2; j >= PS_C; --j) next = z * (next - r[j]);
+#pragma unroll
+        for (int j = PS_C - 1; j >= 0; --j) {
+            next = z * (next - r[j]);
+            c[(size_t)(s + j) * cs] = next;
+        }
+        double prev = r[PS_W - 1];
+#pragma unroll
+        for (int j = 0; j < PS_H; ++j) r[j] = r[j + PS_C];
+#pragma unroll
+        for (int q = 0; q < PS_C; ++q) {  // (values past n-1 repeat the last input: never read, the last window stops at jl)
+            prev = gain * a[q] + z * prev;
+            r[PS_H + q] = prev;
+        }
+    }
+}
+
+// Longitude sweep, same scheme on the wave-per-32-rows LDS tile of prefilter_rows_lds_kernel: the tile is a ring of
+// 64 nodes (two chunks of 32); a lane walks its line (row, component) through it.  Round k: the ring holds the causal
+// values of chunks k and k+1; the lane starts the anticausal walk at the end of chunk k+1, walks chunk k+1 without
+// writing, finishes chunk k in place; the wave stores chunk k as whole 512-byte row segments, drops chunk k+2 (loaded
+// into registers before the walk, so its latency is behind it) into the freed half and runs the causal march over it.
+constexpr int RS_ROWS = 32, RS_C = 32, RS_RING = 2 * RS_C;
+
+__global__ void __launch_bounds__(64) prefilter_rows_stream_kernel(double *__restrict__ packed, int ny, int nx) {
+    __shared__ double ring[RS_ROWS][2 * RS_RING + 1];
+    const double z = -0.26794919243112270647, gain = 6.0, zend = z / (z * z - 1.0);
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
+    const int t = blockIdx.y;
+    const int r0 = blockIdx.x * RS_ROWS;
+    const int lane = threadIdx.x;
+    const int row = lane >> 1, comp = lane & 1;
+    const bool line_ok = r0 + row < ny;
+    double *base = packed + (size_t)t * level + ((size_t)(r0 + LC_PAD_LO) * pitch + LC_PAD_LO) * 2;  // row r0, node 0
+    const int nrows = min(RS_ROWS, ny - r0);
+    double *mine = &ring[row][comp];  // node i of this lane's line: mine[2 * (i & 63)]
+
+    auto chunk_cnt = [&](int k) { return min(RS_C, nx - k * RS_C); };
+    auto fetch = [&](int k, double (&reg)[RS_ROWS]) {  // chunk k of every row -> registers (one 512-byte segment per row)
+        const int cnt = chunk_cnt(k);
+#pragma unroll
+        for (int q = 0; q < RS_ROWS; ++q) {
+            const int rr = min(q, nrows - 1);
+            reg[q] = lane < 2 * cnt ? base[(size_t)rr * pitch * 2 + (size_t)k * RS_C * 2 + lane] : 0.0;
+        }
+    };
+    auto drop = [&](int k, const double (&reg)[RS_ROWS]) {
+        const int h = (k & 1) * RS_C * 2;
+#pragma unroll
+        for (int q = 0; q < RS_ROWS; ++q) ring[q][h + lane] = reg[q];
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto store = [&](int k) {
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = chunk_cnt(k), h = (k & 1) * RS_C * 2;
+        if (lane < 2 * cnt)
+            for (int rr = 0; rr < nrows; ++rr) base[(size_t)rr * pitch * 2 + (size_t)k * RS_C * 2 + lane] = ring[rr][h + lane];
+        __builtin_amdgcn_wave_barrier();
+    };
+    double prev = 0.0;
+    auto causal = [&](int k, int first) {  // march over chunk k from its node ``first``
+        const int cnt = chunk_cnt(k);
+        double *p = mine + (k & 1) * RS_C * 2;
+#pragma unroll 8
+        for (int i = first; i < cnt; ++i) {
+            prev = gain * p[2 * i] + z * prev;
+            p[2 * i] = prev;
+        }
+    };
+
+    double reg[RS_ROWS];
+    fetch(0, reg);
+    drop(0, reg);
+    fetch(1, reg);
+    drop(1, reg);  // nx >= 64: chunks 0 and 1 are whole
+    if (line_ok) {
+        double c0 = gain * mine[0], zi = z;  // start value from the first 64 terms
+#pragma unroll 8
+        for (int k = 1; k < RS_RING; ++k) {
+            c0 += zi * (gain * mine[2 * k]);
+            zi *= z;
+        }
+        prev = c0;
+        mine[0] = prev;
+        causal(0, 1);
+        causal(1, 0);
+    }
+    const int nch = (nx + RS_C - 1) / RS_C;
+    for (int k = 0;; ++k) {
+        const bool last = k + 2 >= nch;  // the ring reaches the end of the line
+        if (!last) fetch(k + 2, reg);
+        if (line_ok) {
+            if (last) {  // scipy's start value at nx-1; chunks k and k+1 are both finished
+                constexpr int M = RS_RING - 1;
+                double next = (z * mine[2 * ((nx - 2) & M)] + mine[2 * ((nx - 1) & M)]) * zend;
+                mine[2 * ((nx - 1) & M)] = next;
+#pragma unroll 8
+                for (int i = nx - 2; i >= k * RS_C; --i) {
+                    next = z * (next - mine[2 * (i & M)]);
+                    mine[2 * (i & M)] = next;
+                }
+            } else {
+                const double *pa = mine + ((k + 1) & 1) * RS_C * 2;
+                double next = (z * pa[2 * (RS_C - 2)] + pa[2 * (RS_C - 1)]) * zend;
+#pragma unroll 8
+                for (int j = RS_C - 2; j >= 0; --j) next = z * (next - pa[2 * j]);
+                double *p = mine + (k & 1) * RS_C * 2;
+#pragma unroll 8
+                for (int j = RS_C - 1; j >= 0; --j) {
+                    next = z * (next - p[2 * j]);
+                    p[2 * j] = next;
+                }
+            }
+        }
+        store(k);
+        if (last) {
+            store(k + 1);
+            return;
+        }
+        drop(k + 2, reg);
+        if (line_ok) causal(k + 2, 0);
+    }
+}
+
 // Order 1 in one pass over the PADDED image: every node (pads included) reads its mirrored
 // source once and writes lin[t] and, when asked, ext[t] = 2 F[t] - F[t+1].
 // A block takes 256 consecutive nodes of one padded row of one level (grid: x chunks, padded rows, levels): no
@@ -612,9 +816,21 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
         // scipy filters axis 0 first, then axis 1 (spline_filter loops over axes in order); the latitude sweep
         // reads the raw field and writes the interleaved image
         size_t lines = (size_t)nt * nx * 2;
-        hipLaunchKernelGGL(prefilter_cols_kernel<T>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
-                           ctx->stream, u, v, packed, nt, ny, nx);
-        if (nx >= PR_CHUNK) {
+        // float64: one read + one write per sweep (lines of 64 nodes or more; LCS_FIR_PREFILTER=0: the two-march kernels)
+        const bool stream = sizeof(T) == 8 && ctx->fir_prefilter;
+        if constexpr (sizeof(T) == 8) {
+            if (stream && ny >= 64)
+                hipLaunchKernelGGL(prefilter_cols_stream_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, ctx->stream, u, v,
+                                   packed, nt, ny, nx);
+        }
+        if (!(stream && ny >= 64))
+            hipLaunchKernelGGL(prefilter_cols_kernel<T>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
+                               ctx->stream, u, v, packed, nt, ny, nx);
+        if (stream && nx >= RS_RING) {
+            if constexpr (sizeof(T) == 8)
+                hipLaunchKernelGGL(prefilter_rows_stream_kernel, dim3((ny + RS_ROWS - 1) / RS_ROWS, nt), dim3(64), 0, ctx->stream, packed,
+                                   ny, nx);
+        } else if (nx >= PR_CHUNK) {
             hipLaunchKernelGGL(prefilter_rows_lds_kernel<T>, dim3((ny + PR_ROWS - 1) / PR_ROWS, nt), dim3(64), 0,
                                ctx->stream, packed, ny, nx);
         } else {

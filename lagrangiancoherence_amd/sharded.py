@@ -174,7 +174,7 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
     return {"sigma": sig, "x_dep": x, "y_dep": y, "rows": (lo, hi)}
 
 
-ENSEMBLE_CHUNK = 8   # time levels per launch of ensemble_advect's level-major order (measured on config 5)
+ENSEMBLE_CHUNK = 16   # time levels per launch of ensemble_advect's level-major order (measured on config 5)
 
 
 def ensemble_advect(engine, field, seed_lat, seed_lon, timestep, members, nsteps: int, SETTLS_order=0, interp_order=1,

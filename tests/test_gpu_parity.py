@@ -560,6 +560,31 @@ def test_one_pass_prefilter_matches_the_recursive_sweeps(eng, O, monkeypatch):
     assert np.array_equal(_np(eng.prepare_field(u2, v2, lat2, lon2, 3).cub), _np(eng0.prepare_field(u2, v2, lat2, lon2, 3).cub))
 
 
+@pytest.mark.parametrize("ny,nx", [(97, 150), (64, 64), (130, 65), (65, 97), (37, 150), (97, 40), (81, 96), (200, 257)])
+def test_float64_streaming_prefilter_matches_the_two_march_sweeps_and_scipy(eng, O, monkeypatch, ny, nx):
+    """float64, order 3: the one-read-one-write sweeps (default; lines of 64 nodes or more, anticausal walk started 32
+    nodes ahead) against the two-march kernels (LCS_FIR_PREFILTER=0) and against scipy's recursion: line lengths at
+    the limit (64), one node over a chunk, a ragged last chunk, a ragged row block, one axis too short for the
+    streaming form; pads and the fused-level image follow."""
+    from lagrangiancoherence_amd.engine import Engine
+    u, v, lat, lon = _rand_field(1000 + ny + nx, nt=3, ny=ny, nx=nx, dtype=np.float64, scale=20.0)
+    monkeypatch.setenv("LCS_FIR_PREFILTER", "0")
+    eng0 = Engine(0)
+    monkeypatch.delenv("LCS_FIR_PREFILTER")
+    a, b = eng.prepare_field(u, v, lat, lon, 3), eng0.prepare_field(u, v, lat, lon, 3)
+    scale = float(np.abs(u).max())
+    for name in ("cub", "ext"):
+        x, y = _np(getattr(a, name)), _np(getattr(b, name))
+        nlev = 3 if name == "cub" else 2
+        x, y = x.reshape(-1, ny + 3, nx + 3, 2)[:nlev], y.reshape(-1, ny + 3, nx + 3, 2)[:nlev]
+        assert np.abs(x - y).max() <= 3e-15 * scale * (3 if name == "ext" else 1), name   # a few last bits of the line's scale (fma grouping)
+    img = _np(a.cub).reshape(3, ny + 3, nx + 3, 2)
+    for t in range(3):
+        np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 0], O.spline_prefilter_mirror(u[t]), rtol=0, atol=2e-14 * scale)
+        np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 1], O.spline_prefilter_mirror(v[t]), rtol=0, atol=2e-14 * scale)
+    assert np.array_equal(img[:, 0, 1:nx + 1], img[:, 2, 1:nx + 1]) and np.array_equal(img[:, :, nx + 2], img[:, :, nx - 2])
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("order", [1, 3])
 def test_launch_geometry_does_not_change_results(dtype, order, monkeypatch):
@@ -872,6 +897,61 @@ def test_advect_batch_equals_member_by_member_in_every_float_kernel(eng, order, 
     finally:
         eng.set_level_chunk(-1)
         eng.set_lds_tiles(-1)
+
+
+@pytest.mark.parametrize("members,stride,nsteps,chunk,K", [(4, 1, 7, 3, 4), (5, 1, 6, 0, 4), (3, 2, 5, 2, 2), (2, 0, 4, 0, 1),
+                                                         (7, 3, 5, 4, 4), (2, 1, 2, 1, 4), (6, 1, 9, -1, 3), (9, 2, 8, 5, 4),
+                                                         (4, 0, 3, 2, 4)])
+def test_member_pairs_in_the_two_seed_kernel_equal_member_by_member(eng, members, stride, nsteps, chunk, K):
+    """lc_advect_batch through the two-seed order-1 kernel holds two consecutive MEMBERS per lane (PATCH_PAIR: launches
+    walk the pair's level window, the second member t0_stride levels behind the first): bit for bit one lc_advect per
+    member -- odd member counts (a pair without a second member), strides 0..3, level chunks that cut the window before /
+    at / after the second member's start, pole rows in leading workgroups and inside the tiles, a continuation in
+    place; and the tall-patch form of the same kernel (LCS_PATCH_MODE=0) for the same call."""
+    from lagrangiancoherence_amd.engine import Engine
+    u, v, lat, lon = flows.era5_like(nt=30, ny=60, nx=120)
+    slat, slon = flows.seed_grid(101, 144, lat, lon)
+    slat = slat.copy(); slat[0], slat[-1] = -90.0, 90.0          # global pole rows (generic per-seed path, Q3)
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    ref = []
+    eng.set_level_chunk(0)
+    for m in range(members):
+        ref.append(eng.advect(f, slat, slon, -1800.0, SETTLS_order=K, interp_order=1, t0=2 + m * stride, nsteps=nsteps))
+    try:
+        eng.set_lds_tiles(1)
+        eng.set_level_chunk(chunk)
+        xb, yb = eng.advect_batch(f, slat, slon, -1800.0, members, nsteps, SETTLS_order=K, interp_order=1, t0=2, t0_stride=stride)
+        want = ", 3>" if nsteps > stride else ", 0>"
+        assert eng.last_advect_kernel().endswith(want), eng.last_advect_kernel()
+        for m in range(members):
+            assert bool((xb[m] == ref[m][0]).all()) and bool((yb[m] == ref[m][1]).all()), m
+        # continuation in place: the first steps, then the rest from where they stopped
+        n1 = max(1, nsteps // 2)
+        xa, ya = eng.advect_batch(f, slat, slon, -1800.0, members, n1, SETTLS_order=K, interp_order=1, t0=2, t0_stride=stride)
+        if nsteps > n1:
+            eng.advect_batch(f, slat, slon, -1800.0, members, nsteps - n1, SETTLS_order=K, interp_order=1, t0=2 + n1,
+                             t0_stride=stride, start=(xa, ya), out=(xa, ya))
+        for m in range(members):
+            assert bool((xa[m] == ref[m][0]).all()) and bool((ya[m] == ref[m][1]).all()), ("continued", m)
+    finally:
+        eng.set_level_chunk(-1)
+        eng.set_lds_tiles(-1)
+    # pole rows inside the tiles (LCS_POLE_BLOCKS=0) and the tall patches (LCS_PATCH_MODE=0): other contexts
+    import os
+    for env, val, suffix in (("LCS_POLE_BLOCKS", "0", want), ("LCS_PATCH_MODE", "0", ", 0>"), ("LCS_PATCH_MODE", "3", ", 3>")):
+        os.environ[env] = val
+        try:
+            e2 = Engine(0)
+        finally:
+            del os.environ[env]
+        f2_ = e2.prepare_field(u, v, lat, lon, 1)
+        e2.set_lds_tiles(1)
+        e2.set_level_chunk(chunk)
+        xb, yb = e2.advect_batch(f2_, slat, slon, -1800.0, members, nsteps, SETTLS_order=K, interp_order=1, t0=2, t0_stride=stride)
+        if nsteps > stride:
+            assert e2.last_advect_kernel().endswith(suffix), e2.last_advect_kernel()
+        for m in range(members):
+            assert bool((xb[m] == ref[m][0]).all()) and bool((yb[m] == ref[m][1]).all()), (env, val, m)
 
 
 @pytest.mark.parametrize("order", [1, 3])
