@@ -267,7 +267,10 @@ int lc_advect_from(lc_ctx *ctx, const void *packed_lin, const void *packed_cub,
  * keeps its positions in the m-th [ny*nx] plane of x_start / x_out ([n_members][ny*nx]; x_start NULL = every member
  * starts on the seed grid; in place allowed).  With lc_ctx_set_level_chunk(c) the members advance together c levels
  * at a time (level-major order), so the launches of a chunk share all but a few of their time levels in the caches
- * and a launch is n_members times deeper than a member's own (no tail of idle compute units between members).  Each
+ * and a launch is n_members times deeper than a member's own (no tail of idle compute units between members).  In
+ * float32 at order 1 with SETTLS_order > 0, from 2^23 seeds per call, consecutive members share a LANE (members 2p and
+ * 2p + 1 at the same grid point: at field level l one takes its step l, the other its step l - t0_stride, from one staged
+ * tile of the wind), and the launches walk the pair's level window instead of a step range.  Each
  * member's result is, bit for bit, what lc_advect(t0 + m * t0_stride) gives.  traj_x / traj_y must be NULL and
  * cyclic_x must not be LC_X_CLAMP_REFERENCE_OUTER when n_members > 1.  No reference counterpart: there the caller
  * loops over start times (LCS/trajectory.py:80 consumes one series). */

@@ -185,7 +185,8 @@ def ensemble_advect(engine, field, seed_lat, seed_lon, timestep, members, nsteps
     launch per chunk (``lc_advect_batch``: member = blockIdx.y): members ``e`` and ``e+1`` of a chunk read time levels
     ``[e + c, e + c + chunk]`` and ``[e + 1 + c, ...]`` -- all but one in common -- so the wind images stay in the
     Infinity Cache / L2, and a launch is as many times deeper as there are members, so no compute unit idles at the
-    end of each member's own launch (config 5 on one MI355X: DESIGN 4).  Any other member list falls back to one launch
+    end of each member's own launch; in float32 at order 1 two consecutive members share a lane of the two-seed kernel
+    (same grid point, one level of travel apart, one staged tile of the wind for both) (config 5 on one MI355X: DESIGN 4).  Any other member list falls back to one launch
     per member and chunk (``lc_advect_from``) on ``streams`` HIP streams.  Results are bit-identical to one launch per
     member (the loop of LCS/trajectory.py:80-126 carries only positions from level to level).  ``level_chunk=0``:
     member-major, one launch per member.  Returns ``[(x, y), ...]`` in the order of ``members``; everything is joined
