@@ -123,7 +123,7 @@ int lc_ctx_set_sigma_march(lc_ctx *ctx, int on);
 typedef int (*lc_flag_allreduce_fn)(void *user, void *flags_dev, size_t count);
 int lc_ctx_set_flag_allreduce(lc_ctx *ctx, lc_flag_allreduce_fn fn, void *user);
 /* lc_advect / lc_advect_from run a series of nsteps time levels as consecutive launches of at most `levels` levels,
- * each continuing from the positions the previous one stored (0 = one launch; -1 = by size, the default: from 2^22
+ * each continuing from the positions the previous one stored (0 = one launch; -1 = by size, the default: from 2^18
  * seeds per call upwards 32 levels per launch for SETTLS_order >= 3, 64 for 2, one launch below).  Results are bit-identical whatever the value; it shapes the launches
  * only (workgroups of one launch stay within `levels` levels of each other, so their tiles of the wind images meet in
  * L2 / the Infinity Cache, and the launch's tail is one chunk long: long series and sparse seed grids gain 7-17 %).

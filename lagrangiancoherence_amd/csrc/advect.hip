@@ -1242,7 +1242,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
 constexpr int SPL = 2;  // seeds per lane
 
 // Tile geometry of the two-seed kernel (nodes).  Measured (advect ms on C3 / on C5's 64 members): 16x8 7.15 / 462,
-// 16x16 7.44 / 477, 32x8 7.85 / 495, 32x16 - / 479.  Where the windows leave the tile (-DLCS_STAMPS counters, C3):
+// 16x16 7.44 / 477, 32x8 7.85 / 495, 32x16 - / 479 (round 3, member pairs on C5: 16x8 6.31 / 277.5, 8x16 6.63 / 297).  Where the windows leave the tile (-DLCS_STAMPS counters, C3):
 // 2.3 % of the seed-samples in x, 4.6 % in y, evenly above and below -- patches the flow has deformed; a 16-row
 // tile brings y down to 1.5 % and the wave-samples with a redo from 19 % to 11 %, but its second staging pass
 // costs what the redos saved (7.19 against 7.04 ms).  C5 (seeds half as dense, 200 steps) is slower per particle
@@ -2430,7 +2430,10 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
 // tiles: a 16 x 16-node tile of img[t] around the patch's current position serves the Euler sample, one of ext[t] anchored on
 // the predicted travel the K iterations; 4 x 4 windows read row by row (cubic_taps_fast64, the function the direct kernel
 // uses: bit-identical); lanes whose window left a tile take the same taps from global memory.  8 x 8 seeds per wave.
-constexpr int T64O3 = 16, T64O3_PITCH = 17;
+#ifndef LCS_T64O3_PITCH
+#define LCS_T64O3_PITCH 20  // nodes; 320-byte rows: the 8 + 8 lanes of a 16-lane read group (two patch rows) overlap in half of the banks instead of 7/8 (pitch 17: 8.46 ms on config 2, 20: 7.90, 24 -- no overlap, but 48 KB of LDS = 3 workgroups per CU -- 8.25)
+#endif
+constexpr int T64O3 = 16, T64O3_PITCH = LCS_T64O3_PITCH;
 template <int KFIX, bool CYCLIC>
 __global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs<double> A0) {
 #pragma clang fp contract(off)
@@ -2984,15 +2987,20 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // series (sparse seed grids: DESIGN 4) -- and the launch's tail is one chunk long.  Positions at a level's end are
     // the kernels' whole state (the latitude clamp is applied before they are stored), so chunked == unchunked, bit
     // for bit.
-    // Default (level_chunk < 0): 32 levels per launch from 2^22 seeds per call upwards -- measured on MI355X against one
-    // launch (profiles/r03): C3 96 steps 6.55 -> 6.46 ms, 200 steps 15.0 -> 13.9, C4 (8192^2 x 384) 100.2 -> 93.0, order 3
-    // 16.1 -> 15.8, one member of C5 (2048^2 x 200) +17 %; chunks of 16 / 24 / 48 / 64 within 1 % of 32.  Smaller grids
-    // run out of workgroups at the end of every launch and keep the single launch.
+    // Default (level_chunk < 0): 32 levels per launch -- measured on MI355X against one launch (profiles/r03): C3 96 steps
+    // 6.55 -> 6.46 ms, 200 steps 15.0 -> 13.9, C4 (8192^2 x 384) 100.2 -> 93.0, order 3 16.1 -> 15.8, one member of C5
+    // (2048^2 x 200) +17 %; chunks of 16 / 24 / 48 / 64 within 1 % of 32.  Small grids too (below): only launches of
+    // less than one workgroup per compute unit keep the single launch.
     // By SETTLS_order too (a level costs 1 + K samples; 200 steps on C3): K = 4 chunks of 32 13.9 ms against 15.0 in one
     // launch, K = 2 chunks of 64 9.66 against 9.86 (32) / 9.91 (one launch), K = 1 one launch 7.21 against 7.59 (32),
     // K = 0 one launch 4.77 against 5.41 (32): the lighter the level, the less a launch's spread over the levels costs.
     const int chunk_for_k = K >= 3 ? 32 : (K == 2 ? 64 : 0);
-    const int auto_chunk = (long long)ny * nx * (n_members > 1 ? n_members : 1) >= (1ll << 22) ? chunk_for_k : 0;
+    // From 2^18 seeds per call (measured, chunks of 32 against one launch, 96 levels of the 720 x 1440 float32 series unless
+    // noted: 512^2 seeds 1.256 -> 1.23 ms, 724^2 1.25 -> 1.05, 1024^2 1.43 -> 1.37, 1024^2 x 200 levels 3.16 -> 2.89, order 3
+    // 3.27 -> 3.15, 2048^2 2.67 -> 2.60; float64 config 2, 1024^2 x 200: order 1 3.30 -> 3.06, order 3 7.66 -> 6.97 with 25-32
+    // levels, 8 / 16 / 50 / 100 within 2-5 % of that).
+    const long long chunk_from = 1ll << 18;
+    const int auto_chunk = (long long)ny * nx * (n_members > 1 ? n_members : 1) >= chunk_from ? chunk_for_k : 0;
     const int want_chunk = ctx->level_chunk < 0 ? auto_chunk : ctx->level_chunk;
     // LC_X_CLAMP_REFERENCE_OUTER: chunks of 16 levels whatever the size, the clamp flag read back after each, the
     // positions before each chunk kept -- so the sub-step path restarts at the chunk in which a parcel first left the

@@ -113,7 +113,7 @@ class Engine:
 
     def set_level_chunk(self, levels: int):
         """Run every advect call as consecutive launches of at most ``levels`` time levels (0: one launch; -1: by size,
-        the default -- 32 levels from 2^22 seeds per call).  Results are bit-identical; it shapes the launches only
+        the default -- 32 levels from 2^18 seeds per call).  Results are bit-identical; it shapes the launches only
         (``lc_ctx_set_level_chunk``)."""
         _capi.check(self.lib.lc_ctx_set_level_chunk(self.ctx, int(levels)), self.lib)
         self.level_chunk = int(levels)

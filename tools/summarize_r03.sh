@@ -16,6 +16,10 @@ W='{"workload":"c2","order":1,"K":4,"dtype":"f64","fuse_levels":true}'
 python profiles/summarize.py gpurun_out/r03_c2 profiles/r03/c2 "$W" > /dev/null
 python profiles/summarize_sq.py gpurun_out/r03_c2 profiles/r03/c2 "$W" 200 > /dev/null
 cp gpurun_out/r03_c2/bench_stdout.json profiles/r03/c2_bench_stdout.json
+W='{"workload":"c2","order":3,"K":4,"dtype":"f64","fuse_levels":true}'
+python profiles/summarize.py gpurun_out/r03_c2_o3 profiles/r03/c2_o3 "$W" > /dev/null
+python profiles/summarize_sq.py gpurun_out/r03_c2_o3 profiles/r03/c2_o3 "$W" 200 > /dev/null
+cp gpurun_out/r03_c2_o3/bench_stdout.json profiles/r03/c2_o3_bench_stdout.json
 tools/regs.sh > /dev/null
 python tools/isa_hist.py build/isa/regs_tmp.s advect_lds2_kernelILi4ELb1ELi0E --json profiles/r03/isa_hist_advect_lds2_k4_cyclic.json > /dev/null
 python tools/isa_hist.py build/isa/regs_tmp.s advect_lds2_o3_kernelILi4ELb1ELi0E --json profiles/r03/isa_hist_advect_lds2_o3_k4_cyclic.json > /dev/null
