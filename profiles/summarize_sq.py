@@ -45,7 +45,7 @@ def short(name):
 
 
 def main():
-    run, out, workload, nsteps = sys.argv[1], sys.argv[2], json.loads(sys.argv[3]), int(sys.argv[4])
+    run, out, workload, nsteps = sys.argv[1], sys.argv[2], json.loads(sys.argv[3]), float(sys.argv[4])
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob(os.path.join(run, "p*", "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):

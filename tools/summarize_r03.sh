@@ -14,11 +14,11 @@ python profiles/summarize_sq.py gpurun_out/r03_c3_o1_traj profiles/r03/c3_o1_tra
 cp gpurun_out/r03_c3_o1_traj/bench_stdout.json profiles/r03/c3_o1_traj_bench_stdout.json
 W='{"workload":"c2","order":1,"K":4,"dtype":"f64","fuse_levels":true}'
 python profiles/summarize.py gpurun_out/r03_c2 profiles/r03/c2 "$W" > /dev/null
-python profiles/summarize_sq.py gpurun_out/r03_c2 profiles/r03/c2 "$W" 200 > /dev/null
+python profiles/summarize_sq.py gpurun_out/r03_c2 profiles/r03/c2 "$W" 28.5714   # 200 levels in 7 launches (6 x 32 + 8) > /dev/null
 cp gpurun_out/r03_c2/bench_stdout.json profiles/r03/c2_bench_stdout.json
 W='{"workload":"c2","order":3,"K":4,"dtype":"f64","fuse_levels":true}'
 python profiles/summarize.py gpurun_out/r03_c2_o3 profiles/r03/c2_o3 "$W" > /dev/null
-python profiles/summarize_sq.py gpurun_out/r03_c2_o3 profiles/r03/c2_o3 "$W" 200 > /dev/null
+python profiles/summarize_sq.py gpurun_out/r03_c2_o3 profiles/r03/c2_o3 "$W" 28.5714 > /dev/null
 cp gpurun_out/r03_c2_o3/bench_stdout.json profiles/r03/c2_o3_bench_stdout.json
 tools/regs.sh > /dev/null
 python tools/isa_hist.py build/isa/regs_tmp.s advect_lds2_kernelILi4ELb1ELi0E --json profiles/r03/isa_hist_advect_lds2_k4_cyclic.json > /dev/null
