@@ -154,3 +154,31 @@ def test_continuation_chunks_and_batches_never_change_a_bit(dtype, order, K, lds
     finally:
         eng.set_level_chunk(-1)
         eng.set_lds_tiles(-1)
+
+
+@settings(max_examples=25 * _SCALE, deadline=None, derandomize=_DERAND, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(ny=st.integers(8, 260), nx=st.integers(8, 300), nt=st.integers(1, 3), seed=st.integers(0, 2 ** 31 - 1),
+       scale=st.sampled_from([1.0, 37.5, 1e-3]))
+def test_float64_cubic_prefilter_matches_scipy_at_any_size(ny, nx, nt, seed, scale):
+    """float64 order-3 pack on random grid sizes (both sweeps below / at / above the 64-node limit of the streaming form,
+    ragged chunks and row blocks) against scipy.ndimage.spline_filter(mode='mirror') itself: a few last bits of the
+    field's scale; pads mirror the coefficients exactly; ext = 2 img[t] - img[t+1] exactly."""
+    from scipy.ndimage import spline_filter
+    eng = _engine()
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal((nt, ny, nx)) * scale
+    v = rng.standard_normal((nt, ny, nx)) * scale
+    lat = np.linspace(-80.0, 80.0, ny)
+    lon = np.linspace(-180.0, 179.0, nx)
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    img = f.cub.cpu().numpy().reshape(nt, ny + 3, nx + 3, 2)
+    tol = 2e-14 * scale * 6.0
+    for t in range(nt):
+        for c, w in ((0, u), (1, v)):
+            ref = spline_filter(w[t], order=3, mode="mirror")
+            assert np.abs(img[t, 1:ny + 1, 1:nx + 1, c] - ref).max() <= tol
+    assert np.array_equal(img[:, 0], img[:, 2]) and np.array_equal(img[:, ny + 1], img[:, ny - 1]) and np.array_equal(img[:, ny + 2], img[:, ny - 2])
+    assert np.array_equal(img[:, :, 0], img[:, :, 2]) and np.array_equal(img[:, :, nx + 1], img[:, :, nx - 1])
+    if nt >= 2:
+        ext = f.ext.cpu().numpy().reshape(nt - 1, ny + 3, nx + 3, 2)
+        assert np.array_equal(ext, 2.0 * img[:-1] - img[1:])
