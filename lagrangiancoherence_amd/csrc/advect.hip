@@ -2192,19 +2192,43 @@ __device__ __forceinline__ void cubic_weights_fast64(double t, double (&w)[4]) {
     w[1] = fma(tt, fma(t, 0.5, -1.0), 2.0 / 3.0);
     w[2] = fma(tt, fma(t, -0.5, 0.5), fma(t, 0.5, 1.0 / 6.0));
 }
-__device__ __forceinline__ d2 cubic_taps_fast64(const d2 *w, size_t rs, const double (&wx)[4], const double (&wy)[4], d2 start) {
+// start + the 16-tap sum of a 4 x 4 window already in registers.  ONE function for the LDS window and for the
+// global-memory window: a lane's result must not depend on which of the two served it.
+__device__ __forceinline__ d2 cubic_apply_fast64(const d2 (&q)[4][4], const double (&wx)[4], const double (&wy)[4], d2 start) {
 #pragma clang fp contract(off)
     d2 acc = start;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const d2 *r = w + (size_t)a * rs;
-        const d2 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-        const double rx = fma(wx[3], q3.x, fma(wx[2], q2.x, fma(wx[1], q1.x, wx[0] * q0.x)));
-        const double ry = fma(wx[3], q3.y, fma(wx[2], q2.y, fma(wx[1], q1.y, wx[0] * q0.y)));
+        const double rx = fma(wx[3], q[a][3].x, fma(wx[2], q[a][2].x, fma(wx[1], q[a][1].x, wx[0] * q[a][0].x)));
+        const double ry = fma(wx[3], q[a][3].y, fma(wx[2], q[a][2].y, fma(wx[1], q[a][1].y, wx[0] * q[a][0].y)));
         acc.x = fma(wy[a], rx, acc.x);
         acc.y = fma(wy[a], ry, acc.y);
     }
     return acc;
+}
+// the window from global memory (row stride rs nodes) ...
+__device__ __forceinline__ d2 cubic_taps_fast64(const d2 *w, size_t rs, const double (&wx)[4], const double (&wy)[4], d2 start) {
+    d2 q[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[a][b] = w[(size_t)a * rs + b];
+    return cubic_apply_fast64(q, wx, wy, start);
+}
+// ... and from an LDS tile (byte address of the window origin; PITCH nodes per row): ds_read_b128 with immediate
+// offsets.  (Through one generic pointer for both, hipcc 7.2 merged the tails of the two branches and read the
+// window's last row with flat_load_dwordx4 -- LDS through the flat path.)
+template <int PITCH>
+__device__ __forceinline__ d2 cubic_taps_lds64(unsigned lds_addr, const double (&wx)[4], const double (&wy)[4], d2 start) {
+    typedef __attribute__((address_space(3))) const d2 lds_d2;
+    lds_d2 *w = (lds_d2 *)(size_t)lds_addr;
+    d2 q[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[a][b] = w[a * PITCH + b];
+    // (all 16 reads forced in flight before the first use -- sched_barrier -- measures the same: 6.49 against 6.45 ms)
+    return cubic_apply_fast64(q, wx, wy, start);
 }
 __device__ __forceinline__ d2 sample_fast64_o3(const double *__restrict__ lvl, const AdvectArgs<double> &A, double x, double y, d2 start) {
     const Loc64 t = locate_fast64(A, x, y);
@@ -2493,7 +2517,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs
         cubic_weights_fast64(t.ty, wy);
         const int rx = t.x0 - ox, ry = t.y0 - oy;
         if (have && (unsigned)rx <= (unsigned)(T64O3 - 4) && (unsigned)ry <= (unsigned)(T64O3 - 4))
-            return cubic_taps_fast64(tile + ry * T64O3_PITCH + rx, (size_t)T64O3_PITCH, wx, wy, start);
+            return cubic_taps_lds64<T64O3_PITCH>(lds_address(tile) + (unsigned)(ry * T64O3_PITCH + rx) * 16u, wx, wy, start);
         return cubic_taps_fast64((const d2 *)level + ((size_t)t.y0 * A.pitch + t.x0), (size_t)A.pitch, wx, wy, start);
     };
     for (int s = 0; s < A.nsteps; ++s) {
