@@ -2147,7 +2147,15 @@ __device__ __forceinline__ Loc64 locate_fast64(const AdvectArgs<double> &A, doub
     double cx = (x - A.lon_min) * A.sx;  // subtract first: exact 0 at the grid origin
     double cy = (y - A.lat_min) * A.sy;
     const double szx = (double)(A.nx_f - 1), szy = (double)(A.ny_f - 1);
-    if (!(cx >= 0.0 && cx <= szx && cy >= 0.0 && cy <= szy)) {  // rare: scipy's 'wrap' map (NaN falls through to the clamp)
+    // scipy's 'wrap' map is discontinuous at the last node (c = n - 1 stays, anything above lands next to node 0), and within
+    // a rounding of it this multiply form and numpy's (n (x - min)) / span (tools.py:21-22) can fall on different sides -- a
+    // seed row that sits exactly on the last node row of a coarser field does.  So the common-case test stops 1e-12 short of
+    // n - 1, and in that band the coordinate IS numpy's expression: the decision and the value are the reference's there, and
+    // the two forms meet at the band's edges to rounding.  (At c = 0 both forms are exact: the subtraction comes first.)
+    const double gx = szx * (1.0 - 1e-12), gy = szy * (1.0 - 1e-12);
+    if (!(cx >= 0.0 && cx < gx && cy >= 0.0 && cy < gy)) {  // rare: the band, or scipy's 'wrap' map (NaN falls through to the clamp)
+        if (cx >= gx && cx <= szx * (1.0 + 1e-12)) cx = ((double)A.nx_f * (x - A.lon_min)) / A.lon_span;
+        if (cy >= gy && cy <= szy * (1.0 + 1e-12)) cy = ((double)A.ny_f * (y - A.lat_min)) / A.lat_span;
         cx = wrap_coord<double>(cx, szx);
         cy = wrap_coord<double>(cy, szy);
     }

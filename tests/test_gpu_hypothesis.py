@@ -48,8 +48,19 @@ def test_float64_advect_and_sigma_match_oracle(ny, nx, nt, K, order, dt, cyclic,
     xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=dt, SETTLS_order=K, interp_order=order,
                                     cyclic_xboundary=cyclic, seed_lat=slat, seed_lon=slon, t0=t0, nsteps=nsteps)
     xg, yg = x.cpu().numpy(), y.cpu().numpy()
-    np.testing.assert_allclose(yg, yr_, rtol=0, atol=1e-9)
-    np.testing.assert_allclose(xg, xr_, rtol=0, atol=1e-9)
+    # 1e-9 degrees -- or, where this white-noise flow amplifies more than that, what the oracle itself makes of seeds moved
+    # by a few ulp of the coordinates (1.4e-14 degrees at 100; measured through a 1e-12 degree shift): the fused-level default
+    # rounds differently from numpy (fuse_levels=False does not: tools/repro_hyp_fp64.py, 6e-14 where this form shows 7e-9
+    # at a point that a 1e-12 degree shift of the seeds moves by 8e-6)
+    xs_, ys_ = O.parcel_propagation(u, v, lat, lon, timestep=dt, SETTLS_order=K, interp_order=order, cyclic_xboundary=cyclic,
+                                    seed_lat=slat + 1e-12, seed_lon=slon + 1e-12, t0=t0, nsteps=nsteps)
+    sx = np.abs(xs_ - xr_)
+    from scipy.ndimage import maximum_filter
+    sens = maximum_filter(np.maximum(np.minimum(sx, np.abs(sx - 360.0)), np.abs(ys_ - yr_)), size=3, mode="nearest") * 0.1   # ~7 ulp
+    dxg = np.abs(xg - xr_)
+    dxg = np.minimum(dxg, np.abs(dxg - 360.0)) if cyclic else dxg
+    assert (np.abs(yg - yr_) <= 1e-9 + sens).all(), float(np.abs(yg - yr_).max())
+    assert (dxg <= 1e-9 + sens).all(), float(dxg.max())
     if slat.size >= 5 and slon.size >= 5:
         # sigma from the ORACLE's departure points on both sides: isolates the gradient/eigen kernel
         ref = O.sigma_max(O.flowmap_gradient(xr_, yr_, slat, slon))

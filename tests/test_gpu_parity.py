@@ -759,6 +759,37 @@ def test_float64_fused_levels_option(eng, O, order):
     assert np.abs(_np(xe) - xo).max() < 1e-12 and np.abs(_np(ye) - yo).max() < 1e-12
 
 
+@pytest.mark.parametrize("order", [1, 3])
+@pytest.mark.parametrize("K", [0, 4])
+def test_float64_fast_form_on_the_last_node_row_decides_the_wrap_as_numpy_does(eng, O, order, K):
+    """scipy's 'wrap' map is discontinuous at the last node (tools.py:21-22 scales by n / span, so c = n - 1 is an ordinary
+    coordinate and anything above lands next to node 0).  A seed row that sits on the last node row of a coarser field has
+    c = n - 1 to rounding: the float64 fast form (index map by multiplication) and numpy's (n (x - min)) / span fell on
+    different sides there (found by the randomised run of tests/test_gpu_hypothesis.py: 0.34 degrees on a whole seed row).
+    Within 1e-12 of n - 1 the fast form now takes numpy's expression: same side, same sample."""
+    rng = np.random.default_rng(6739)
+    lat = np.linspace(-60.0, 60.0, 18)
+    lon = -180 + 360.0 / 23 * np.arange(23)
+    u = 5.0 * rng.standard_normal((3, 18, 23))
+    v = 2.5 * rng.standard_normal((3, 18, 23))
+    slat = np.linspace(lat[0], lat[-1], 19)            # row 17: (53.33.. + 60) * 18 / 120 = 17 = n - 1 to rounding
+    slon = np.linspace(lon[0], lon[-1], 24)            # column 22: c = 22 = n - 1 to rounding
+    cy = 18 * (slat - lat[0]) / (lat[-1] - lat[0])
+    cx = 23 * (slon - lon[0]) / (lon[-1] - lon[0])
+    assert np.abs(cy - 17).min() < 1e-13 and np.abs(cx - 22).min() < 1e-13
+    f = eng.prepare_field(u, v, lat, lon, order)
+    for mode in (-1, 0):
+        try:
+            eng.set_lds_tiles(mode)
+            x, y = eng.advect(f, slat, slon, -5400.0, SETTLS_order=K, interp_order=order)
+        finally:
+            eng.set_lds_tiles(-1)
+        xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-5400.0, SETTLS_order=K, interp_order=order, cyclic_xboundary=True,
+                                      seed_lat=slat, seed_lon=slon)
+        d = np.abs(_np(x) - xo)
+        assert np.minimum(d, np.abs(d - 360)).max() < POS_ATOL64 and np.abs(_np(y) - yo).max() < POS_ATOL64
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_non_finite_and_huge_wind_values_stay_contained(eng, dtype):
     """NaN, +-inf and 1e30 m/s at a few wind nodes: every kernel variant finishes (the rare-case branches
