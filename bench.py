@@ -159,7 +159,7 @@ def cpu_baseline(flows, u, v, lat, lon, dt, K, order, nsteps):
 # N > 1 without an external launcher.  `python bench.py --gpus N` (WORLD_SIZE unset) starts the N ranks itself, as
 # FRESH child processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on
 # 127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank does.  The parent never touches the GPU (no
-# torch import, no HIP call) and never replaces itself with another program; a rank that fails or a run that
+# torch import, no HIP call: it counts the GPUs from /dev, visible_gpu_count) and never replaces itself with another program; a rank that fails or a run that
 # exceeds the wall-clock limit takes the other ranks down with it (by the PIDs started here), so a stuck
 # communicator costs a clear error, not the lease.  Under `python -m torch.distributed.run ...` (WORLD_SIZE set)
 # none of this runs: the process is a rank.
@@ -169,6 +169,23 @@ def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def visible_gpu_count() -> int:
+    """GPUs a child process of this one can open, counted WITHOUT loading torch or the HIP / HSA runtime (on ROCm
+    builds without amdsmi ``torch.cuda.device_count()`` falls through to ``hipGetDeviceCount``, which initialises the
+    runtime and leaves the launcher holding a GPU context for the whole N-rank run): the compute device ``/dev/kfd``
+    plus one accessible render node ``/dev/dri/renderD*`` per GPU (a container is handed the render nodes of the GPUs
+    it may use), capped by the ``*_VISIBLE_DEVICES`` lists a rank would honour."""
+    import glob
+    if not os.access("/dev/kfd", os.R_OK | os.W_OK):
+        return 0
+    n = sum(1 for d in glob.glob("/dev/dri/renderD*") if os.access(d, os.R_OK | os.W_OK))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
 
 
 def spawn_ranks(n: int, child_argv, timeout_s: float, extra_env=None, out=None, err=None) -> int:
@@ -349,8 +366,7 @@ def main():
         if args.workload == "c2":
             raise SystemExit("--workload c2 is a one-GPU configuration")
         if not os.environ.get("LCS_BENCH_ONE_GPU"):
-            import torch                                   # device_count() does not initialise the GPU
-            have = torch.cuda.device_count()
+            have = visible_gpu_count()                     # from /dev: no torch import, no HIP / HSA runtime in the parent
             if have < args.gpus:
                 raise SystemExit(f"--gpus {args.gpus}: this machine shows {have} GPU(s) (one rank per GPU; "
                                  "LCS_BENCH_BACKEND=gloo LCS_BENCH_ONE_GPU=1 rehearses the N>1 path on one)")
@@ -677,7 +693,9 @@ def main():
         "kernel_ms": ms,
         "roofline": {**roofline(advect_kernel, "valu" if "lds" in advect_kernel else "tcp", pts_launch, adv_ms, K, order,
                                 s_p, s_f, True, comp, wl, csrc,
-                                -(-nsteps // ens_chunk) if level_major else eng.last_advect_launches()),
+                                # level-major: the launches the ensemble call made (the member-pair path walks
+                                # nsteps + stride levels; the per-member fallback makes one launch per chunk and call)
+                                max(eng.last_advect_launches(), -(-nsteps // ens_chunk)) if level_major else eng.last_advect_launches()),
                      "measured_copy_peak_GBps": copy_gbps},
         "roofline_sigma": {
             "bound": "hbm", "kernel": eng.last_sigma_kernel(), "achieved": sigma_gbps, "peak": HBM_PEAK_GBPS,

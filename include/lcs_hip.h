@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define LC_VERSION 100 /* 0.1.0 */
+/* 101: lc_spectral_truncate gained `gridtype`, lc_fourth_order_derivative gained `isglobal` (arguments inserted: a
+ * client built against 100 must be rebuilt), lc_ctx_get_level_chunk and lc_ctx_set/get_f64_fidelity added.  lc_version() returns the value the LIBRARY
+ * was built with: compare it with this macro before any other call (tests/c/abi_smoke.c, _capi.load do). */
+#define LC_VERSION 101 /* 0.1.1 */
 
 typedef struct lc_ctx lc_ctx;
 
@@ -130,6 +133,27 @@ int lc_ctx_set_flag_allreduce(lc_ctx *ctx, lc_flag_allreduce_fn fn, void *user);
  * The environment variable LCS_LEVEL_CHUNK sets the initial value, read ONCE in lc_ctx_create.  No reference
  * counterpart (the reference's loop over time levels is LCS/trajectory.py:80-126). */
 int lc_ctx_set_level_chunk(lc_ctx *ctx, int levels);
+/* The value in force (what lc_ctx_set_level_chunk was last given, or what LCS_LEVEL_CHUNK set at creation): a caller
+ * that changes it for one call restores THIS, not a guess. */
+int lc_ctx_get_level_chunk(const lc_ctx *ctx, int *levels_out);
+/* float64 on the ONE-CALL host routes (lc_lcs_host, lc_lcs_global_host -- what a reference-side binding calls, where a
+ * user expects the reference's numbers): which form of the SETTLS iteration they take.
+ *   LC_F64_EXACT_ORDER  numpy / scipy's operation order (two samples per iteration, true divisions, scipy's tap sums;
+ *                       LCS/trajectory.py:86-87,110-112): ~1e-13 degrees from the reference's float64 result;
+ *   LC_F64_FAST         one sample of the fused-level image 2F[t]-F[t+1] per iteration, multiplied index map, fused
+ *                       lerps: the same mathematics with different ROUNDING, 1.4-2x faster at BASELINE config 2's size;
+ *                       distance from the reference <= 1e-9 degrees, or the flow's own amplification of a 1e-12 degree
+ *                       seed shift if that is larger (ill-conditioned flows; INTEGRATION.md "Behavioural notes");
+ *   LC_F64_AUTO         (default) exact order up to LC_EXACT_ORDER_MAX_SEEDS seeds per call -- there the time is launch
+ *                       latency, not arithmetic: the reference's example (89 x 180) and the 360 x 721 common grid of
+ *                       isglobal=True are on this side -- and the fast form above.
+ * float32 always takes the fused form (it cannot be bit-comparable with scipy's float64 interpolation anyway).
+ * lc_advect itself is explicit: packed_ext == NULL is the exact order.  LCS_F64_FIDELITY (auto / exact / fast) sets the
+ * initial value, read ONCE in lc_ctx_create. */
+enum lc_f64_fidelity { LC_F64_AUTO = 0, LC_F64_EXACT_ORDER = 1, LC_F64_FAST = 2 };
+#define LC_EXACT_ORDER_MAX_SEEDS (1 << 18)
+int lc_ctx_set_f64_fidelity(lc_ctx *ctx, int mode);
+int lc_ctx_get_f64_fidelity(const lc_ctx *ctx, int *mode_out);
 /* Name of the kernel the context's last lc_advect call launched (static string, "" before the first call);
  * what a profiler shows, so a benchmark labels its numbers with the kernel that actually ran. */
 const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx);

@@ -11,11 +11,14 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblcs_hip.so")
 
+LC_VERSION = 101     # include/lcs_hip.h: the ABI these prototypes describe (checked against lc_version() in load())
 LC_F32, LC_F64, LC_F64_WIND_F32 = 0, 1, 2
 LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM, LC_ERCCL = 0, -1, -2, -3, -4, -5
 LC_LAYOUT_REFERENCE, LC_LAYOUT_PHYSICAL = 0, 1
 LC_X_CLAMP_POINT, LC_X_CYCLIC, LC_X_CLAMP_REFERENCE_OUTER = 0, 1, 2
 LC_GRID_REGULAR, LC_GRID_GAUSSIAN = 0, 1
+LC_F64_AUTO, LC_F64_EXACT_ORDER, LC_F64_FAST = 0, 1, 2
+LC_EXACT_ORDER_MAX_SEEDS = 1 << 18
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 
@@ -32,6 +35,9 @@ PROTOTYPES = {
     "lc_ctx_set_lds_tiles": (_i, [_vp, _i]),
     "lc_ctx_set_sigma_march": (_i, [_vp, _i]),
     "lc_ctx_set_level_chunk": (_i, [_vp, _i]),
+    "lc_ctx_get_level_chunk": (_i, [_vp, C.POINTER(_i)]),
+    "lc_ctx_set_f64_fidelity": (_i, [_vp, _i]),
+    "lc_ctx_get_f64_fidelity": (_i, [_vp, C.POINTER(_i)]),
     "lc_ctx_set_flag_allreduce": (_i, [_vp, _vp, _vp]),
     "lc_ctx_last_advect_kernel": (C.c_char_p, [_vp]),
     "lc_ctx_last_advect_launches": (_i, [_vp]),
@@ -102,6 +108,9 @@ def load(path: str | None = None):
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.lc_version() != LC_VERSION:   # an argument list changed between ABI versions: never call across them
+        raise RuntimeError(f"{p} is ABI version {lib.lc_version()}, these bindings are for {LC_VERSION}: rebuild it with "
+                           "`python -m lagrangiancoherence_amd.build --force`")
     if path is None:
         _lib = lib
     return lib

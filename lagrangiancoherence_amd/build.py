@@ -75,16 +75,46 @@ def needs_build() -> bool:
 
 def build_library(force: bool = False, verbose: bool = True, extra_flags=(), out: str | None = None) -> str:
     """``out``/``extra_flags``: experiment variants (e.g. ``-DLCS_LDS_READ2``) built beside the product
-    library and selected at run time with ``LCS_LIB=<path>`` (see ``_capi.load``)."""
+    library and selected at run time with ``LCS_LIB=<path>`` (see ``_capi.load``).
+
+    Every translation unit is compiled to its own object (in parallel, cached under ``build/obj/<flags>/`` by the
+    modification times of the source and the shared headers), then linked: editing one kernel file recompiles that
+    file only."""
     if out is None and not force and not needs_build():
         return LIB
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     # the library carries the hash of the sources it was built from and the experiment flags it was built with
     # (lc_build_id()): a benchmark ties replayed counters to the BINARY that ran, not to the working tree
     build_id = csrc_hash() + ("" if not extra_flags else "+" + " ".join(sorted(extra_flags)))
-    cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", *extra_flags,
-           f'-DLCS_BUILD_ID="{build_id}"',
-           "-o", out or LIB, *[os.path.join(CSRC, s) for s in SOURCES], "-ldl"]
+    common = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fno-gpu-rdc", "-Wall",
+              "-Wno-unused-function", "-Wno-pass-failed", *extra_flags]
+    objdir = os.path.join(os.path.dirname(HERE), "build", "obj",
+                          hashlib.sha256(" ".join(common).encode()).hexdigest()[:12])
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "lcs_hip.h"))
+    hdr_t = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(src):
+        path, obj = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
+        # api.hip holds lc_build_id(): its object depends on the id
+        stamp = [f'-DLCS_BUILD_ID="{build_id}"'] if src == "api.hip" else []
+        tag = obj + ".id"
+        fresh = (not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t)
+                 and (not stamp or (os.path.exists(tag) and open(tag).read() == build_id)))
+        if fresh:
+            return obj
+        cmd = [*common, *stamp, "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        if stamp:
+            open(tag, "w").write(build_id)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out or LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -21,6 +21,7 @@
 // always in range and its (u,v) pairs are contiguous along x, so one sample
 // position costs 2 (order 1, float) wide loads per level instead of 8 scalars.
 #include "lcs_common.h"
+#include "launch_plan.h"
 
 namespace {
 
@@ -77,13 +78,10 @@ struct AdvectArgs {
 // xcd_chunk = 0: XCD x takes the x-th contiguous eighth of the tiles (neighbouring tiles share an L2).
 // xcd_chunk = C: chunks of C tiles (whole tile rows) go to the XCDs cyclically, so every XCD sees every latitude
 // band and they finish together even when the bands cost differently (redo rate, pole rows).
+// (the arithmetic is lcplan::tile_of_block, launch_plan.h: unit-tested on the CPU as a bijection blocks <-> tiles)
 template <typename T>
 __device__ __forceinline__ int xcd_tile_id(const AdvectArgs<T> &A) {
-    const int b = (int)blockIdx.x - A.pole_blocks;  // pole_blocks is a multiple of 8: b % 8 is still the XCD
-    const int xcd = b % 8, j = b / 8;
-    if (A.xcd_chunk <= 0) return xcd * ((A.ntiles + 7) / 8) + j;
-    const int cj = j / A.xcd_chunk, r = j - cj * A.xcd_chunk;
-    const int d = (cj * 8 + xcd) * A.xcd_chunk + r;  // position in dispatch order
+    // pole_blocks is a multiple of 8: (blockIdx.x - pole_blocks) % 8 is still the XCD
     // Order of the tile rows.  Next to a pole 1 / cos(lat) makes a time step many cells long, the windows leave
     // their tiles at every sample and those workgroups live several times longer than the others: started last they
     // are the launch's tail, started first they hide behind it.  1: the last row first, then 0, 1, 2, ... (default:
@@ -91,20 +89,11 @@ __device__ __forceinline__ int xcd_tile_id(const AdvectArgs<T> &A) {
     // last-1, 1, ...: the launch ends on the equatorial rows, whose patches stay coherent longest) -- the two-seed
     // order-1 kernel's default (C3 6.68 -> 6.40 ms like 1, but C5 426 -> 419 where 1 gives 440; order 3 17.54 and
     // float64 C2 +5 % with it, so not for them); 0: as stored.
-    if (A.tile_order && d < A.ntiles) {
-        const int dr = d / A.ntx, c = d - dr * A.ntx, nty = A.ntiles / A.ntx;
-        const int row = A.tile_order == 2 ? ((dr & 1) ? (dr >> 1) : nty - 1 - (dr >> 1)) : (dr == 0 ? nty - 1 : dr - 1);
-        return row * A.ntx + c;
-    }
-    return d;
+    return lcplan::tile_of_block((int)blockIdx.x - A.pole_blocks, A.ntiles, A.ntx, A.xcd_chunk, A.tile_order);
 }
 template <typename T>
 static inline unsigned nmem(const AdvectArgs<T> &A) { return A.n_members > 1 ? (unsigned)A.n_members : 1u; }  // grid.y of an advect launch
-static inline int xcd_grid(int ntiles, int chunk) {
-    if (chunk <= 0) return ((ntiles + 7) / 8) * 8;
-    const int nch = (ntiles + chunk - 1) / chunk;
-    return ((nch + 7) / 8) * 8 * chunk;
-}
+static inline int xcd_grid(int ntiles, int chunk) { return lcplan::xcd_grid(ntiles, chunk); }
 
 template <typename T>
 struct Pair {
@@ -502,7 +491,7 @@ __device__ __forceinline__ bool pole_block(const AdvectArgs<T> &A) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < (A.pole_lo + A.pole_hi) * A.nx) {
         const int k = i / A.nx, ix = i - k * A.nx;
-        const int iy = k < A.pole_lo ? k : A.ny - A.pole_hi + (k - A.pole_lo);
+        const int iy = lcplan::pole_row(k, A.pole_lo, A.pole_hi, A.ny);
         advect_seed<T, 1, false>(A, A.lin, iy, ix);
     }
     return true;
@@ -513,10 +502,9 @@ __device__ __forceinline__ bool pole_block(const AdvectArgs<T> &A) {
 template <typename T>
 __device__ __forceinline__ AdvectArgs<T> group_member(const AdvectArgs<T> &A, int q) {
     AdvectArgs<T> M = A;
-    const int l0 = A.pair_l0, l1 = A.pair_l0 + A.nsteps;
-    const int lo = max(l0, q * A.pair_d), hi = min(l1, A.pair_n + q * A.pair_d);
-    M.t0 = A.t0 + (lo - l0);
-    M.nsteps = max(hi - lo, 0);
+    const lcplan::Window w = lcplan::member_window(q, A.pair_l0, A.nsteps, A.pair_n, A.pair_d);
+    M.t0 = A.t0 + (w.lo - A.pair_l0);
+    M.nsteps = max(w.hi - w.lo, 0);
     const size_t off = (size_t)q * A.pair_plane;
     M.x_out = A.x_out + off;
     M.y_out = A.y_out + off;
@@ -1428,7 +1416,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     const f2 zero = {0.0f, 0.0f};
     f2 dprev = {0.0f, 0.0f};
     // member groups: level iterations of this workgroup (a short last group stops with its last member's steps)
-    const int nlev = GROUP ? min(A.nsteps, max(A.pair_n + (cnt - 1) * A.pair_d - A.pair_l0, 0)) : A.nsteps;
+    const int nlev = GROUP ? lcplan::group_levels(A.nsteps, A.pair_l0, A.pair_n, A.pair_d, cnt) : A.nsteps;
 #ifdef LCS_STAMPS
     long long acc_t[5] = {0, 0, 0, 0, 0}, last_t = __builtin_amdgcn_s_memtime();
     unsigned long long acc_n[3] = {0, 0, 0};
@@ -1446,8 +1434,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
             int qlo = NS, qhi = 0;
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                const int l = A.pair_l0 + s - q * A.pair_d;
-                act[q] = l >= 0 && l < A.pair_n && q < cnt;
+                act[q] = lcplan::member_steps(q, s, A.pair_l0, A.pair_n, A.pair_d) && q < cnt;
                 keep[q] = p[q];
                 if (act[q]) {
                     qlo = min(qlo, q);
@@ -2967,12 +2954,10 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.tile_order = ctx->tile_order >= 0 ? ctx->tile_order : 1;
     A.tile_order_two_seed = ctx->tile_order >= 0 ? ctx->tile_order : 2;
     {   // leading workgroups for the global pole rows present in this block of seed rows
-        const int lo = min(max(A.order - A.row0, 0), ny), hi = min(max(A.row0 + ny - (A.ny_global - A.order), 0), ny);
-        const long long npole = (long long)(lo + hi) * nx;
-        const bool on = ctx->pole_blocks && lo + hi <= ny && npole > 0 && npole < (1ll << 30);
-        A.pole_lo = on ? lo : 0;
-        A.pole_hi = on ? hi : 0;
-        A.pole_blocks = on ? (int)(((npole + BLOCK - 1) / BLOCK + 7) / 8 * 8) : 0;
+        const lcplan::PoleRows pr = lcplan::pole_rows(A.order, A.row0, ny, A.ny_global, nx, ctx->pole_blocks != 0, BLOCK);
+        A.pole_lo = pr.lo;
+        A.pole_hi = pr.hi;
+        A.pole_blocks = pr.blocks;
     }
     const int grid = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
     // Kernel choice (float + fused levels only; measured on MI355X, 4096^2 seeds, 96 steps, K=4, 8x8-seed waves):
@@ -3026,39 +3011,37 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // By SETTLS_order too (a level costs 1 + K samples; 200 steps on C3): K = 4 chunks of 32 13.9 ms against 15.0 in one
     // launch, K = 2 chunks of 64 9.66 against 9.86 (32) / 9.91 (one launch), K = 1 one launch 7.21 against 7.59 (32),
     // K = 0 one launch 4.77 against 5.41 (32): the lighter the level, the less a launch's spread over the levels costs.
-    const int chunk_for_k = K >= 3 ? 32 : (K == 2 ? 64 : 0);
+    // (lcplan::chunk_for_k)
     // From 2^18 seeds per call (measured, chunks of 32 against one launch, 96 levels of the 720 x 1440 float32 series unless
     // noted: 512^2 seeds 1.256 -> 1.23 ms, 724^2 1.25 -> 1.05, 1024^2 1.43 -> 1.37, 1024^2 x 200 levels 3.16 -> 2.89, order 3
     // 3.27 -> 3.15, 2048^2 2.67 -> 2.60; float64 config 2, 1024^2 x 200: order 1 3.30 -> 3.06, order 3 7.66 -> 6.97 with 25-32
     // levels, 8 / 16 / 50 / 100 within 2-5 % of that).
-    const long long chunk_from = 1ll << 18;
-    const int auto_chunk = (long long)ny * nx * (n_members > 1 ? n_members : 1) >= chunk_from ? chunk_for_k : 0;
-    const int want_chunk = ctx->level_chunk < 0 ? auto_chunk : ctx->level_chunk;
-    // LC_X_CLAMP_REFERENCE_OUTER: chunks of 16 levels whatever the size, the clamp flag read back after each, the
-    // positions before each chunk kept -- so the sub-step path restarts at the chunk in which a parcel first left the
-    // box instead of at t0 (regional domains: parcels leave routinely; the fused work thrown away is one chunk)
-    const int chunk_asked = outer ? (want_chunk > 0 ? want_chunk : 16) : (want_chunk > 0 ? want_chunk : (nsteps > 0 ? nsteps : 1));
+    // (lcplan::CHUNK_FROM_SEEDS)
+    // LC_X_CLAMP_REFERENCE_OUTER: chunks of 16 levels WHATEVER the size (lcplan::OUTER_CHUNK), the clamp flag read back after
+    // each, the positions before each chunk kept -- so the sub-step path restarts at the chunk in which a parcel first left
+    // the box instead of at t0 (regional domains: parcels leave routinely; the fused work thrown away is one chunk).  The
+    // value must not depend on the local block: each chunk ends in one flag all-reduce over the ranks of a row-sharded
+    // grid, whose blocks differ in size (a by-size rule sent ranks on either side of 2^18 seeds into different numbers
+    // of collectives).
     const size_t plane_elems = (size_t)ny * nx;
     // An ensemble through the float32 two-seed order-1 kernel: consecutive MEMBERS share a lane (PATCH_PAIR).
     // Launches walk the group's level window [0, nsteps + (g - 1) d): member q steps at levels [q d, q d + nsteps)
     // (d = t0_stride), so the group shares its tiles for nsteps - (g - 1) d of them; continuation in place as for any chunk.
-    int group = 0;  // members per lane: 0 (no groups) or 2
-    if (n_members > 1 && order == 1 && !outer && !traj_x && use_lds && (ctx->patch_mode < 0 || ctx->patch_mode == PATCH_PAIR) &&
-        order1_two_seed_applies(A, ctx->lds_tiles)) {
-        // (four members per lane -- 99 VGPRs, the members of a lane up to 3 d levels of travel apart -- measured 480 ms on
-        // config 5 against 280 for pairs: in the jets three steps are 6 cells, nearly every wave-sample has a lane outside the tile)
-        group = nsteps > t0_stride ? 2 : 0;
-    }
-    const int total = group ? nsteps + (group - 1) * t0_stride : nsteps;
-    if (group) {
+    // (four members per lane -- 99 VGPRs, the members of a lane up to 3 d levels of travel apart -- measured 480 ms on
+    // config 5 against 280 for pairs: in the jets three steps are 6 cells, nearly every wave-sample has a lane outside the tile)
+    const bool pairs_ok = n_members > 1 && order == 1 && !outer && !traj_x && use_lds &&
+                          (ctx->patch_mode < 0 || ctx->patch_mode == PATCH_PAIR) && order1_two_seed_applies(A, ctx->lds_tiles);
+    const lcplan::Groups G = lcplan::member_groups(n_members, t0_stride, nsteps, pairs_ok);
+    const int total = G.total;
+    if (G.g) {
         A.pair_d = t0_stride;
         A.pair_n = nsteps;
         A.pair_plane = plane_elems;
-        A.pair_g = group;
-        A.pair_last = n_members % group ? n_members % group : group;
-        A.n_members = (n_members + group - 1) / group;
-        A.member_t0_stride = group * t0_stride;
-        A.member_plane = (size_t)group * plane_elems;
+        A.pair_g = G.g;
+        A.pair_last = G.last;
+        A.n_members = G.n_groups;
+        A.member_t0_stride = G.group_stride;
+        A.member_plane = (size_t)G.g * plane_elems;
     }
     int n_launches = 0;
     T *saved = nullptr;   // [2][ny*nx]: positions at the start of the current chunk (outer mode, from the second chunk on)
@@ -3067,11 +3050,12 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         lc_set_error("lc_advect: the flag all-reduce of LC_X_CLAMP_REFERENCE_OUTER failed (lc_ctx_set_flag_allreduce callback returned non-zero)");
         return LC_ERCCL;
     };
-    const int chunk = (!outer && want_chunk <= 0) ? (total > 0 ? total : 1) : chunk_asked;
-    for (int s0 = 0; s0 == 0 || s0 < total; s0 += chunk) {
+    const int chunk = lcplan::level_chunk(ctx->level_chunk, outer, (long long)ny * nx, n_members, K, total);
+    for (int ci = 0, nci = lcplan::n_chunks(total, chunk); ci < nci; ++ci) {
+        const int s0 = lcplan::chunk_first(ci, chunk);
         AdvectArgs<T> C = A;
         C.t0 = t0 + s0;
-        C.nsteps = total - s0 < chunk ? total - s0 : chunk;
+        C.nsteps = lcplan::chunk_levels(ci, total, chunk);
         C.pair_l0 = s0;
         if (s0 > 0) {
             C.x_start = A.x_out;
@@ -3105,7 +3089,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 LC_HIP_CHECK(e1);
             }
             if (moved) {
-                restart = (s0 > 0 && !saved) ? 0 : s0;   // (no room for the saved positions: from the seed grid, as before)
+                restart = lcplan::outer_restart(s0, saved != nullptr);   // (no room for the saved positions: from the seed grid, as before)
                 break;
             }
         }

@@ -58,6 +58,8 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     if (const char *ev = getenv("LCS_SIGMA_MARCH")) c->sigma_march = ev[0] == '0' ? 0 : (ev[0] == '1' ? 1 : 2);  // read once, here
     c->level_chunk = -1;  // by size (advect.hip: 32 levels per launch from 2^22 seeds per call)
     if (const char *ev = getenv("LCS_LEVEL_CHUNK")) c->level_chunk = atoi(ev) >= 0 ? atoi(ev) : -1;  // read once, here
+    c->f64_fidelity = LC_F64_AUTO;
+    if (const char *ev = getenv("LCS_F64_FIDELITY")) c->f64_fidelity = ev[0] == 'e' ? LC_F64_EXACT_ORDER : (ev[0] == 'f' ? LC_F64_FAST : LC_F64_AUTO);  // read once, here
     c->patch_mode = -1;
     if (const char *ev = getenv("LCS_PATCH_MODE")) c->patch_mode = (ev[0] >= '0' && ev[0] <= '3') ? ev[0] - '0' : -1;  // read once, here
     c->flag_reduce = nullptr;
@@ -90,6 +92,32 @@ extern "C" int lc_ctx_set_flag_allreduce(lc_ctx *ctx, lc_flag_allreduce_fn fn, v
     LC_REQUIRE(ctx, "lc_ctx_set_flag_allreduce: null context");
     ctx->flag_reduce = fn;
     ctx->flag_reduce_user = user;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_set_f64_fidelity(lc_ctx *ctx, int mode) {
+    LC_REQUIRE(ctx, "lc_ctx_set_f64_fidelity: null context");
+    LC_REQUIRE(mode >= LC_F64_AUTO && mode <= LC_F64_FAST, "lc_ctx_set_f64_fidelity: mode %d (LC_F64_AUTO / LC_F64_EXACT_ORDER / LC_F64_FAST)", mode);
+    ctx->f64_fidelity = mode;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_get_f64_fidelity(const lc_ctx *ctx, int *mode_out) {
+    LC_REQUIRE(ctx && mode_out, "lc_ctx_get_f64_fidelity: null pointer");
+    *mode_out = ctx->f64_fidelity;
+    return LC_OK;
+}
+
+// float64 on the one-call host routes: the reference's operation order (no fused-level image) or the fast form
+static bool f64_exact_order(const lc_ctx *ctx, int dtype, int ny, int nx) {
+    if (dtype != LC_F64) return false;
+    return ctx->f64_fidelity == LC_F64_EXACT_ORDER ||
+           (ctx->f64_fidelity == LC_F64_AUTO && (long long)ny * nx <= LC_EXACT_ORDER_MAX_SEEDS);
+}
+
+extern "C" int lc_ctx_get_level_chunk(const lc_ctx *ctx, int *levels_out) {
+    LC_REQUIRE(ctx && levels_out, "lc_ctx_get_level_chunk: null pointer");
+    *levels_out = ctx->level_chunk;
     return LC_OK;
 }
 
@@ -379,8 +407,9 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     LC_HIP_CHECK(hipMemcpyAsync(v.p, v_host, fbytes, hipMemcpyHostToDevice, st));
     LC_HIP_CHECK(hipMemcpyAsync(slat.p, seed_lat_host, ny * es, hipMemcpyHostToDevice, st));
     LC_HIP_CHECK(hipMemcpyAsync(slon.p, seed_lon_host, nx * es, hipMemcpyHostToDevice, st));
-    // one combined sample per SETTLS iteration (ext image of the matching order), float32 and float64 alike
-    const bool fusable = interp_order == 1 || interp_order == 3;
+    // one combined sample per SETTLS iteration (ext image of the matching order) in float32, and in float64 beyond the
+    // size / setting where the reference's own operation order is kept (lc_ctx_set_f64_fidelity)
+    const bool fusable = (interp_order == 1 || interp_order == 3) && !f64_exact_order(ctx, dtype, ny, nx);
     if (settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
     LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
     if (interp_order != 1) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, interp_order, cub.p, ext.p));
@@ -505,7 +534,7 @@ extern "C" int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v
     const size_t pbytes = lc_packed_elems(nt, ny, nx) * es;
     LC_TRY(lin.alloc(pbytes));
     if (interp_order != 1) LC_TRY(cub.alloc(pbytes));
-    const bool fusable = interp_order == 1 || interp_order == 3;
+    const bool fusable = (interp_order == 1 || interp_order == 3) && !f64_exact_order(ctx, wdtype, ny, nx);
     if (settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny, nx) * es));
     LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
     if (interp_order != 1) LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, interp_order, cub.p, ext.p));

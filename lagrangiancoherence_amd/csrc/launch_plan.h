@@ -1,0 +1,155 @@
+// Launch bookkeeping of lc_advect as pure functions: no HIP call, no pointer, no context -- integers in, integers out.
+// advect.hip's host launcher (advect_impl) and its kernels (tile order, member windows) call these; the CPU suite compiles
+// the same header with g++ -fsanitize=address,undefined and checks the invariants the kernels rely on
+// (tests/c/launch_plan_test.cpp, tests/test_launch_plan.py).  No reference counterpart: the reference's loop over time
+// levels (LCS/trajectory.py:80-126) is one Python loop over whole arrays; this is how that loop is cut into launches.
+#pragma once
+#include <cstddef>
+
+#if defined(__HIPCC__)
+#define LCP_HD __host__ __device__ __forceinline__
+#else
+#define LCP_HD inline
+#endif
+
+namespace lcplan {
+
+constexpr int XCDS = 8;  // MI355X: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD has its own L2
+
+LCP_HD int imin(int a, int b) { return a < b ? a : b; }
+LCP_HD int imax(int a, int b) { return a > b ? a : b; }
+
+// ---- XCD-aware block -> tile map --------------------------------------------------------------------------------------
+// Blocks of a launch beyond the leading pole blocks: b = blockIdx.x - pole_blocks (pole_blocks is a multiple of 8, so
+// b % 8 is still the XCD).  xcd_chunk = 0: XCD x takes the x-th contiguous eighth of the tiles.  xcd_chunk = C: chunks of
+// C tiles (whole tile rows) go to the XCDs cyclically.  Returns the tile a block works on; a value >= ntiles means the
+// block has no tile (the grid is rounded up).
+// tile_order: 0 as stored; 1 the last tile row first, then 0, 1, 2, ...; 2 from the poles inwards (last, 0, last-1, 1, ...).
+LCP_HD int tile_of_block(int b, int ntiles, int ntx, int xcd_chunk, int tile_order) {
+    const int xcd = b % XCDS, j = b / XCDS;
+    if (xcd_chunk <= 0) return xcd * ((ntiles + XCDS - 1) / XCDS) + j;
+    const int cj = j / xcd_chunk, r = j - cj * xcd_chunk;
+    const int d = (cj * XCDS + xcd) * xcd_chunk + r;  // position in dispatch order
+    if (tile_order && d < ntiles) {
+        const int dr = d / ntx, c = d - dr * ntx, nty = ntiles / ntx;
+        const int row = tile_order == 2 ? ((dr & 1) ? (dr >> 1) : nty - 1 - (dr >> 1)) : (dr == 0 ? nty - 1 : dr - 1);
+        return row * ntx + c;
+    }
+    return d;
+}
+// Blocks to launch so that every tile has one (excluding the pole blocks).
+LCP_HD int xcd_grid(int ntiles, int xcd_chunk) {
+    if (xcd_chunk <= 0) return ((ntiles + XCDS - 1) / XCDS) * XCDS;
+    const int nch = (ntiles + xcd_chunk - 1) / xcd_chunk;
+    return ((nch + XCDS - 1) / XCDS) * XCDS * xcd_chunk;
+}
+
+// ---- pole rows -----------------------------------------------------------------------------------------------------------
+// The first / last `order` GLOBAL seed rows take order 1 + 'constant' (LCS/tools.py:24-39, Q3).  Of the local block
+// [row0, row0 + ny): lo of them at its start, hi at its end; `blocks` leading workgroups (a multiple of 8, `block` seeds
+// each) take them one seed per thread; 0 blocks = the tiles do.
+struct PoleRows {
+    int lo, hi, blocks;
+};
+LCP_HD PoleRows pole_rows(int order, int row0, int ny, int ny_global, int nx, bool enabled, int block) {
+    const int lo = imin(imax(order - row0, 0), ny), hi = imin(imax(row0 + ny - (ny_global - order), 0), ny);
+    const long long npole = (long long)(lo + hi) * nx;
+    const bool on = enabled && lo + hi <= ny && npole > 0 && npole < (1ll << 30);
+    PoleRows p;
+    p.lo = on ? lo : 0;
+    p.hi = on ? hi : 0;
+    p.blocks = on ? (int)(((npole + block - 1) / block + XCDS - 1) / XCDS * XCDS) : 0;
+    return p;
+}
+// Local row of the k-th pole seed row (k < lo + hi).
+LCP_HD int pole_row(int k, int lo, int hi, int ny) { return k < lo ? k : ny - hi + (k - lo); }
+
+// ---- level chunks ---------------------------------------------------------------------------------------------------------
+// A series of `total` levels runs as consecutive launches of at most `chunk` levels (lc_ctx_set_level_chunk).
+// By SETTLS_order: 32 levels per launch for K >= 3, 64 for K = 2, one launch for K <= 1 (profiles/r03).
+LCP_HD int chunk_for_k(int K) { return K >= 3 ? 32 : (K == 2 ? 64 : 0); }
+constexpr long long CHUNK_FROM_SEEDS = 1ll << 18;  // seeds per call from which the default chunks (measured)
+constexpr int OUTER_CHUNK = 16;                    // LC_X_CLAMP_REFERENCE_OUTER: levels between two reads of the clamp flag
+
+// Levels per launch.  ctx_level_chunk: -1 by size (default), 0 one launch, n > 0 at most n levels.
+// `outer` (LC_X_CLAMP_REFERENCE_OUTER): every chunk ends with one flag all-reduce over the ranks of a row-sharded grid, so
+// the value MUST NOT depend on the local block (seeds_local differs between ranks whose row counts differ by one, or
+// by the halo rows they advect redundantly): fixed 16 levels unless the caller set a value (which it sets on every rank).
+// It also makes the fused-prefix / exact-suffix split of a sharded run the split of the unsharded run (float32 results
+// stay bit-identical).
+LCP_HD int level_chunk(int ctx_level_chunk, bool outer, long long seeds_local, int n_members, int K, int total) {
+    const int all = total > 0 ? total : 1;
+    if (outer) return ctx_level_chunk > 0 ? ctx_level_chunk : OUTER_CHUNK;
+    int want = ctx_level_chunk;
+    if (want < 0) want = seeds_local * (n_members > 1 ? n_members : 1) >= CHUNK_FROM_SEEDS ? chunk_for_k(K) : 0;
+    return want > 0 ? want : all;
+}
+// Number of launches and the i-th launch's first level / level count.  A call with total = 0 still makes one (empty)
+// launch: it stores the start positions.
+LCP_HD int n_chunks(int total, int chunk) { return total <= 0 ? 1 : (total + chunk - 1) / chunk; }
+LCP_HD int chunk_first(int i, int chunk) { return i * chunk; }
+LCP_HD int chunk_levels(int i, int total, int chunk) {
+    const int left = total - i * chunk;
+    return left < chunk ? imax(left, 0) : chunk;
+}
+
+// ---- member groups (lc_advect_batch, two members per lane) ---------------------------------------------------------------
+// Members 2p and 2p+1 share a lane.  A group's LEVEL window is [0, nsteps + (g - 1) d): member q of the group steps at the
+// window levels [q d, q d + nsteps) (d = t0_stride).  Grouping only pays (and is only correct as implemented) when the
+// members overlap in time: nsteps > d.
+struct Groups {
+    int g;            // members per lane: 0 = no groups, else 2
+    int total;        // levels the launches walk
+    int n_groups;     // grid.y
+    int last;         // members of the last group (1 .. g)
+    int group_stride; // start-level distance of consecutive groups
+};
+LCP_HD Groups member_groups(int n_members, int t0_stride, int nsteps, bool eligible) {
+    Groups G;
+    G.g = (eligible && n_members > 1 && nsteps > t0_stride) ? 2 : 0;
+    G.total = G.g ? nsteps + (G.g - 1) * t0_stride : nsteps;
+    G.n_groups = G.g ? (n_members + G.g - 1) / G.g : n_members;
+    G.last = G.g ? (n_members % G.g ? n_members % G.g : G.g) : 1;
+    G.group_stride = G.g ? G.g * t0_stride : t0_stride;
+    return G;
+}
+// Window levels [lo, hi) of member q's own steps inside a launch that covers the window levels [l0, l0 + n) (pair_n =
+// the member's step count, d = t0_stride); empty when hi <= lo.
+struct Window {
+    int lo, hi;
+};
+LCP_HD Window member_window(int q, int l0, int n, int pair_n, int d) {
+    Window w;
+    w.lo = imax(l0, q * d);
+    w.hi = imin(l0 + n, pair_n + q * d);
+    return w;
+}
+// Does member q take a step at level s of a launch that starts at window level l0?
+LCP_HD bool member_steps(int q, int s, int l0, int pair_n, int d) {
+    const int l = l0 + s - q * d;
+    return l >= 0 && l < pair_n;
+}
+// Levels of a launch in which ANY of the group's cnt members still steps (the kernel's loop count).
+LCP_HD int group_levels(int n, int l0, int pair_n, int d, int cnt) { return imin(n, imax(pair_n + (cnt - 1) * d - l0, 0)); }
+
+// ---- LC_X_CLAMP_REFERENCE_OUTER ------------------------------------------------------------------------------------------
+// The fused kernel ran chunk [s0, ...) and a parcel left the box: the sub-step path restarts at s0 from the positions
+// saved before that chunk, or from the seed grid when they could not be kept.
+LCP_HD int outer_restart(int s0, bool have_saved) { return (s0 > 0 && !have_saved) ? 0 : s0; }
+
+// ---- tile grids ----------------------------------------------------------------------------------------------------------
+// Tiles of w x h seeds over an ny x nx block, XCD chunks of xcd_rows tile rows.
+struct TileGrid {
+    int ntx, nty, ntiles, xcd_chunk, grid;  // grid: blocks incl. the pole blocks
+};
+LCP_HD TileGrid tile_grid(int ny, int nx, int w, int h, int xcd_rows, int pole_blocks) {
+    TileGrid t;
+    t.ntx = (nx + w - 1) / w;
+    t.nty = (ny + h - 1) / h;
+    t.ntiles = t.ntx * t.nty;
+    t.xcd_chunk = xcd_rows * t.ntx;
+    t.grid = xcd_grid(t.ntiles, t.xcd_chunk) + pole_blocks;
+    return t;
+}
+
+}  // namespace lcplan

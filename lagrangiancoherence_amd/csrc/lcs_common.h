@@ -22,6 +22,7 @@ struct lc_ctx {
     int tile_order;      // lc_advect tile-row order: -1 per kernel (default), 0 as stored, 1 last row first, 2 poles inwards (LCS_TILE_ORDER at creation)
     int pole_blocks;     // lc_advect: 1 leading workgroups take the global pole rows (default), 0 the tiles do (LCS_POLE_BLOCKS at creation)
     int level_chunk;     // lc_advect: time levels per launch (-1 by size, the default: 32 from 2^18 seeds per call; 0 = the whole series in one launch); LCS_LEVEL_CHUNK at creation / lc_ctx_set_level_chunk
+    int f64_fidelity;    // one-call host routes, float64: enum lc_f64_fidelity (LCS_F64_FIDELITY at creation / lc_ctx_set_f64_fidelity)
     int patch_mode;      // two-seed advect kernel, seeds of a wave / form of the trajectory stores: -1 by call (default: whole-line stores through LDS with trajectories, tall patches without, groups of members for lc_advect_batch), 0 tall, 1 wide, 2 lines, 3 two ensemble members per lane (LCS_PATCH_MODE at creation; advect.hip enum Patch)
     lc_flag_allreduce_fn flag_reduce;  // NULL, or the caller's max-all-reduce over the ranks of a row-sharded grid (lc_ctx_set_flag_allreduce)
     void *flag_reduce_user;

@@ -21,7 +21,12 @@ Deliberate differences from the reference (all outside the arithmetic):
     written -- outer-product assignment over offending rows x columns (LCS/trajectory.py:96-97):
     the fused kernel runs first and, only if a parcel really left the longitude range, the engine re-runs
     sub-step by sub-step with that rule (``lc_advect`` mode ``LC_X_CLAMP_REFERENCE_OUTER``);
-  * mixed float32/float64 inputs are computed in float64 (engine.common_dtype).
+  * mixed float32/float64 inputs are computed in float64 (engine.common_dtype);
+  * float64 calls of up to 2^18 seeds (the example's 89 x 180 grid, the 360 x 721 common grid of ``isglobal=True``)
+    follow numpy / scipy's operation order (LCS/trajectory.py:86-87,110-112): ~1e-13 degrees from the reference.
+    Larger float64 calls take the fused-level form, which differs by rounding only (<= 1e-9 degrees, or the flow's own
+    response to a 1e-12 degree seed shift where that is larger); ``get_engine().set_f64_fidelity('exact' | 'fast' |
+    'auto')`` chooses explicitly (INTEGRATION.md "Behavioural notes").
 """
 from __future__ import annotations
 
@@ -120,7 +125,8 @@ def parcel_propagation(U, V, timestep=1, propdim="time", verbose=True, return_tr
         times.reverse()                                     # labels only (Q6)
     eng = get_engine()
     verboseprint(f"Propagating {len(times) - 1} time levels on {eng.device}")
-    field = eng.prepare_field(u, v, lat, lon, interp_order)
+    field = eng.prepare_field(u, v, lat, lon, interp_order,
+                              fuse_levels=eng.f64_fuse_levels(common_dtype(u, v, lat, lon), lat.size * lon.size))
     res = eng.advect(field, lat, lon, timestep, SETTLS_order=SETTLS_order, interp_order=interp_order,
                      cyclic_xboundary=cyclic_xboundary, return_traj=return_traj)
     coords2d = {"latitude": lat, "longitude": lon}
@@ -243,7 +249,8 @@ class LCS:
             cyclic_xboundary = False
 
         verboseprint("*---- Parcel propagation ----*")
-        field = eng.prepare_field(uu, vv, lat, lon, traj_interp_order)
+        field = eng.prepare_field(uu, vv, lat, lon, traj_interp_order,
+                                  fuse_levels=eng.f64_fuse_levels(common_dtype(uu, vv, lat, lon), lat.size * lon.size))
         dtype = field.dtype
         lat_t, lon_t = lat.astype(dtype), lon.astype(dtype)
         res = eng.lcs(field, lat_t, lon_t, timestep, SETTLS_order=self.SETTLS_order,

@@ -85,7 +85,6 @@ class Engine:
         self.device = torch.device("cuda", self.device_index)
         ctx = C.c_void_p()
         _capi.check(self.lib.lc_ctx_create(self.device_index, C.byref(ctx)), self.lib)
-        self.level_chunk = -1         # what set_level_chunk was last given (-1: by size, or LCS_LEVEL_CHUNK)
         self.lds_tiles_mode = -1      # what set_lds_tiles was last given (-1: the library's default, or LCS_LDS_TILES)
         self.ctx = ctx
 
@@ -116,7 +115,37 @@ class Engine:
         the default -- 32 levels from 2^18 seeds per call).  Results are bit-identical; it shapes the launches only
         (``lc_ctx_set_level_chunk``)."""
         _capi.check(self.lib.lc_ctx_set_level_chunk(self.ctx, int(levels)), self.lib)
-        self.level_chunk = int(levels)
+
+    @property
+    def level_chunk(self) -> int:
+        """The context's levels-per-launch setting in force (``lc_ctx_get_level_chunk``): what :meth:`set_level_chunk`
+        was last given, or what ``LCS_LEVEL_CHUNK`` set when the context was created (-1: by size)."""
+        v = C.c_int()
+        _capi.check(self.lib.lc_ctx_get_level_chunk(self.ctx, C.byref(v)), self.lib)
+        return v.value
+
+    _FIDELITY = {"auto": _capi.LC_F64_AUTO, "exact": _capi.LC_F64_EXACT_ORDER, "fast": _capi.LC_F64_FAST}
+
+    def set_f64_fidelity(self, mode: str):
+        """float64 on the reference-shaped surfaces (the drop-in's ``LCS`` / ``parcel_propagation``, the one-call host
+        routes): ``'exact'`` = numpy / scipy's operation order (~1e-13 degrees from the reference), ``'fast'`` = the
+        fused-level form (rounding-level differences, <= 1e-9 degrees or the flow's own response to a 1e-12 degree seed
+        shift, whichever is larger), ``'auto'`` (default) = exact up to 2^18 seeds per call, fast above
+        (``lc_ctx_set_f64_fidelity``).  :meth:`prepare_field`'s own ``fuse_levels`` argument is explicit and unaffected."""
+        if mode not in self._FIDELITY:
+            raise ValueError(f"float64 fidelity {mode!r}: 'auto', 'exact' or 'fast'")
+        _capi.check(self.lib.lc_ctx_set_f64_fidelity(self.ctx, self._FIDELITY[mode]), self.lib)
+
+    def f64_fuse_levels(self, dtype, n_seeds: int) -> bool:
+        """``fuse_levels`` for a reference-shaped call of ``n_seeds`` seeds in ``dtype`` under the context's fidelity
+        setting (the rule of ``lc_lcs_host``: float32 always fuses)."""
+        if np.dtype(dtype) != np.dtype(np.float64):
+            return True
+        m = C.c_int()
+        _capi.check(self.lib.lc_ctx_get_f64_fidelity(self.ctx, C.byref(m)), self.lib)
+        if m.value == _capi.LC_F64_EXACT_ORDER:
+            return False
+        return m.value == _capi.LC_F64_FAST or int(n_seeds) > _capi.LC_EXACT_ORDER_MAX_SEEDS
 
     def set_flag_allreduce(self, group=None, comm=None, enable=True):
         """Row-sharded grids with the reference's non-cyclic clamp (``LC_X_CLAMP_REFERENCE_OUTER``): install the
@@ -563,8 +592,10 @@ class Engine:
 # ---------------------------------------------------------------------------
 def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cyclic_xboundary=False,
              seed_lat=None, seed_lon=None, t0=0, nsteps=None, gauss_sigma=None, fd_fp32_cast=True,
-             tensor_layout="reference", return_traj=False, want_sigma=True, device=0, noncyclic_clamp=None):
-    """numpy in, numpy out, via the one-call C entry point.  Returns a dict."""
+             tensor_layout="reference", return_traj=False, want_sigma=True, device=0, noncyclic_clamp=None,
+             float64_fidelity=None):
+    """numpy in, numpy out, via the one-call C entry point.  Returns a dict.
+    ``float64_fidelity``: ``'auto'`` (default) / ``'exact'`` / ``'fast'``, see :meth:`Engine.set_f64_fidelity`."""
     lib = _capi.load()
     dtype = common_dtype(u, v, lat_f, lon_f, seed_lat, seed_lon)
     u = np.ascontiguousarray(u, dtype=dtype)
@@ -591,6 +622,8 @@ def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cycli
     ctx = C.c_void_p()
     _capi.check(lib.lc_ctx_create(int(device), C.byref(ctx)), lib)
     try:
+        if float64_fidelity is not None:
+            _capi.check(lib.lc_ctx_set_f64_fidelity(ctx, Engine._FIDELITY[float64_fidelity]), lib)
         gs = float(gauss_sigma) if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool) else 0.0
         _capi.check(lib.lc_lcs_host(
             ctx, p(u), p(v), _NP2LC[dtype], nt, ny_f, nx_f, p(lat_f), p(lon_f), p(seed_lat), ny, p(seed_lon), nx,
@@ -604,7 +637,8 @@ def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cycli
 
 
 def lcs_global_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, interp_to_common_grid=True,
-                    truncation=20, gauss_sigma=None, fd_fp32_cast=True, tensor_layout="reference", device=0):
+                    truncation=20, gauss_sigma=None, fd_fp32_cast=True, tensor_layout="reference", device=0,
+                    float64_fidelity=None):
     """The reference's default global call form ``LCS(...)(ds, isglobal=True)`` (LCS/LCS.py:105-157) on numpy
     arrays, torch-free, through ``lc_lcs_global_host``: regrid to the common 0.5 degree grid, T-truncation,
     cyclic advection from the grid nodes, sigma.  Returns a dict with ``sigma, x_dep, y_dep, latitude, longitude``."""
@@ -631,6 +665,8 @@ def lcs_global_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3
     ctx = C.c_void_p()
     _capi.check(lib.lc_ctx_create(int(device), C.byref(ctx)), lib)
     try:
+        if float64_fidelity is not None:
+            _capi.check(lib.lc_ctx_set_f64_fidelity(ctx, Engine._FIDELITY[float64_fidelity]), lib)
         _capi.check(lib.lc_lcs_global_host(
             ctx, p(u), p(v), _NP2LC[dtype], nt, ny_f, nx_f, p(lat_f), p(lon_f), int(bool(interp_to_common_grid)),
             -1 if truncation is None else int(truncation), float(timestep), int(SETTLS_order), int(interp_order), gs,

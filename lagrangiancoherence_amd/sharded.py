@@ -195,7 +195,10 @@ def ensemble_advect(engine, field, seed_lat, seed_lon, timestep, members, nsteps
     import torch
     members = list(members)
     chunk = ENSEMBLE_CHUNK if level_chunk is None else int(level_chunk)
-    if chunk <= 0 or chunk >= nsteps:
+    # cyclic_xboundary=False is the reference's outer-product clamp, which is decided per member over its WHOLE series
+    # (lc_advect restarts sub-step by sub-step from the chunk in which a parcel first left the box and cannot continue
+    # from given positions): member-major, one call per member
+    if chunk <= 0 or chunk >= nsteps or not cyclic_xboundary:
         chunk = max(nsteps, 1)
     dtype = getattr(torch, np.dtype(field.dtype).name)
     ny, nx = len(seed_lat), len(seed_lon)

@@ -72,6 +72,10 @@ int main(void) {
         v[k] = 0.0;
     }
     printf("lc_version = %d\n", lc_version());
+    if (lc_version() != LC_VERSION) { /* argument lists changed between versions: header and library must match */
+        fprintf(stderr, "liblcs_hip.so is ABI %d, this client was compiled against %d\n", lc_version(), LC_VERSION);
+        return 4;
+    }
     lc_ctx *ctx = NULL;
     if (lc_ctx_create(0, &ctx) != LC_OK) {
         fprintf(stderr, "lc_ctx_create: %s\n", lc_last_error());

@@ -180,3 +180,39 @@ def test_example_default_global_call_with_regrid_and_truncation():
     np.testing.assert_allclose(eig.values[0][20:-20], s[20:-20], rtol=1e-7)
     # T20 is a strong low-pass: the 2-degree vortex is smeared out, sigma stays close to the identity map's
     assert np.isfinite(eig.values).all()
+
+
+def test_float64_dropin_keeps_the_reference_operation_order_at_the_example_size():
+    """The drop-in surface in float64 up to 2^18 seeds per call (the example's 89 x 180 grid; the 360 x 721 common grid
+    of isglobal=True) runs numpy / scipy's operation order (LCS/trajectory.py:86-87,110-112): every config-1 golden
+    within 1e-12 degrees.  `set_f64_fidelity('fast')` selects the fused-level form (held to 1e-9 degrees), 'auto'
+    restores the default."""
+    from LagrangianCoherence.LCS import LCS, trajectory
+    from lagrangiancoherence_amd import dropin
+    ds, times, lat, lon = _dataset()
+    eng = dropin.get_engine()
+    for tag, dt, K in (("bwd_k4", -21600, 4), ("fwd_k2", 21600, 2), ("fwd_k4", 21600, 4)):
+        for order in (3, 1):
+            g = np.load(os.path.join(GOLD, f"g1_{tag}_o{order}.npz"))
+            x, y = trajectory.parcel_propagation(ds.u, ds.v, timestep=dt, SETTLS_order=K, interp_order=order,
+                                                 cyclic_xboundary=True, verbose=False)
+            assert eng.last_advect_kernel() == f"advect_kernel<double, {order}, false>", eng.last_advect_kernel()
+            ex, ey = np.abs(x.values - g["x_dep"]).max(), np.abs(y.values - g["y_dep"]).max()
+            print(f"drop-in {tag} order {order}: max |dx| {ex:.2e} |dy| {ey:.2e} deg")
+            assert ex < 1e-12 and ey < 1e-12
+            eig, xd, yd = LCS.LCS(timestep=dt, SETTLS_order=K, return_dpts=True)(
+                ds.copy(), isglobal=True, interp_to_common_grid=False, truncation=None, verbose=False, traj_interp_order=order)
+            assert np.array_equal(xd.values, x.values) and np.array_equal(yd.values, y.values)
+            np.testing.assert_allclose(eig.values[0], g["sigma"], rtol=1e-7)
+    try:
+        eng.set_f64_fidelity("fast")
+        g = np.load(os.path.join(GOLD, "g1_bwd_k4_o3.npz"))
+        x, y = trajectory.parcel_propagation(ds.u, ds.v, timestep=-21600, SETTLS_order=4, cyclic_xboundary=True, verbose=False)
+        assert "lds64_o3" in eng.last_advect_kernel() or "true>" in eng.last_advect_kernel(), eng.last_advect_kernel()
+        np.testing.assert_allclose(x.values, g["x_dep"], rtol=0, atol=1e-9)
+        with pytest.raises(ValueError):
+            eng.set_f64_fidelity("sloppy")
+    finally:
+        eng.set_f64_fidelity("auto")
+    x2, _ = trajectory.parcel_propagation(ds.u, ds.v, timestep=-21600, SETTLS_order=4, cyclic_xboundary=True, verbose=False)
+    assert eng.last_advect_kernel() == "advect_kernel<double, 3, false>"

@@ -28,7 +28,13 @@ class OracleEngine:
     def to_device(self, a, dtype):
         return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=dtype)))
 
+    fuse_asked = []           # what the adapter asked of prepare_field (float64 fidelity rule of the drop-in surface)
+
+    def f64_fuse_levels(self, dtype, n_seeds):
+        return np.dtype(dtype) != np.dtype(np.float64) or n_seeds > (1 << 18)
+
     def prepare_field(self, u, v, lat, lon, interp_order=1, dtype=None, fuse_levels=None):
+        self.fuse_asked.append(fuse_levels)
         if interp_order not in (1, 3):
             raise ValueError(f"interp_order {interp_order} unsupported")
         dt = np.dtype(dtype or common_dtype(u, v, lat, lon))

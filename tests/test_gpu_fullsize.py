@@ -41,6 +41,9 @@ def test_config3_full_size_subset_vs_oracle(eng, c3, order):
     u, v, lat, lon, slat, slon = c3
     f = eng.prepare_field(u, v, lat, lon, order)
     x, y = eng.advect(f, slat, slon, -900.0, SETTLS_order=4, interp_order=order, cyclic_xboundary=True)
+    # the kernel BASELINE configs[2] is dispatched to (asserted so a change of the launcher's size thresholds cannot
+    # silently move the configuration onto a kernel variant without an oracle anchor)
+    assert eng.last_advect_kernel() == {1: "advect_lds2_kernel<4, true, 0>", 3: "advect_lds2_o3_kernel<4, true, 0>"}[order]
     rows, cols = _subset(4096, 40, order), _subset(4096, 40, 0)
     xg = x[rows][:, cols].cpu().numpy().astype(np.float64)
     yg = y[rows][:, cols].cpu().numpy().astype(np.float64)
@@ -95,6 +98,7 @@ def test_config2_full_size_subset_vs_oracle(eng):
     u, v, lat, lon = flows.config2()
     f = eng.prepare_field(u, v, lat, lon, 1)
     r = eng.lcs(f, lat, lon, -900.0, SETTLS_order=4, interp_order=1, cyclic_xboundary=True)
+    assert eng.last_advect_kernel() == "advect_lds64_kernel<4, true>", eng.last_advect_kernel()
     rows, cols = _subset(1024, 24, 1), _subset(1024, 24, 0)
     xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=1,
                                     cyclic_xboundary=True, seed_lat=lat[rows], seed_lon=lon[cols])
@@ -105,3 +109,53 @@ def test_config2_full_size_subset_vs_oracle(eng):
     np.testing.assert_allclose(yg, yr_, rtol=0, atol=1e-9)
     s = r["sigma"].cpu().numpy()
     assert np.isfinite(s).all() and s.max() > 1.5      # the vortex does stretch the flow map
+
+
+def test_config2_order3_full_size_subset_vs_oracle(eng):
+    """configs[1] as the reference itself would run it: float64, seeds = field nodes (LCS/trajectory.py:68-70) and the
+    default interp_order=3 (:16), on the float64 order-3 LDS-tile kernel.  12 steps: the order-3 oracle re-runs scipy's
+    whole-field prefilter 18 times per step."""
+    from oracle import lcs_oracle as O
+    u, v, lat, lon = flows.config2(nt=13)
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    x, y = eng.advect(f, lat, lon, -900.0, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
+    assert eng.last_advect_kernel() == "advect_lds64_o3_kernel<4, true>", eng.last_advect_kernel()
+    rows, cols = _subset(1024, 24, 3), _subset(1024, 24, 0)
+    xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=3,
+                                    cyclic_xboundary=True, seed_lat=lat[rows], seed_lon=lon[cols])
+    xg, yg = x[rows][:, cols].cpu().numpy(), y[rows][:, cols].cpu().numpy()
+    print(f"C2 order 3: max |dx| {np.abs(xg - xr_).max():.3e} |dy| {np.abs(yg - yr_).max():.3e} deg")
+    np.testing.assert_allclose(xg, xr_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(yg, yr_, rtol=0, atol=1e-9)
+
+
+def test_config3_return_traj_whole_line_stores_full_size(eng, c3):
+    """return_traj (LCS/trajectory.py:125-139) in float32 at configs[2]'s seed count: the two-seed kernel with the
+    trajectory slab stores (`advect_lds2_kernel<4, true, 2>`: positions through LDS, whole 128-byte lines, non-temporal).
+    Every stored level of a seed subset against the oracle's trajectory list, inside the float32 oracle's band."""
+    import torch
+    from oracle import lcs_oracle as O
+    from tests._fullsize import positions_check
+    u, v, lat, lon, slat, slon = c3
+    nt = 25
+    f = eng.prepare_field(u[:nt], v[:nt], lat, lon, 1)
+    x, y, tx, ty = eng.advect(f, slat, slon, -900.0, SETTLS_order=4, interp_order=1, cyclic_xboundary=True, return_traj=True)
+    assert eng.last_advect_kernel() == "advect_lds2_kernel<4, true, 2>", eng.last_advect_kernel()
+    assert tuple(tx.shape) == (nt, 4096, 4096)
+    # entry 0 is the seed grid (trajectory.py:73-74), the last entry the departure points
+    assert torch.equal(tx[0], torch.from_numpy(slon).cuda()[None, :].expand(4096, 4096))
+    assert torch.equal(ty[0], torch.from_numpy(slat).cuda()[:, None].expand(4096, 4096))
+    assert torch.equal(tx[-1], x) and torch.equal(ty[-1], y)
+    rows, cols = _subset(4096, 40, 1), _subset(4096, 40, 0)
+    ri, ci = torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()
+    xg = tx[:, ri][:, :, ci].cpu().numpy().astype(np.float64)
+    yg = ty[:, ri][:, :, ci].cpu().numpy().astype(np.float64)
+    kw = dict(timestep=-900.0, SETTLS_order=4, interp_order=1, cyclic_xboundary=True, return_traj=True)
+    c = lambda a, dt: np.asarray(a).astype(dt, copy=False)
+    o = {}
+    for dt in (np.float32, np.float64):
+        o[dt] = O.parcel_propagation(c(u[:nt], dt), c(v[:nt], dt), c(lat, dt), c(lon, dt), seed_lat=c(slat, dt)[rows],
+                                     seed_lon=c(slon, dt)[cols], **kw)
+    for lev in range(1, nt):
+        positions_check(eng, f, slat, slon, rows, cols, xg[lev], yg[lev], (o[np.float32][0][lev], o[np.float32][1][lev]),
+                        (o[np.float64][0][lev], o[np.float64][1][lev]), f"C3 traj level {lev}", (1e-4, 5e-4, 2e-3), nsteps=lev)

@@ -15,6 +15,17 @@ from tests._fullsize import band, dilate, oracle_subset, oracle_window, position
 pytestmark = pytest.mark.gpu
 KW = dict(timestep=-900.0, SETTLS_order=4, cyclic_xboundary=True)
 
+# The kernel each BASELINE configuration is dispatched to.  Every test below asserts the name of the kernel that ran
+# (lc_ctx_last_advect_kernel), so a change of the launcher's size thresholds cannot silently move a configuration onto a
+# kernel variant that has no oracle anchor at that size.
+EXPECT = {
+    ("c3", 1): "advect_lds2_kernel<4, true, 0>",          # 4096^2 seeds: two seeds per lane, tall patches
+    ("c3", 3): "advect_lds2_o3_kernel<4, true, 0>",
+    ("c4 shard", 1): "advect_lds2_kernel<4, true, 0>",    # 1024 x 8192 seeds = 2^23 per call
+    ("c5 member", 1): "advect_lds_kernel<1, 4, true>",    # one member alone: 2^22 seeds, one seed per lane
+    ("c5 rank", 1): "advect_lds2_kernel<4, true, 3>",     # a rank's 8 members through lc_advect_batch: two MEMBERS per lane
+}
+
 
 @pytest.fixture(scope="module")
 def eng():
@@ -43,6 +54,9 @@ def c3(eng):
     for order, nt in ((1, 97), (3, 25)):       # the order-3 oracle re-runs scipy's prefilter 18x per step: 24 steps
         f = eng.prepare_field(u[:nt], v[:nt], lat, lon, order)
         r = eng.lcs(f, slat, slon, -900.0, SETTLS_order=4, interp_order=order, cyclic_xboundary=True)
+        # the kernels BASELINE configs[2] dispatches to (2^24 seeds per call: two seeds per lane)
+        assert eng.last_advect_kernel() == EXPECT[("c3", order)], eng.last_advect_kernel()
+        assert eng.last_sigma_kernel() == "sigma_march_kernel_f32", eng.last_sigma_kernel()
         res[order] = {k: _np(r[k]) for k in ("sigma", "x_dep", "y_dep")}
         res[order]["field"] = f
         del r
@@ -100,6 +114,7 @@ def test_config4_row_shards_full_size(eng, O):
     bounds = [sharded.row_partition(NY, WORLD, r) for r in range(WORLD)]
     for lo, hi in bounds:                                          # advection needs no communication
         xs, ys = eng.advect(f, slat[lo:hi], slon, -900.0, 4, 1, True, row0=lo, ny_global=NY)
+        assert eng.last_advect_kernel() == EXPECT[("c4 shard", 1)], eng.last_advect_kernel()
         x[lo:hi], y[lo:hi] = xs, ys
     # (a) positions: a subset containing every shard's first and last row, vs the oracle on those seeds
     must = [r for lo, hi in bounds for r in (lo, lo + 1, hi - 2, hi - 1)]
@@ -140,6 +155,7 @@ def test_config5_ensemble_members_full_size(eng, O):
         mine, sig, xd, yd = sharded.ensemble_lcs(eng, f, slat, slon, -900.0, NE, NS, rank=e, world=NE, SETTLS_order=4,
                                                  interp_order=1, return_dpts=True)
         assert mine == [e]
+        assert eng.last_advect_kernel() == EXPECT[("c5 member", 1)], eng.last_advect_kernel()
         kw = dict(KW, interp_order=1, t0=e, nsteps=NS)
         o32 = oracle_subset(O, u, v, lat, lon, slat, slon, rows, cols, np.float32, **kw)
         o64 = oracle_subset(O, u, v, lat, lon, slat, slon, rows, cols, np.float64, **kw)
@@ -152,4 +168,40 @@ def test_config5_ensemble_members_full_size(eng, O):
         assert np.isfinite(_np(sig[0])).all()
         g = {"x_dep": _np(xd[0]), "y_dep": _np(yd[0]), "sigma": _np(sig[0]), "field": f}
         _window_check(eng, g, slat, slon, (r0, r1, c0, c1), w32, w64, f"C5 member {e} window", 1,
+                      (5e-4, 5e-3, 5e-2), (2e-4, 2e-3, 1e-2), t0=e, nsteps=NS)
+
+
+def test_config5_one_rank_of_eight_as_dispatched(eng, O):
+    """configs[4] as the 8-GPU layout runs it: rank 7's block of 8 consecutive start times (members 56..63) x 2048^2
+    seeds x 200 steps in ONE lc_advect_batch call -- level-major chunks, two members per lane of the two-seed kernel
+    (`advect_lds2_kernel<4, true, 3>`, the kernel the C5 throughput is quoted on).  The reference runs its start-time
+    loop one series at a time (LCS/trajectory.py:80-126 per start time); the oracle does exactly that for the first
+    member of the block (first of a lane pair), a middle one (second of a pair) and the last (second of a pair, whose
+    last step reads the series' last level): positions on a seed subset and sigma on a 64x64 window."""
+    NE, NS, N, WORLD, RANK = 64, 200, 2048, 8, 7
+    u, v, lat, lon = flows.era5_like(nt=NE + NS)
+    slat, slon = flows.seed_grid(N, N, lat, lon)
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    mine, sig, xd, yd = sharded.ensemble_lcs(eng, f, slat, slon, -900.0, NE, NS, rank=RANK, world=WORLD, SETTLS_order=4,
+                                             interp_order=1, return_dpts=True)
+    assert mine == list(range(56, 64))
+    assert eng.last_advect_kernel() == EXPECT[("c5 rank", 1)], eng.last_advect_kernel()
+    # the pair path walks the window [0, nsteps + 1) in chunks of sharded.ENSEMBLE_CHUNK levels
+    assert eng.last_advect_launches() == -(-(NS + 1) // sharded.ENSEMBLE_CHUNK)
+    rows, cols = subset(N, 48, 1), subset(N, 48, 0)
+    r0, r1, c0, c1 = 1400, 1464, 300, 364
+    for e in (56, 59, 63):
+        i = e - mine[0]
+        kw = dict(KW, interp_order=1, t0=e, nsteps=NS)
+        o32 = oracle_subset(O, u, v, lat, lon, slat, slon, rows, cols, np.float32, **kw)
+        o64 = oracle_subset(O, u, v, lat, lon, slat, slon, rows, cols, np.float64, **kw)
+        xg, yg = _np(xd[i][rows][:, cols]), _np(yd[i][rows][:, cols])
+        positions_check(eng, f, slat, slon, rows, cols, xg, yg, o32, o64, f"C5 rank 7 member {e} (200 steps, batch)",
+                        (2e-4, 2e-3, 1e-2), t0=e, nsteps=NS)
+        kw = dict(KW, t0=e, nsteps=NS)
+        w32 = oracle_window(O, u, v, lat, lon, slat, slon, r0, r1, c0, c1, np.float32, 1, **kw)
+        w64 = oracle_window(O, u, v, lat, lon, slat, slon, r0, r1, c0, c1, np.float64, 1, **kw)
+        assert np.isfinite(_np(sig[i])).all()
+        g = {"x_dep": _np(xd[i]), "y_dep": _np(yd[i]), "sigma": _np(sig[i]), "field": f}
+        _window_check(eng, g, slat, slon, (r0, r1, c0, c1), w32, w64, f"C5 rank 7 member {e} window", 1,
                       (5e-4, 5e-3, 5e-2), (2e-4, 2e-3, 1e-2), t0=e, nsteps=NS)

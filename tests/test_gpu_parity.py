@@ -466,10 +466,18 @@ def test_lcs_host_route_matches_engine(eng):
     from lagrangiancoherence_amd.engine import lcs_host
     u, v, lat, lon = flows.config1()
     out = lcs_host(u, v, lat, lon, -21600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True, return_traj=True)
-    f = eng.prepare_field(u, v, lat, lon, 3)
+    # float64 at the example's size: the host route keeps numpy / scipy's operation order (LC_F64_AUTO)
+    f = eng.prepare_field(u, v, lat, lon, 3, fuse_levels=False)
     r = eng.lcs(f, lat, lon, -21600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
+    assert eng.last_advect_kernel() == "advect_kernel<double, 3, false>"
     assert np.array_equal(out["x_dep"], _np(r["x_dep"])) and np.array_equal(out["sigma"], _np(r["sigma"]))
     assert out["traj_x"].shape == (8, 89, 180) and np.array_equal(out["traj_x"][-1], out["x_dep"])
+    g = np.load(os.path.join(GOLD, "g1_bwd_k4_o3.npz"))
+    assert np.abs(out["x_dep"] - g["x_dep"]).max() < 1e-12 and np.abs(out["y_dep"] - g["y_dep"]).max() < 1e-12
+    # 'fast' = the engine's default fused-level form, bit for bit; inside the float64 tolerance of the reference
+    fast = lcs_host(u, v, lat, lon, -21600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True, float64_fidelity="fast")
+    rf = eng.lcs(eng.prepare_field(u, v, lat, lon, 3), lat, lon, -21600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
+    assert np.array_equal(fast["x_dep"], _np(rf["x_dep"])) and np.abs(fast["x_dep"] - g["x_dep"]).max() < POS_ATOL64
 
 
 def test_gauss_sigma_path(eng, O):
@@ -669,6 +677,28 @@ def test_ensemble_members_are_t0_windows(eng, O):
         b = sharded.ensemble_lcs(eng, f, slat, slon, -1800.0, n_members=5, nsteps=4, SETTLS_order=2, return_dpts=True,
                                  streams=ns, level_chunk=chunk)
         assert a[0] == b[0] and all(bool((x == y).all()) for x, y in zip(a[1:], b[1:])), (chunk, ns)
+
+
+def test_ensemble_with_the_reference_noncyclic_clamp_on_a_long_series(eng, O):
+    """cyclic_xboundary=False through ensemble_lcs with more steps than ENSEMBLE_CHUNK (round-3 advisor finding: the
+    level-major path continued each member in place with start positions, which LC_X_CLAMP_REFERENCE_OUTER refuses).  The
+    reference's clamp is decided per member over its whole series: member-major, each member == its own lc_advect."""
+    from lagrangiancoherence_amd import sharded
+    nsteps = sharded.ENSEMBLE_CHUNK + 5
+    u, v, lat, lon = _rand_field(23, nt=nsteps + 3, ny=19, nx=27, scale=3.0)
+    u[:] = u * 4 + 25.0                          # a zonal flow that pushes parcels out of the regional box
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    mine, sig, xd, yd = sharded.ensemble_lcs(eng, f, lat, lon, 3600.0, n_members=3, nsteps=nsteps, SETTLS_order=1,
+                                             interp_order=1, cyclic_xboundary=False, return_dpts=True)
+    assert mine == [0, 1, 2]
+    for e in mine:
+        r = eng.lcs(f, lat, lon, 3600.0, SETTLS_order=1, interp_order=1, cyclic_xboundary=False, t0=e, nsteps=nsteps)
+        assert eng.last_advect_kernel() == "outer_substep_kernel"       # parcels did leave: the reference's rule ran
+        assert bool((xd[e] == r["x_dep"]).all()) and bool((yd[e] == r["y_dep"]).all()) and bool((sig[e] == r["sigma"]).all())
+        xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=3600.0, SETTLS_order=1, interp_order=1,
+                                        cyclic_xboundary=False, noncyclic_clamp="reference_outer", t0=e, nsteps=nsteps)
+        np.testing.assert_allclose(_np(xd[e]), xr_, rtol=0, atol=POS_ATOL64)
+        np.testing.assert_allclose(_np(yd[e]), yr_, rtol=0, atol=POS_ATOL64)
 
 
 @pytest.mark.parametrize("order", [1, 3])

@@ -197,3 +197,69 @@ def test_sharded_noncyclic_reference_clamp_equals_unsharded(world, dtype):
     for rank, msg, _ in res:
         assert msg == "ok", f"rank {rank}: {msg}"
     assert any(d for _, _, d in res)       # on some rank the per-point clamp gives different departure points
+
+
+def _outer_straddle_worker(rank, world, port, late, q):
+    """LC_X_CLAMP_REFERENCE_OUTER on a row-sharded grid whose blocks straddle 2^18 seeds (511 x 1024 seeds over 2 ranks:
+    256 and 255 rows), 40 levels, SETTLS_order 4 (round-3 advisor finding): the level chunk -- one flag all-reduce each
+    -- used to follow the LOCAL seed count (32 levels from 2^18 seeds, 16 below), so the ranks issued different numbers of
+    collectives.  `late` = the level from which a zonal jet pushes parcels out of the box (0: never)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        import numpy as np
+        from lagrangiancoherence_amd import sharded
+        from lagrangiancoherence_amd.engine import Engine
+        torch.cuda.set_device(0)
+        eng = Engine(0)
+        rng = np.random.default_rng(17)
+        ny, nx, nt = 41, 56, 41
+        lat = np.linspace(-40, 40, ny).astype(np.float32)
+        lon = np.linspace(-60, 50, nx).astype(np.float32)
+        u = (0.5 * rng.standard_normal((nt, ny, nx))).astype(np.float32)
+        v = (0.5 * rng.standard_normal((nt, ny, nx))).astype(np.float32)
+        if late:
+            u[late:] += np.float32(60.0)
+        slat = np.linspace(-39, 39, 511).astype(np.float32)        # seeds strictly inside the box
+        slon = np.linspace(-50, 40, 1024).astype(np.float32)
+        f = eng.prepare_field(u, v, lat, lon, 1)
+        kw = dict(SETTLS_order=4, interp_order=1, cyclic_xboundary=False)
+        full = eng.lcs(f, slat, slon, 900.0, **kw)
+        moved = eng.last_advect_kernel() == "outer_substep_kernel"
+        calls = []
+        out = sharded.sharded_lcs(eng, f, slat, slon, 900.0, rank, world, **kw)
+        launches = eng.last_advect_launches()
+        red = sharded.sharded_lcs(eng, f, slat, slon, 900.0, rank, world, redundant_halo=True, **kw)
+        lo, hi = out["rows"]
+        straddle = (hi - lo) * 1024 >= (1 << 18) if rank == 0 else (hi - lo) * 1024 < (1 << 18)
+        ok = torch.equal(out["x_dep"], full["x_dep"][lo:hi]) and torch.equal(out["y_dep"], full["y_dep"][lo:hi]) \
+            and torch.equal(out["sigma"], full["sigma"][lo:hi]) and torch.equal(red["sigma"], out["sigma"])
+        msg = "ok" if ok and straddle and moved == bool(late) else \
+            f"rows {lo}:{hi} equal={ok} straddle={straddle} sub-step path={moved} (late={late})"
+        q.put((rank, msg, launches))
+        eng.close()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), -1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("late", [0, 20])
+def test_sharded_noncyclic_clamp_with_blocks_on_either_side_of_the_chunk_threshold(late):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_outer_straddle_worker, args=(r, world, port, late, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg, _ in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+    # every rank made the same number of fused launches = the same number of "did a parcel leave" all-reduces
+    assert len({n for _, _, n in res}) == 1, res
