@@ -85,8 +85,9 @@ class LCSError(RuntimeError):
     """A C-ABI call returned LC_EHIP / LC_ERCCL."""
 
 
-def load(path: str | None = None):
-    """Load liblcs_hip.so and attach prototypes.  Raises if it is not built."""
+def load(path: str | None = None, import_torch: bool = True):
+    """Load liblcs_hip.so and attach prototypes.  Raises if it is not built.  ``import_torch=False``: a torch-free host
+    process (ctypes only, e.g. the one-call routes or tests/fake_rccl_driver.py) skips the torch import below."""
     global _lib
     if _lib is not None and path is None:
         return _lib
@@ -95,10 +96,11 @@ def load(path: str | None = None):
     # One HIP runtime per process: torch wheels bundle their own ROCm libraries, and loading ours
     # (linked against /opt/rocm) first leaves the process with two HSA runtimes and "no ROCm-capable
     # device".  Importing torch first makes our DT_NEEDED entries resolve to the copies torch loaded.
-    try:
-        import torch  # noqa: F401
-    except ImportError:  # torch-free hosts use lc_lcs_host only
-        pass
+    if import_torch:
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # torch-free hosts use lc_lcs_host only
+            pass
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} is missing: the HIP extension is the only compute path of this package "
