@@ -35,7 +35,8 @@ extern "C" {
 #endif
 
 /* 101: lc_spectral_truncate gained `gridtype`, lc_fourth_order_derivative gained `isglobal` (arguments inserted: a
- * client built against 100 must be rebuilt), lc_ctx_get_level_chunk and lc_ctx_set/get_f64_fidelity added.  lc_version() returns the value the LIBRARY
+ * client built against 100 must be rebuilt), lc_ctx_get_level_chunk, lc_ctx_set/get_f64_fidelity, lc_advect_ex and
+ * lc_sample_raw added, lc_field_pack accepts packed_dev == NULL at order 1 (fused-level image only).  lc_version() returns the value the LIBRARY
  * was built with: compare it with this macro before any other call (tests/c/abi_smoke.c, _capi.load do). */
 #define LC_VERSION 101 /* 0.1.1 */
 
@@ -182,7 +183,9 @@ int lc_memcpy_d2h(lc_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes
  * scipy.ndimage.spline_filter(order, mode='mirror'); orders 4, 5 agree with scipy to 1e-12: the pole
  * constants differ in the last bit).
  *
- * lc_packed_elems() = number of dtype elements the image needs.            */
+ * lc_packed_elems() = number of dtype elements the image needs.
+ * interp_order 1 with packed_dev == NULL and ext_dev != NULL builds ONLY the fused-level image: what a float64
+ * caller needs who hands lc_advect_ex the raw planes as the order-1 source (half the bytes written).          */
 size_t lc_packed_elems(int nt, int ny_f, int nx_f);
 int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype,
                   int nt, int ny_f, int nx_f, int interp_order, void *packed_dev,
@@ -309,6 +312,37 @@ int lc_advect_batch(lc_ctx *ctx, const void *packed_lin, const void *packed_cub,
                     int t0, int nsteps, int n_members, int t0_stride,
                     void *x_out, void *y_out, void *traj_x, void *traj_y);
 
+/* lc_advect_batch with its arguments in one structure (same names, same meaning), plus the RAW wind planes as the
+ * order-1 source in place of the packed_lin image:
+ *   u_raw, v_raw   NULL, or the [nt][ny_f][nx_f] arrays lc_field_pack was given (dtype elements, device, still alive and
+ *                  unchanged).  With them packed_lin may be NULL when interp_order != 1 (the first / last interp_order
+ *                  seed rows gather their order-1 / 'constant' samples, LCS/tools.py:31-39, straight from the planes) and
+ *                  in LC_F64 / LC_F64_WIND_F32 at interp_order 1 (the Euler sample, LCS/trajectory.py:82-84, too): the
+ *                  order-1 image is then never built, written or read -- one third of the pack's traffic at order 1 and a
+ *                  fifth at order 3 -- and the results are bit-identical to the packed_lin form (same node values, same
+ *                  arithmetic).  LC_F32 at interp_order 1 keeps packed_lin (its kernels read 16-byte {u, v} node pairs)
+ *                  and ignores the planes.
+ *   struct_size    sizeof(lc_advect_args) as the caller compiled it: a library built for another layout refuses.
+ * lc_advect / lc_advect_from / lc_advect_batch are this call with u_raw = v_raw = NULL. */
+typedef struct lc_advect_args {
+    size_t struct_size;
+    const void *packed_lin, *packed_cub, *packed_ext;
+    const void *u_raw, *v_raw;
+    int dtype, nt, ny_f, nx_f;
+    double lat_min, lat_max, lon_min, lon_max;
+    const void *seed_lat_dev;
+    int ny;
+    const void *seed_lon_dev;
+    int nx;
+    int row0, ny_global;
+    const void *x_start, *y_start;
+    double timestep;
+    int settls_order, interp_order, cyclic_x;
+    int t0, nsteps, n_members, t0_stride;
+    void *x_out, *y_out, *traj_x, *traj_y;
+} lc_advect_args;
+int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args);
+
 /* One interpolation pass on its own: tools.xr_map_coordinates (LCS/tools.py:11-41) for the
  * u and v fields of time level `level` at the given positions (degrees), same index
  * scale, row classes and boundary modes as inside lc_advect.  pos_x/pos_y/out_u/out_v
@@ -318,6 +352,14 @@ int lc_sample(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int d
               double lat_min, double lat_max, double lon_min, double lon_max, int level,
               const void *pos_x_dev, const void *pos_y_dev, int ny, int nx,
               int row0, int ny_global, int interp_order, void *out_u, void *out_v);
+
+/* lc_sample with the raw planes as the order-1 source (see lc_advect_ex): packed_lin may then be NULL (interp_order != 1:
+ * only the pole rows sample order 1; LC_F64 at interp_order 1: every row does). */
+int lc_sample_raw(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *u_raw, const void *v_raw, int dtype,
+                  int nt, int ny_f, int nx_f,
+                  double lat_min, double lat_max, double lon_min, double lon_max, int level,
+                  const void *pos_x_dev, const void *pos_y_dev, int ny, int nx,
+                  int row0, int ny_global, int interp_order, void *out_u, void *out_v);
 
 /* ---- K3: flow-map gradient + largest singular value ------------------------
  * Replaces LCS.flowmap_gradient (LCS/LCS.py:171-225), tools.derivative_spherical_coords

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "lc_advect_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _i, _vp, _i, _i, _i, _vp, _vp,
                              _d, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lc_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lc_sample_raw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lc_sigma": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _d, _d, _i, _i, _i, _i, _vp]),
     "lc_flowmap_gradient": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _d, _d, _i, _vp]),
     "lc_fourth_order_derivative": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -77,6 +78,25 @@ PROTOTYPES = {
 }
 
 FLAG_ALLREDUCE_FN = C.CFUNCTYPE(_i, _vp, _vp, _sz)   # lc_flag_allreduce_fn of include/lcs_hip.h
+
+
+class AdvectArgs(C.Structure):
+    """``lc_advect_args`` of include/lcs_hip.h, field for field."""
+    _fields_ = [("struct_size", _sz),
+                ("packed_lin", _vp), ("packed_cub", _vp), ("packed_ext", _vp),
+                ("u_raw", _vp), ("v_raw", _vp),
+                ("dtype", _i), ("nt", _i), ("ny_f", _i), ("nx_f", _i),
+                ("lat_min", _d), ("lat_max", _d), ("lon_min", _d), ("lon_max", _d),
+                ("seed_lat_dev", _vp), ("ny", _i), ("seed_lon_dev", _vp), ("nx", _i),
+                ("row0", _i), ("ny_global", _i),
+                ("x_start", _vp), ("y_start", _vp),
+                ("timestep", _d),
+                ("settls_order", _i), ("interp_order", _i), ("cyclic_x", _i),
+                ("t0", _i), ("nsteps", _i), ("n_members", _i), ("t0_stride", _i),
+                ("x_out", _vp), ("y_out", _vp), ("traj_x", _vp), ("traj_y", _vp)]
+
+
+PROTOTYPES["lc_advect_ex"] = (_i, [_vp, C.POINTER(AdvectArgs)])
 
 _lib = None
 

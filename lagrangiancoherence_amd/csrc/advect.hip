@@ -39,6 +39,11 @@ struct AdvectArgs {
     const T *lin;  // order-1 image (raw values)
     const T *img;  // image for the interior rows (== lin for order 1, coefficients for order 3)
     const T *ext;  // null, or 2*img[t] - img[t+1] (lc_field_extrapolate)
+    // The raw wind planes u, v [nt][ny_f][nx_f] as the ORDER-1 source instead of the lin image (lc_advect_ex; NULL: lin):
+    // the pole seed rows' order-1 / 'constant' samples (Q3), and in float64 at order 1 the Euler sample (img == lin is then
+    // not read at all).  Same node values, same arithmetic, bit-identical results -- the image the pack no longer writes.
+    const T *u_raw, *v_raw;
+    size_t raw_plane;  // ny_f * nx_f
     size_t level_elems;
     int pitch;  // nodes per padded row
     int ny_f, nx_f;
@@ -303,13 +308,36 @@ __device__ __forceinline__ Tap<T> locate(const AdvectArgs<T> &A, T x, T y) {
         t.wx[0] = T(1) - t.tx;
         t.wx[1] = T(1) - t.wx[0];
         t.off = ((unsigned)(y0 + LC_PAD_LO) * (unsigned)A.pitch + (unsigned)(x0 + LC_PAD_LO)) * 2u;
+        t.sy = y0;  // (the raw-plane fetch addresses by node index)
+        t.sx = x0;
     }
     return t;
 }
 
-template <typename T, int ORDER>
+// The order-1 window {u00, v00, u01, v01}, {u10, v10, u11, v11} of cell (y0, x0) from the RAW planes of one level
+// (up = this level's u plane, vp = its v plane).  The image's pad nodes hold the mirrored interior value, so the
+// neighbour of the last node is node n - 2 here too (its weight is 0 at c = n - 1 exactly; the value still matters for
+// non-finite winds): the same eight numbers as a window of the lin image.
+template <typename T>
+__device__ __forceinline__ void raw_window(const T *__restrict__ up, const T *__restrict__ vp, const AdvectArgs<T> &A, int y0, int x0,
+                                           T (&a)[4], T (&b)[4]) {
+    const int x1 = x0 + 1 < A.nx_f ? x0 + 1 : A.nx_f - 2, y1 = y0 + 1 < A.ny_f ? y0 + 1 : A.ny_f - 2;
+    const size_t r0 = (size_t)y0 * A.nx_f, r1 = (size_t)y1 * A.nx_f;
+    a[0] = up[r0 + x0];
+    a[1] = vp[r0 + x0];
+    a[2] = up[r0 + x1];
+    a[3] = vp[r0 + x1];
+    b[0] = up[r1 + x0];
+    b[1] = vp[r1 + x0];
+    b[2] = up[r1 + x1];
+    b[3] = vp[r1 + x1];
+}
+
+// RAW (order 1 only): `lvl` is the level's raw u plane, the v plane lies A.v_raw - A.u_raw elements on
+template <typename T, int ORDER, bool RAW = false>
 __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const AdvectArgs<T> &A, const Tap<T> &t) {
 #pragma clang fp contract(off)
+    static_assert(!RAW || ORDER == 1, "the raw planes are an order-1 source");
     Pair<T> r;
     if (t.zero) {
         r.u = T(0);
@@ -317,7 +345,7 @@ __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const Advect
         return r;
     }
     if (ORDER != 1 && ORDER != 3) return fetch_general<T, ORDER>(lvl, A, t);
-    const T *p = lvl + t.off;
+    const T *p = RAW ? lvl : lvl + t.off;
     if (ORDER == 3) {
         T su = T(0), sv = T(0);
 #pragma unroll
@@ -335,8 +363,12 @@ __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const Advect
         return r;
     }
     T a[4], b[4];
-    __builtin_memcpy(a, p, sizeof(a));                            // {u00, v00, u01, v01}
-    __builtin_memcpy(b, p + (unsigned)A.pitch * 2u, sizeof(b));   // {u10, v10, u11, v11}
+    if (RAW) {
+        raw_window<T>(p, p + (A.v_raw - A.u_raw), A, t.sy, t.sx, a, b);
+    } else {
+        __builtin_memcpy(a, p, sizeof(a));                            // {u00, v00, u01, v01}
+        __builtin_memcpy(b, p + (unsigned)A.pitch * 2u, sizeof(b));   // {u10, v10, u11, v11}
+    }
     if (Fast<T>::value) {
 #pragma clang fp contract(fast)
         const T u0 = fma(t.tx, a[2] - a[0], a[0]), v0 = fma(t.tx, a[3] - a[1], a[1]);
@@ -360,9 +392,9 @@ __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const Advect
     return r;
 }
 
-template <typename T, int ORDER, bool WRAP>
+template <typename T, int ORDER, bool WRAP, bool RAW = false>
 __device__ __forceinline__ Pair<T> sample(const T *__restrict__ lvl, const AdvectArgs<T> &A, T x, T y) {
-    return fetch<T, ORDER>(lvl, A, locate<T, ORDER, WRAP>(A, x, y));
+    return fetch<T, ORDER, RAW>(lvl, A, locate<T, ORDER, WRAP>(A, x, y));
 }
 
 // y + a*x: fused for float, mul-then-add (numpy's two roundings) for double
@@ -424,7 +456,8 @@ __device__ __forceinline__ T settls_bracket(const AdvectArgs<T> &A, T e, T c, T 
 // FUSED (opt-in, lc_advect with packed_ext in LC_F64): each SETTLS iteration samples the fused image
 // ext[t] = 2 F[t] - F[t+1] once instead of F[t] and F[t+1] separately.  Interpolation is linear in the
 // field, so the value differs from the reference's (e + 2c) - n only by rounding (~1 ulp of the wind).
-template <typename T, int ORDER, bool WRAP, bool FUSED = false>
+// RAW: `image` is A.u_raw (order 1, two-sample form): levels are raw planes, raw_plane elements apart.
+template <typename T, int ORDER, bool WRAP, bool FUSED = false, bool RAW = false>
 __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image, int iy, int ix) {
 #pragma clang fp contract(off)
     T x = start_x<T>(A, iy, ix);
@@ -440,11 +473,12 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
         A.traj_x[idx] = x;
         A.traj_y[idx] = y;
     }
-    const T *lvl = image + (size_t)A.t0 * A.level_elems;
+    const size_t lstride = RAW ? A.raw_plane : A.level_elems;
+    const T *lvl = image + (size_t)A.t0 * lstride;
     const T *elv = FUSED ? A.ext + (size_t)A.t0 * A.level_elems : nullptr;
     for (int s = 0; s < A.nsteps; ++s) {
-        const T *nxt = lvl + A.level_elems;
-        Pair<T> e = sample<T, ORDER, WRAP>(lvl, A, x, y);        // trajectory.py:82-84
+        const T *nxt = lvl + lstride;
+        Pair<T> e = sample<T, ORDER, WRAP, RAW>(lvl, A, x, y);   // trajectory.py:82-84
         e.u = round_sample<T>(A, e.u);
         e.v = round_sample<T>(A, e.v);
         y = y + lat_increment<T>(A, A.dtcy, e.v);                // :86
@@ -459,8 +493,8 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
                 clamp_position<T>(A, x, y);
                 continue;
             }
-            Pair<T> c = fetch<T, ORDER>(lvl, A, tap);             // :105,107
-            Pair<T> n = fetch<T, ORDER>(nxt, A, tap);             // :106,108
+            Pair<T> c = fetch<T, ORDER, RAW>(lvl, A, tap);        // :105,107
+            Pair<T> n = fetch<T, ORDER, RAW>(nxt, A, tap);        // :106,108
             c.u = round_sample<T>(A, c.u);
             c.v = round_sample<T>(A, c.v);
             n.u = round_sample<T>(A, n.u);
@@ -485,14 +519,26 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
 // workgroup's life (every sample a dependent global gather), and the workgroups of the last tile row would be the
 // launch's tail (measured on C3: 7.0 -> 6.7 ms without it).  So the launch starts with `pole_blocks` workgroups that
 // take those rows one seed per thread, all lanes busy, and the tiles skip them.  Same function, same results.
-template <typename T>
+// A pole-row seed: order 1 + 'constant' through the whole series, from the lin image or -- when the caller handed the raw
+// planes instead (lc_advect_ex) -- from those.  SRC: 0 = the lin image (float32 order-1 kernels: lin is their interior
+// image anyway, it always exists), 2 = the raw planes (kernel variants compiled for them), 1 = whichever the call has.
+constexpr int POLE_LIN = 0, POLE_EITHER = 1, POLE_RAW = 2;
+template <typename T, int SRC>
+__device__ __forceinline__ void pole_seed(const AdvectArgs<T> &A, int iy, int ix) {
+    if (SRC == POLE_RAW || (SRC == POLE_EITHER && A.u_raw))
+        advect_seed<T, 1, false, false, true>(A, A.u_raw, iy, ix);
+    else
+        advect_seed<T, 1, false>(A, A.lin, iy, ix);
+}
+
+template <typename T, int SRC = POLE_EITHER>
 __device__ __forceinline__ bool pole_block(const AdvectArgs<T> &A) {
     if ((int)blockIdx.x >= A.pole_blocks) return false;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < (A.pole_lo + A.pole_hi) * A.nx) {
         const int k = i / A.nx, ix = i - k * A.nx;
         const int iy = lcplan::pole_row(k, A.pole_lo, A.pole_hi, A.ny);
-        advect_seed<T, 1, false>(A, A.lin, iy, ix);
+        pole_seed<T, SRC>(A, iy, ix);
     }
     return true;
 }
@@ -520,7 +566,7 @@ template <typename T>
 __device__ __forceinline__ bool pole_block_group(const AdvectArgs<T> &A) {
     if ((int)blockIdx.x >= A.pole_blocks) return false;
     const int cnt = group_count(A);
-    for (int q = 0; q < cnt; ++q) pole_block(group_member(A, q));
+    for (int q = 0; q < cnt; ++q) pole_block<T, POLE_LIN>(group_member(A, q));  // (float32 order 1: the lin image is the interior image too)
     return true;
 }
 
@@ -982,7 +1028,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     constexpr int WOFF = ORDER == 3 ? 0 : LC_PAD_LO;  // padded window origin = (y0 + WOFF, x0 + WOFF)
     typedef EulerGeom<ORDER> E;
     __shared__ __attribute__((aligned(16))) f2 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH + E::ELEMS];
-    if (pole_block(A)) return;
+    if (pole_block<float, ORDER != 1 ? POLE_EITHER : POLE_LIN>(A)) return;
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
@@ -995,7 +1041,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     if (live) {
         const int grow = A.row0 + iy;
         if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path, whole integration (Q3)
-            if (!A.pole_blocks) advect_seed<float, 1, false>(A, A.lin, iy, ix);  // (else the leading workgroups did them)
+            if (!A.pole_blocks) pole_seed<float, ORDER != 1 ? POLE_EITHER : POLE_LIN>(A, iy, ix);  // (else the leading workgroups did them)
             live = false;
         }
     }
@@ -1313,7 +1359,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     __shared__ __attribute__((aligned(16))) f4 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
     // PATCH_LINES: two slabs (alternating by level) of the workgroup's 16 x 32 longitudes and latitudes
     __shared__ __attribute__((aligned(16))) float s_slab[2][2][LINES ? 16 * SLAB_PITCH : 4];
-    if (GROUP ? pole_block_group(A) : pole_block(A)) return;
+    if (GROUP ? pole_block_group(A) : pole_block<float, POLE_LIN>(A)) return;
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
@@ -1712,7 +1758,7 @@ struct PatchLanes {  // the lane's SPL seeds: where they are in the grid, their 
             if (live[q]) {
                 const int grow = A.row0 + iy;
                 if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path, whole integration (Q3)
-                    if (!A.pole_blocks) advect_seed<float, 1, false>(A, A.lin, iy, ix);  // (else the leading workgroups did them)
+                    if (!A.pole_blocks) pole_seed<float, POLE_EITHER>(A, iy, ix);  // (else the leading workgroups did them)
                     live[q] = false;
                 }
             }
@@ -2175,6 +2221,25 @@ __device__ __forceinline__ d2 sample_fast64(const double *__restrict__ lvl, cons
     return lerp_fast64(a, b, t.tx, t.ty);
 }
 
+// The same sample with the RAW planes of the level as the source (up = its u plane; lc_advect_ex): the window's rows are
+// two 16-byte loads per plane instead of one 32-byte load of interleaved nodes.  The image's pad node behind the last
+// node holds node n - 2 (mirror); the pair is loaded one node to the left there and swapped -- the same eight numbers.
+__device__ __forceinline__ d2 sample_fast64_raw(const double *__restrict__ up, const AdvectArgs<double> &A, double x, double y) {
+    const Loc64 t = locate_fast64(A, x, y);
+    const double *vp = up + (A.v_raw - A.u_raw);
+    const int xa = min(t.x0, A.nx_f - 2), y1 = t.y0 + 1 < A.ny_f ? t.y0 + 1 : A.ny_f - 2;
+    const size_t r0 = (size_t)t.y0 * A.nx_f + xa, r1 = (size_t)y1 * A.nx_f + xa;
+    d2 u0, v0, u1, v1;
+    __builtin_memcpy(&u0, up + r0, 16);
+    __builtin_memcpy(&v0, vp + r0, 16);
+    __builtin_memcpy(&u1, up + r1, 16);
+    __builtin_memcpy(&v1, vp + r1, 16);
+    const bool last = t.x0 > xa;  // x0 == nx_f - 1: window = {node n - 1, node n - 2}
+    const d4 a = last ? (d4){u0.y, v0.y, u0.x, v0.x} : (d4){u0.x, v0.x, u0.y, v0.y};
+    const d4 b = last ? (d4){u1.y, v1.y, u1.x, v1.x} : (d4){u1.x, v1.x, u1.y, v1.y};
+    return lerp_fast64(a, b, t.tx, t.ty);
+}
+
 // Order 3 in the fast float64 form: scipy's cubic B-spline weights as polynomials in t (cubic_weights_p in double) and the
 // 16 taps as four fused row sums combined by a fused column sum.  Shared by the direct and the LDS-tile kernel (explicit
 // operations: a seed's result must not depend on which of the two served it).  `w` points at the window's first node
@@ -2269,6 +2334,7 @@ __device__ void advect_seed_fast64_o3(const AdvectArgs<double> &A, int iy, int i
     A.y_out[idx] = y;
 }
 
+template <bool RAW>
 __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) {
 #pragma clang fp contract(fast)
     double x = start_x<double>(A, iy, ix), y = start_y<double>(A, iy, ix);
@@ -2280,10 +2346,12 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
         A.traj_x[idx] = x;
         A.traj_y[idx] = y;
     }
-    const double *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    // the Euler sample's source: the lin image, or the raw planes (then img is not read at all)
+    const size_t lstride = RAW ? A.raw_plane : A.level_elems;
+    const double *lvl = (RAW ? A.u_raw : A.img) + (size_t)A.t0 * lstride;
     const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
     for (int s = 0; s < A.nsteps; ++s) {
-        const d2 e = sample_fast64(lvl, A, x, y);       // trajectory.py:82-84
+        const d2 e = RAW ? sample_fast64_raw(lvl, A, x, y) : sample_fast64(lvl, A, x, y);   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                        // :86
         x = fma(dtcx, e.x, x);                          // :87
         clamp_position<double>(A, x, y);                // :89-97
@@ -2297,7 +2365,7 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
             A.traj_x[(size_t)(s + 1) * plane + idx] = x;
             A.traj_y[(size_t)(s + 1) * plane + idx] = y;
         }
-        lvl += A.level_elems;
+        lvl += lstride;
         elv += A.level_elems;
     }
     A.x_out[idx] = x;
@@ -2326,7 +2394,9 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
 #define LCS_LDS64_NUM_SGPR 0
 #endif
 constexpr int T64_COLS = 16, T64_ROWS = LCS_T64_ROWS, T64_PITCH = 17;  // nodes; rows shift 4 banks of 16 bytes
-template <int KFIX, bool CYCLIC>
+// RAW: the Euler sample (and the pole rows) from the raw planes of the level instead of the lin image (lc_advect_ex) -- a
+// compile-time variant: as a run-time choice the extra uniform state cost the kernel 9 vector registers and a wave per SIMD.
+template <int KFIX, bool CYCLIC, bool RAW>
 __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
 #if LCS_LDS64_NUM_SGPR > 0
     __attribute__((amdgpu_num_sgpr(LCS_LDS64_NUM_SGPR)))
@@ -2336,7 +2406,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
     const AdvectArgs<double> A = for_member(A0);
     const int K = KFIX >= 0 ? KFIX : A.K;
     __shared__ __attribute__((aligned(16))) d2 s_tiles[BLOCK / 64][T64_ROWS * T64_PITCH];
-    if (pole_block(A)) return;
+    if (pole_block<double, RAW ? POLE_RAW : POLE_LIN>(A)) return;
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
     const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
@@ -2348,7 +2418,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
     if (live) {
         const int grow = A.row0 + iy;
         if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path (Q3)
-            if (!A.pole_blocks) advect_seed<double, 1, false>(A, A.lin, iy, ix);
+            if (!A.pole_blocks) pole_seed<double, RAW ? POLE_RAW : POLE_LIN>(A, iy, ix);
             live = false;
         }
     }
@@ -2363,7 +2433,9 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
         A.traj_x[idx] = x;
         A.traj_y[idx] = y;
     }
-    const double *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    // the Euler sample's source: the lin image, or the raw planes (lc_advect_ex: then img is not read at all)
+    const size_t lstride = RAW ? A.raw_plane : A.level_elems;
+    const double *lvl = (RAW ? A.u_raw : A.img) + (size_t)A.t0 * lstride;
     const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
     constexpr int CENTRE = TILE_W / 2 + TILE_W * 4;  // middle seed of the wave's 8 x 8 patch
@@ -2386,9 +2458,9 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
 #pragma unroll
             for (int r = 0; r < T64_ROWS / 4; ++r) __builtin_memcpy(&stage[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
         }
-        // ---- 2. Euler sample: direct gather from img[t] ------------------------------------------------------------
+        // ---- 2. Euler sample: direct gather from img[t] (or the raw planes of level t) ---------------------------
         const double x0p = x, y0p = y;
-        const d2 e = sample_fast64(lvl, A, x, y);       // trajectory.py:82-84
+        const d2 e = RAW ? sample_fast64_raw(lvl, A, x, y) : sample_fast64(lvl, A, x, y);   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                        // :86
         x = fma(dtcx, e.x, x);                          // :87
         clamp_position<double>(A, x, y);                // :89-97
@@ -2436,7 +2508,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
             A.traj_x[(size_t)(s + 1) * plane + idx] = x;
             A.traj_y[(size_t)(s + 1) * plane + idx] = y;
         }
-        lvl += A.level_elems;
+        lvl += lstride;
         elv += A.level_elems;
     }
     if (live) {
@@ -2471,7 +2543,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs
     if (live) {
         const int grow = A.row0 + iy;
         if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path (Q3)
-            if (!A.pole_blocks) advect_seed<double, 1, false>(A, A.lin, iy, ix);
+            if (!A.pole_blocks) pole_seed<double, POLE_EITHER>(A, iy, ix);
             live = false;
         }
     }
@@ -2557,14 +2629,18 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs
     }
 }
 
-template <typename T, int ORDER, bool FUSED>
+// RAW (float64 at order 1 only): the order-1 source is the raw planes (lc_advect_ex; img == lin is not read)
+template <typename T, int ORDER, bool FUSED, bool RAW = false>
 struct InteriorPath {
     static __device__ __forceinline__ void run(const AdvectArgs<T> &A, int iy, int ix) {
-        advect_seed<T, ORDER, true, FUSED>(A, A.img, iy, ix);
+        if constexpr (RAW)
+            advect_seed<T, 1, true, false, true>(A, A.u_raw, iy, ix);   // exact order, two samples per iteration
+        else
+            advect_seed<T, ORDER, true, FUSED>(A, A.img, iy, ix);
     }
 };
 template <>
-struct InteriorPath<double, 3, true> {
+struct InteriorPath<double, 3, true, false> {
     static __device__ __forceinline__ void run(const AdvectArgs<double> &A, int iy, int ix) {
         if (A.wind_f32)
             advect_seed<double, 3, true, true>(A, A.img, iy, ix);  // (never launched: LC_F64_WIND_F32 takes no ext)
@@ -2572,17 +2648,14 @@ struct InteriorPath<double, 3, true> {
             advect_seed_fast64_o3(A, iy, ix);
     }
 };
-template <>
-struct InteriorPath<double, 1, true> {
+template <bool RAW>
+struct InteriorPath<double, 1, true, RAW> {
     static __device__ __forceinline__ void run(const AdvectArgs<double> &A, int iy, int ix) {
-        if (A.wind_f32)
-            advect_seed<double, 1, true, true>(A, A.img, iy, ix);  // (never launched: LC_F64_WIND_F32 takes no ext)
-        else
-            advect_seed_fast64(A, iy, ix);
+        advect_seed_fast64<RAW>(A, iy, ix);  // (LC_F64_WIND_F32 takes no ext: never launched in this form)
     }
 };
 template <int ORDER, bool FUSED>
-struct InteriorPath<float, ORDER, FUSED> {
+struct InteriorPath<float, ORDER, FUSED, false> {
     static __device__ __forceinline__ void run(const AdvectArgs<float> &A, int iy, int ix) {
         if (ORDER == 1 || ORDER == 3)
             advect_seed_f32<ORDER>(A, iy, ix);  // looks at A.ext itself
@@ -2593,10 +2666,14 @@ struct InteriorPath<float, ORDER, FUSED> {
 
 // double, order 1 sits at 69 VGPRs (7 waves per SIMD); asking for 8 costs nothing measurable per wave and
 // lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
-template <typename T, int ORDER, bool FUSED>
+template <typename T, int ORDER, bool FUSED, bool RAW = false>
 __device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A0) {
     const AdvectArgs<T> A = for_member(A0);
-    if (pole_block(A)) return;
+    static_assert(!RAW || (sizeof(T) == 8 && ORDER == 1), "RAW variants exist for float64 at order 1 (the others choose per call)");
+    // order-1 source of the pole rows: float64 at order 1 has its own kernel variants for the raw planes (held to 64
+    // registers, a run-time choice spills); float32 at order 1 always has the lin image; everything else: per call
+    constexpr int PSRC = (sizeof(T) == 8 && ORDER == 1) ? (RAW ? POLE_RAW : POLE_LIN) : ((sizeof(T) == 8 || ORDER != 1) ? POLE_EITHER : POLE_LIN);
+    if (pole_block<T, PSRC>(A)) return;
     const int tile = xcd_tile_id(A);  // tile rows dealt to the XCDs cyclically (see xcd_tile_id)
     if (tile >= A.ntiles) return;
     const int tyi = tile / A.ntx, txi = tile - tyi * A.ntx;
@@ -2606,16 +2683,16 @@ __device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A0) {
     const int grow = A.row0 + iy;
     const bool pole = grow < A.order || grow >= A.ny_global - A.order;  // tools.py:24-33 (Q3)
     if (pole) {
-        if (!A.pole_blocks) advect_seed<T, 1, false>(A, A.lin, iy, ix);  // (else the leading workgroups did them)
+        if (!A.pole_blocks) pole_seed<T, PSRC>(A, iy, ix);  // (else the leading workgroups did them)
     } else
-        InteriorPath<T, ORDER, FUSED>::run(A, iy, ix);
+        InteriorPath<T, ORDER, FUSED, RAW>::run(A, iy, ix);
 }
 
 // double, order 1 sits at 69 VGPRs (7 waves per SIMD); asking for 8 costs nothing measurable per wave and
 // lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
-template <typename T, int ORDER, bool FUSED = false>
+template <typename T, int ORDER, bool FUSED = false, bool RAW = false>
 __global__ void __launch_bounds__(BLOCK, (sizeof(T) == 8 && ORDER == 1) ? 8 : 1) advect_kernel(const AdvectArgs<T> A) {
-    advect_kernel_body<T, ORDER, FUSED>(A);
+    advect_kernel_body<T, ORDER, FUSED, RAW>(A);
 }
 
 // float: 98 SGPRs as compiled would admit 6 workgroups per CU instead of 7 (MI355X_MICROARCH.md: 97-112 -> 6);
@@ -2643,18 +2720,23 @@ struct Lds64Launch<double> {
     // the wind is float32-valued (numpy promotion path), K = 0, or the field is smaller than a tile
     static const char *launch(const AdvectArgs<double> &A, int grid, hipStream_t st, int mode) {
         if (mode == 0 || A.wind_f32 || A.K == 0 || !A.ext || A.nx_f + LC_PAD < T64_COLS || A.ny_f + LC_PAD < T64_ROWS) return nullptr;
-        if (A.K == 4 && A.cyclic) {
-            hipLaunchKernelGGL((advect_lds64_kernel<4, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-            return "advect_lds64_kernel<4, true>";
-        } else if (A.K == 4) {
-            hipLaunchKernelGGL((advect_lds64_kernel<4, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-            return "advect_lds64_kernel<4, false>";
-        } else if (A.cyclic) {
-            hipLaunchKernelGGL((advect_lds64_kernel<-1, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-            return "advect_lds64_kernel<-1, true>";
+        // (names as a profiler prints them; the last argument: order-1 source = the raw planes, lc_advect_ex)
+#define LC_LDS64(KF, CY, RW, NAME)                                                                                  \
+    {                                                                                                               \
+        hipLaunchKernelGGL((advect_lds64_kernel<KF, CY, RW>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);          \
+        return NAME;                                                                                                \
+    }
+        if (A.u_raw) {
+            if (A.K == 4 && A.cyclic) LC_LDS64(4, true, true, "advect_lds64_kernel<4, true, true>")
+            if (A.K == 4) LC_LDS64(4, false, true, "advect_lds64_kernel<4, false, true>")
+            if (A.cyclic) LC_LDS64(-1, true, true, "advect_lds64_kernel<-1, true, true>")
+            LC_LDS64(-1, false, true, "advect_lds64_kernel<-1, false, true>")
         }
-        hipLaunchKernelGGL((advect_lds64_kernel<-1, false>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-        return "advect_lds64_kernel<-1, false>";
+        if (A.K == 4 && A.cyclic) LC_LDS64(4, true, false, "advect_lds64_kernel<4, true, false>")
+        if (A.K == 4) LC_LDS64(4, false, false, "advect_lds64_kernel<4, false, false>")
+        if (A.cyclic) LC_LDS64(-1, true, false, "advect_lds64_kernel<-1, true, false>")
+        LC_LDS64(-1, false, false, "advect_lds64_kernel<-1, false, false>")
+#undef LC_LDS64
     }
     // order 3 (SETTLS_order = 0 included: the Euler sample has its own tile)
     static const char *launch_o3(const AdvectArgs<double> &A, int grid, hipStream_t st, int mode) {
@@ -2677,10 +2759,17 @@ struct Lds64Launch<double> {
 template <typename T, int ORDER>
 struct DirectLaunch {
     static const char *launch(const AdvectArgs<T> &A, int grid, hipStream_t st) {
+        if constexpr (ORDER == 1 && sizeof(T) == 8) {
+            if (A.u_raw) {  // exact order with the raw planes as the order-1 source (lc_advect_ex)
+                hipLaunchKernelGGL((advect_kernel<T, 1, false, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+                return "advect_kernel<double, 1, false, true>";
+            }
+        }
         hipLaunchKernelGGL((advect_kernel<T, ORDER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-        return ORDER == 1 ? "advect_kernel<double, 1, false>" : ORDER == 2 ? "advect_kernel<double, 2, false>"
-             : ORDER == 3 ? "advect_kernel<double, 3, false>" : ORDER == 4 ? "advect_kernel<double, 4, false>"
-                                                                           : "advect_kernel<double, 5, false>";
+        // (as a profiler prints them: all four template arguments)
+        return ORDER == 1 ? "advect_kernel<double, 1, false, false>" : ORDER == 2 ? "advect_kernel<double, 2, false, false>"
+             : ORDER == 3 ? "advect_kernel<double, 3, false, false>" : ORDER == 4 ? "advect_kernel<double, 4, false, false>"
+                                                                                  : "advect_kernel<double, 5, false, false>";
     }
 };
 template <int ORDER>
@@ -2737,9 +2826,13 @@ __global__ void outer_substep_kernel(const AdvectArgs<T> A, const OuterArgs<T> O
         const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((ys * T(3.141592653589793)) / T(180))));
         const int grow = A.row0 + iy;
         const bool pole = grow < A.order || grow >= A.ny_global - A.order;  // tools.py:24-33 (Q3), global row index
-        const T *lvl = (pole ? A.lin : A.img) + (size_t)level * A.level_elems;
+        // order-1 source: the raw planes when the caller handed those instead of the lin image (lc_advect_ex)
+        const bool raw = A.u_raw && (pole || ORDER == 1);
+        const size_t lstride = raw ? A.raw_plane : A.level_elems;
+        const T *lvl = (raw ? A.u_raw : (pole ? A.lin : A.img)) + (size_t)level * lstride;
         if (!is_iter) {
-            Pair<T> e = pole ? sample<T, 1, false>(lvl, A, x, y) : sample<T, ORDER, true>(lvl, A, x, y);
+            Pair<T> e = raw ? (pole ? sample<T, 1, false, true>(lvl, A, x, y) : sample<T, 1, true, true>(lvl, A, x, y))
+                            : (pole ? sample<T, 1, false>(lvl, A, x, y) : sample<T, ORDER, true>(lvl, A, x, y));
             e.u = round_sample<T>(A, e.u);
             e.v = round_sample<T>(A, e.v);
             O.eu[i] = e.u;
@@ -2747,9 +2840,13 @@ __global__ void outer_substep_kernel(const AdvectArgs<T> A, const OuterArgs<T> O
             y = y + lat_increment<T>(A, A.dtcy, e.v);          // trajectory.py:86
             x = axpy<T>(A.dt * cx_conv, e.u, x);               // :87
         } else {
-            const T *nxt = lvl + A.level_elems;
+            const T *nxt = lvl + lstride;
             Pair<T> c, nn;
-            if (pole) {
+            if (raw) {
+                const Tap<T> tap = pole ? locate<T, 1, false>(A, x, y) : locate<T, 1, true>(A, x, y);
+                c = fetch<T, 1, true>(lvl, A, tap);
+                nn = fetch<T, 1, true>(nxt, A, tap);
+            } else if (pole) {
                 const Tap<T> tap = locate<T, 1, false>(A, x, y);
                 c = fetch<T, 1>(lvl, A, tap);
                 nn = fetch<T, 1>(nxt, A, tap);
@@ -2881,8 +2978,8 @@ reduce_failed:
 }
 
 template <typename T>
-int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *packed_ext, int nt, int ny_f,
-                int nx_f,
+int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *packed_ext, const void *u_raw,
+                const void *v_raw, int nt, int ny_f, int nx_f,
                 double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
                 int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, const void *x_start,
@@ -2904,6 +3001,9 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.lin = (const T *)packed_lin;
     A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
     A.ext = (order == 1 || order == 3) ? (const T *)packed_ext : nullptr;  // general orders: two-sample form
+    A.u_raw = (const T *)u_raw;  // (lc_advect_ex validated: only where a kernel reads them)
+    A.v_raw = (const T *)v_raw;
+    A.raw_plane = (size_t)ny_f * nx_f;
     A.level_elems = lc_level_elems(ny_f, nx_f);
     A.pitch = nx_f + LC_PAD;
     A.ny_f = ny_f;
@@ -2980,7 +3080,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 name = Lds64Launch<T>::launch_o3(A, grid, ctx->stream, ctx->lds_tiles);
                 if (!name) {
                     hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
-                    name = "advect_kernel<double, 3, true>";
+                    name = "advect_kernel<double, 3, true, false>";
                 }
             } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
                 name = DirectLaunch<T, 3>::launch(A, grid, ctx->stream);
@@ -2989,8 +3089,15 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
             if (fused64) {
                 name = Lds64Launch<T>::launch(A, grid, ctx->stream, ctx->lds_tiles);
                 if (!name) {
-                    hipLaunchKernelGGL((advect_kernel<T, 1, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
-                    name = "advect_kernel<double, 1, true>";
+                    if constexpr (sizeof(T) == 8) {
+                        if (A.u_raw) {
+                            hipLaunchKernelGGL((advect_kernel<T, 1, true, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
+                            name = "advect_kernel<double, 1, true, true>";
+                        } else {
+                            hipLaunchKernelGGL((advect_kernel<T, 1, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
+                            name = "advect_kernel<double, 1, true, false>";
+                        }
+                    }
                 }
             } else if (!(use_lds && (name = LdsLaunch<T, 1>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
                 name = DirectLaunch<T, 1>::launch(A, grid, ctx->stream);
@@ -3122,7 +3229,10 @@ __global__ void sample_kernel(const AdvectArgs<T> A, const T *__restrict__ px, c
         const int grow = A.row0 + iy;
         const bool pole = grow < A.order || grow >= A.ny_global - A.order;
         Pair<T> r;
-        if (pole)
+        if (A.u_raw && (pole || ORDER == 1)) {  // order-1 source: the raw planes (lc_sample_ex)
+            const T *up = A.u_raw + (size_t)level * A.raw_plane;
+            r = pole ? sample<T, 1, false, true>(up, A, px[i], py[i]) : sample<T, 1, true, true>(up, A, px[i], py[i]);
+        } else if (pole)
             r = sample<T, 1, false>(A.lin + (size_t)level * A.level_elems, A, px[i], py[i]);
         else
             r = sample<T, ORDER, true>(A.img + (size_t)level * A.level_elems, A, px[i], py[i]);
@@ -3132,12 +3242,15 @@ __global__ void sample_kernel(const AdvectArgs<T> A, const T *__restrict__ px, c
 }
 
 template <typename T>
-int sample_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int ny_f, int nx_f, double lat_min,
+int sample_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *u_raw, const void *v_raw, int ny_f, int nx_f, double lat_min,
                 double lat_max, double lon_min, double lon_max, int level, const void *px, const void *py, int ny,
                 int nx, int row0, int ny_global, int order, void *out_u, void *out_v) {
     AdvectArgs<T> A = {};
     A.lin = (const T *)packed_lin;
     A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
+    A.u_raw = (const T *)u_raw;
+    A.v_raw = (const T *)v_raw;
+    A.raw_plane = (size_t)ny_f * nx_f;
     A.level_elems = lc_level_elems(ny_f, nx_f);
     A.pitch = nx_f + LC_PAD;
     A.ny_f = ny_f;
@@ -3198,27 +3311,43 @@ extern "C" int lc_debug_read_stamps(unsigned long long *out8, int reset) {
 }
 #endif
 
-extern "C" int lc_sample(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype, int nt, int ny_f,
-                         int nx_f, double lat_min, double lat_max, double lon_min, double lon_max, int level,
-                         const void *pos_x_dev, const void *pos_y_dev, int ny, int nx, int row0, int ny_global,
-                         int interp_order, void *out_u, void *out_v) {
+// order-1 source of a call: may the lin image be absent?  (raw planes given, and a kernel family that reads them)
+static bool raw_replaces_lin(const void *u_raw, const void *v_raw, int dtype, int interp_order) {
+    return u_raw && v_raw && (interp_order != 1 || dtype != LC_F32);
+}
+
+extern "C" int lc_sample_raw(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *u_raw, const void *v_raw,
+                             int dtype, int nt, int ny_f, int nx_f, double lat_min, double lat_max, double lon_min,
+                             double lon_max, int level, const void *pos_x_dev, const void *pos_y_dev, int ny, int nx, int row0,
+                             int ny_global, int interp_order, void *out_u, void *out_v) {
     LC_REQUIRE(ctx, "lc_sample: null context");
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_sample: bad dtype %d", dtype);
     if (interp_order < 1 || interp_order > 5) {
         lc_set_error("lc_sample: interp_order %d unsupported (scipy's spline orders 1..5; 0 fails in the reference)", interp_order);
         return LC_EUNSUPPORTED;
     }
-    LC_REQUIRE(packed_lin && (interp_order == 1 || packed_cub), "lc_sample: missing field image");
+    LC_REQUIRE((u_raw == nullptr) == (v_raw == nullptr), "lc_sample_raw: u_raw and v_raw must both be set or both NULL");
+    LC_REQUIRE((packed_lin || raw_replaces_lin(u_raw, v_raw, dtype, interp_order)) && (interp_order == 1 || packed_cub),
+               "lc_sample: missing field image");
     LC_REQUIRE(pos_x_dev && pos_y_dev && out_u && out_v, "lc_sample: null pointer");
     LC_REQUIRE(level >= 0 && level < nt && ny_f >= 4 && nx_f >= 4 && ny >= 1 && nx >= 1, "lc_sample: bad sizes");
     LC_REQUIRE(row0 >= 0 && row0 + ny <= ny_global, "lc_sample: rows outside the global grid");
     LC_REQUIRE(lat_max > lat_min && lon_max > lon_min, "lc_sample: field coordinates must be ascending");
     LC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!raw_replaces_lin(u_raw, v_raw, dtype, interp_order)) u_raw = v_raw = nullptr;
     if (dtype == LC_F32)
-        return sample_impl<float>(ctx, packed_lin, packed_cub, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, level,
+        return sample_impl<float>(ctx, packed_lin, packed_cub, u_raw, v_raw, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, level,
                                   pos_x_dev, pos_y_dev, ny, nx, row0, ny_global, interp_order, out_u, out_v);
-    return sample_impl<double>(ctx, packed_lin, packed_cub, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, level,
+    return sample_impl<double>(ctx, packed_lin, packed_cub, u_raw, v_raw, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, level,
                                pos_x_dev, pos_y_dev, ny, nx, row0, ny_global, interp_order, out_u, out_v);
+}
+
+extern "C" int lc_sample(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, int dtype, int nt, int ny_f,
+                         int nx_f, double lat_min, double lat_max, double lon_min, double lon_max, int level,
+                         const void *pos_x_dev, const void *pos_y_dev, int ny, int nx, int row0, int ny_global,
+                         int interp_order, void *out_u, void *out_v) {
+    return lc_sample_raw(ctx, packed_lin, packed_cub, nullptr, nullptr, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
+                         level, pos_x_dev, pos_y_dev, ny, nx, row0, ny_global, interp_order, out_u, out_v);
 }
 
 extern "C" int lc_advect(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, const void *packed_ext,
@@ -3248,7 +3377,55 @@ extern "C" int lc_advect_batch(lc_ctx *ctx, const void *packed_lin, const void *
                                int ny_global, const void *x_start, const void *y_start, double timestep, int settls_order,
                                int interp_order, int cyclic_x, int t0, int nsteps, int n_members, int t0_stride, void *x_out,
                                void *y_out, void *traj_x, void *traj_y) {
+    lc_advect_args a = {};
+    a.struct_size = sizeof(a);
+    a.packed_lin = packed_lin;
+    a.packed_cub = packed_cub;
+    a.packed_ext = packed_ext;
+    a.dtype = dtype;
+    a.nt = nt;
+    a.ny_f = ny_f;
+    a.nx_f = nx_f;
+    a.lat_min = lat_min;
+    a.lat_max = lat_max;
+    a.lon_min = lon_min;
+    a.lon_max = lon_max;
+    a.seed_lat_dev = seed_lat_dev;
+    a.ny = ny;
+    a.seed_lon_dev = seed_lon_dev;
+    a.nx = nx;
+    a.row0 = row0;
+    a.ny_global = ny_global;
+    a.x_start = x_start;
+    a.y_start = y_start;
+    a.timestep = timestep;
+    a.settls_order = settls_order;
+    a.interp_order = interp_order;
+    a.cyclic_x = cyclic_x;
+    a.t0 = t0;
+    a.nsteps = nsteps;
+    a.n_members = n_members;
+    a.t0_stride = t0_stride;
+    a.x_out = x_out;
+    a.y_out = y_out;
+    a.traj_x = traj_x;
+    a.traj_y = traj_y;
+    return lc_advect_ex(ctx, &a);
+}
+
+extern "C" int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args) {
+    LC_REQUIRE(args, "lc_advect_ex: null arguments");
+    LC_REQUIRE(args->struct_size == sizeof(lc_advect_args), "lc_advect_ex: struct_size %zu, this library's lc_advect_args has %zu bytes",
+               args->struct_size, sizeof(lc_advect_args));
     LC_REQUIRE(ctx, "lc_advect: null context");
+    const lc_advect_args &a = *args;
+    const void *packed_lin = a.packed_lin, *packed_cub = a.packed_cub, *packed_ext = a.packed_ext, *u_raw = a.u_raw, *v_raw = a.v_raw;
+    const int dtype = a.dtype, nt = a.nt, ny_f = a.ny_f, nx_f = a.nx_f, ny = a.ny, nx = a.nx, row0 = a.row0, ny_global = a.ny_global;
+    const int settls_order = a.settls_order, interp_order = a.interp_order, cyclic_x = a.cyclic_x, t0 = a.t0, nsteps = a.nsteps;
+    const int n_members = a.n_members, t0_stride = a.t0_stride;
+    const void *x_start = a.x_start, *y_start = a.y_start, *seed_lat_dev = a.seed_lat_dev, *seed_lon_dev = a.seed_lon_dev;
+    void *x_out = a.x_out, *y_out = a.y_out, *traj_x = a.traj_x, *traj_y = a.traj_y;
+    const double lat_min = a.lat_min, lat_max = a.lat_max, lon_min = a.lon_min, lon_max = a.lon_max, timestep = a.timestep;
     LC_REQUIRE(n_members >= 1 && n_members <= 65535 && t0_stride >= 0, "lc_advect_batch: bad n_members %d / t0_stride %d", n_members,
                t0_stride);
     if (n_members > 1) {
@@ -3271,7 +3448,11 @@ extern "C" int lc_advect_batch(lc_ctx *ctx, const void *packed_lin, const void *
                      interp_order);
         return LC_EUNSUPPORTED;
     }
-    LC_REQUIRE(packed_lin, "lc_advect: packed_lin is required (pole rows use order 1)");
+    LC_REQUIRE((u_raw == nullptr) == (v_raw == nullptr), "lc_advect_ex: u_raw and v_raw must both be set or both NULL");
+    const bool raw_ok = raw_replaces_lin(u_raw, v_raw, dtype, interp_order);
+    LC_REQUIRE(packed_lin || raw_ok, "lc_advect: packed_lin is required (the order-1 image: pole rows use order 1) unless lc_advect_ex is "
+               "given the raw planes u_raw / v_raw -- and in LC_F32 at interp_order 1 always");
+    if (!raw_ok) u_raw = v_raw = nullptr;  // (float32 at order 1 reads the lin image's 16-byte node pairs)
     LC_REQUIRE(interp_order == 1 || packed_cub, "lc_advect: interp_order > 1 needs packed_cub (lc_field_pack of that order)");
     LC_REQUIRE(interp_order == 1 || interp_order == 3 || !packed_ext, "lc_advect: orders 2, 4, 5 take no packed_ext");
     LC_REQUIRE(nt >= 2 && ny_f >= 4 && nx_f >= 4, "lc_advect: field too small (nt=%d ny_f=%d nx_f=%d)", nt, ny_f, nx_f);
@@ -3299,12 +3480,12 @@ extern "C" int lc_advect_batch(lc_ctx *ctx, const void *packed_lin, const void *
     }
     LC_HIP_CHECK(hipSetDevice(ctx->device));
     if (dtype == LC_F32)
-        return advect_impl<float>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
-                                  seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
+        return advect_impl<float>(ctx, packed_lin, packed_cub, packed_ext, u_raw, v_raw, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
+                                  lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                   interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start, 0,
                                   n_members, t0_stride);
-    return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max,
-                               seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
+    return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, u_raw, v_raw, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
+                               lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start,
                                dtype == LC_F64_WIND_F32, n_members, t0_stride);
 }

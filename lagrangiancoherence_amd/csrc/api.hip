@@ -108,6 +108,49 @@ extern "C" int lc_ctx_get_f64_fidelity(const lc_ctx *ctx, int *mode_out) {
     return LC_OK;
 }
 
+// lc_advect with the raw planes as the order-1 source where a kernel reads them (lc_advect_ex): the host routes then
+// neither allocate nor pack the order-1 image
+static bool host_route_needs_lin(int dtype, int interp_order) { return dtype == LC_F32 && interp_order == 1; }
+static int advect_with_raw(lc_ctx *ctx, const void *lin, const void *cub, const void *ext, const void *u, const void *v, int dtype,
+                           int nt, int ny_f, int nx_f, double lat_min, double lat_max, double lon_min, double lon_max,
+                           const void *slat, int ny, const void *slon, int nx, double timestep, int K, int order, int cyclic_x,
+                           int t0, int nsteps, void *x, void *y, void *tx, void *ty) {
+    lc_advect_args a = {};
+    a.struct_size = sizeof(a);
+    a.packed_lin = lin;
+    a.packed_cub = cub;
+    a.packed_ext = ext;
+    a.u_raw = u;
+    a.v_raw = v;
+    a.dtype = dtype;
+    a.nt = nt;
+    a.ny_f = ny_f;
+    a.nx_f = nx_f;
+    a.lat_min = lat_min;
+    a.lat_max = lat_max;
+    a.lon_min = lon_min;
+    a.lon_max = lon_max;
+    a.seed_lat_dev = slat;
+    a.ny = ny;
+    a.seed_lon_dev = slon;
+    a.nx = nx;
+    a.row0 = 0;
+    a.ny_global = ny;
+    a.timestep = timestep;
+    a.settls_order = K;
+    a.interp_order = order;
+    a.cyclic_x = cyclic_x;
+    a.t0 = t0;
+    a.nsteps = nsteps;
+    a.n_members = 1;
+    a.t0_stride = 0;
+    a.x_out = x;
+    a.y_out = y;
+    a.traj_x = tx;
+    a.traj_y = ty;
+    return lc_advect_ex(ctx, &a);
+}
+
 // float64 on the one-call host routes: the reference's operation order (no fused-level image) or the fast form
 static bool f64_exact_order(const lc_ctx *ctx, int dtype, int ny, int nx) {
     if (dtype != LC_F64) return false;
@@ -207,7 +250,9 @@ extern "C" int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, 
                              int interp_order, void *packed_dev, void *ext_dev) {
     LC_REQUIRE(ctx, "lc_field_pack: null context");
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_field_pack: bad dtype %d", dtype);
-    LC_REQUIRE(u_dev && v_dev && packed_dev, "lc_field_pack: null pointer");
+    LC_REQUIRE(u_dev && v_dev, "lc_field_pack: null pointer");
+    LC_REQUIRE(packed_dev || (interp_order == 1 && ext_dev && nt >= 2),
+               "lc_field_pack: packed_dev may only be NULL at interp_order 1 with ext_dev set (fused-level image alone)");
     LC_REQUIRE(nt >= 1 && ny_f >= 4 && nx_f >= 4, "lc_field_pack: field too small (nt=%d ny_f=%d nx_f=%d)", nt, ny_f,
                nx_f);
     if (interp_order < 1 || interp_order > 5) {
@@ -392,7 +437,8 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     DevBuf u, v, lin, cub, ext, slat, slon, x, y, tx, ty, sig, gx, gy, gtmp;
     LC_TRY(u.alloc(fbytes));
     LC_TRY(v.alloc(fbytes));
-    LC_TRY(lin.alloc(pbytes));
+    const bool need_lin = host_route_needs_lin(dtype, interp_order);
+    if (need_lin) LC_TRY(lin.alloc(pbytes));
     if (interp_order != 1) LC_TRY(cub.alloc(pbytes));
     LC_TRY(slat.alloc(ny * es));
     LC_TRY(slon.alloc(nx * es));
@@ -411,10 +457,11 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     // size / setting where the reference's own operation order is kept (lc_ctx_set_f64_fidelity)
     const bool fusable = (interp_order == 1 || interp_order == 3) && !f64_exact_order(ctx, dtype, ny, nx);
     if (settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
-    LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
+    if (need_lin || (interp_order == 1 && ext.p))
+        LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
     if (interp_order != 1) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, interp_order, cub.p, ext.p));
-    LC_TRY(lc_advect(ctx, lin.p, cub.p, ext.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p,
-                     nx, 0, ny, timestep, settls_order, interp_order, cyclic_x, t0, nsteps, x.p, y.p, tx.p, ty.p));
+    LC_TRY(advect_with_raw(ctx, lin.p, cub.p, ext.p, u.p, v.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny,
+                           slon.p, nx, timestep, settls_order, interp_order, cyclic_x, t0, nsteps, x.p, y.p, tx.p, ty.p));
     if (sigma_out) {
         LC_TRY(sig.alloc(sbytes));
         const void *xs = x.p, *ys = y.p;
@@ -532,18 +579,21 @@ extern "C" int lc_lcs_global_host(lc_ctx *ctx, const void *u_host, const void *v
     LC_HIP_CHECK(hipMemcpyAsync(slon.p, ho.data(), nx * es, hipMemcpyHostToDevice, st));
     LC_HIP_CHECK(hipStreamSynchronize(st));  // hl / ho are pageable locals
     const size_t pbytes = lc_packed_elems(nt, ny, nx) * es;
-    LC_TRY(lin.alloc(pbytes));
+    const bool need_lin = host_route_needs_lin(wdtype, interp_order);
+    if (need_lin) LC_TRY(lin.alloc(pbytes));
     if (interp_order != 1) LC_TRY(cub.alloc(pbytes));
     const bool fusable = (interp_order == 1 || interp_order == 3) && !f64_exact_order(ctx, wdtype, ny, nx);
     if (settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny, nx) * es));
-    LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
+    if (need_lin || (interp_order == 1 && ext.p))
+        LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
     if (interp_order != 1) LC_TRY(lc_field_pack(ctx, uw, vw, wdtype, nt, ny, nx, interp_order, cub.p, ext.p));
     LC_TRY(x.alloc(sbytes));
     LC_TRY(y.alloc(sbytes));
     const double lat_min = wdtype == LC_F32 ? (double)(float)lat[0] : lat[0], lat_max = wdtype == LC_F32 ? (double)(float)lat[ny - 1] : lat[ny - 1];
     const double lon_min = wdtype == LC_F32 ? (double)(float)lon[0] : lon[0], lon_max = wdtype == LC_F32 ? (double)(float)lon[nx - 1] : lon[nx - 1];
-    LC_TRY(lc_advect(ctx, lin.p, cub.p, ext.p, wdtype, nt, ny, nx, lat_min, lat_max, lon_min, lon_max, slat.p, ny, slon.p, nx, 0,
-                     ny, timestep, settls_order, interp_order, LC_X_CYCLIC /* LCS.py:119 */, 0, nt - 1, x.p, y.p, nullptr, nullptr));
+    LC_TRY(advect_with_raw(ctx, lin.p, cub.p, ext.p, uw, vw, wdtype, nt, ny, nx, lat_min, lat_max, lon_min, lon_max, slat.p, ny,
+                           slon.p, nx, timestep, settls_order, interp_order, LC_X_CYCLIC /* LCS.py:119 */, 0, nt - 1, x.p, y.p,
+                           nullptr, nullptr));
     if (sigma_out) {
         LC_REQUIRE(ny >= 5 && nx >= 5, "lc_lcs_global_host: sigma needs at least a 5x5 grid");
         LC_TRY(sig.alloc(sbytes));

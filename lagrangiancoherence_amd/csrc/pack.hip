@@ -603,6 +603,13 @@ __global__ void __launch_bounds__(64) prefilter_rows_stream_kernel(double *__res
 #else
 #define LCS_PACK_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)
 #endif
+// A thread walks PACK_LV consecutive time levels of its node and carries level t+1 forward, so every raw level is read
+// ONCE (plus one level in PACK_LV at the chunk's end) instead of twice -- as F[t] for lin[t] / ext[t] and again as F[t+1]
+// for ext[t-1]: float64 config 2 moved 13.9 GB for 10.1 GB compulsory that way (profiles/r03/c2_pmc_traffic.json).  The
+// loads of a chunk are issued together (static trip count), then the stores.
+// lin == NULL: the fused-level image alone (lc_field_pack(order 1, packed_dev = NULL): the caller samples order 1 from
+// the raw planes, lc_advect_ex).
+constexpr int PACK_LV = 8;
 template <typename T>
 __global__ void __launch_bounds__(256) pack_fused_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ lin,
                                                          T *__restrict__ ext, int nt, int ny, int nx) {
@@ -611,23 +618,35 @@ __global__ void __launch_bounds__(256) pack_fused_kernel(const T *__restrict__ u
     if (px >= pitch) return;
     const size_t plane = (size_t)ny * nx, level = (size_t)(ny + LC_PAD) * pitch;
     const int sx = mirror_index(px - LC_PAD_LO, nx);
-    for (int py = blockIdx.y; py < ny + LC_PAD; py += gridDim.y) {     // (the grid covers every row and level unless
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    for (int py = blockIdx.y; py < ny + LC_PAD; py += gridDim.y) {     // (the grid covers every row and level chunk unless
         const int sy = mirror_index(py - LC_PAD_LO, ny);               //  a dimension exceeds 65535 blocks)
         const size_t so = (size_t)sy * nx + sx, po = (size_t)py * pitch + px;
-        for (int t = blockIdx.z; t < nt; t += gridDim.z) {
-            const T *us = u + (size_t)t * plane, *vs = v + (size_t)t * plane;
-            const T a = us[so], b = vs[so];
-            typedef T T2 __attribute__((ext_vector_type(2)));
-            LCS_PACK_STORE((T2 *)(lin + ((size_t)t * level + po) * 2), ((T2){a, b}));
-            if (ext && t + 1 < nt)
-                LCS_PACK_STORE((T2 *)(ext + ((size_t)t * level + po) * 2), ((T2){T(2) * a - us[plane + so], T(2) * b - vs[plane + so]}));
+        for (int t0 = blockIdx.z * PACK_LV; t0 < nt; t0 += gridDim.z * PACK_LV) {
+            T a[PACK_LV + 1], b[PACK_LV + 1];
+#pragma unroll
+            for (int q = 0; q <= PACK_LV; ++q) {
+                const size_t t = (size_t)min(t0 + q, nt - 1);          // (past the series: the last level again, never used)
+                a[q] = u[t * plane + so];
+                b[q] = v[t * plane + so];
+            }
+#pragma unroll
+            for (int q = 0; q < PACK_LV; ++q) {
+                const int t = t0 + q;
+                if (t >= nt) break;
+                if (lin) LCS_PACK_STORE((T2 *)(lin + ((size_t)t * level + po) * 2), ((T2){a[q], b[q]}));
+                if (ext && t + 1 < nt)
+                    LCS_PACK_STORE((T2 *)(ext + ((size_t)t * level + po) * 2), ((T2){T(2) * a[q] - a[q + 1], T(2) * b[q] - b[q + 1]}));
+            }
         }
     }
 }
 
 // Pads of img and the whole of ext = 2*img[t] - img[t+1] in one pass over the padded levels: every padded node
 // reads its mirrored interior source at levels t and t+1 (interior nodes are final by now), writes its own pad
-// of img[t] if it is one, and its node of ext[t].  Replaces fill_pads_kernel + extrapolate_kernel.
+// of img[t] if it is one, and its node of ext[t].  Replaces fill_pads_kernel + extrapolate_kernel.  Level t+1 is
+// carried forward over PACK_LV levels as in pack_fused_kernel: each level of the image is read once (float64 config 2 at
+// order 3: 10.4 -> 7.0 GB moved).
 template <typename T>
 __global__ void __launch_bounds__(256) pads_ext_kernel(T *__restrict__ img, T *__restrict__ ext, int nt, int ny, int nx) {
     // same decomposition as pack_fused_kernel: 256 nodes of one padded row per block, no integer division
@@ -636,20 +655,21 @@ __global__ void __launch_bounds__(256) pads_ext_kernel(T *__restrict__ img, T *_
     if (px >= pitch) return;
     const size_t level = (size_t)(ny + LC_PAD) * pitch;
     const int x = px - LC_PAD_LO, sx = mirror_index(x, nx);
+    typedef T T2 __attribute__((ext_vector_type(2)));
     for (int py = blockIdx.y; py < ny + LC_PAD; py += gridDim.y) {
         const int y = py - LC_PAD_LO, sy = mirror_index(y, ny);
         const bool pad = !(y >= 0 && y < ny && x >= 0 && x < nx);
         const size_t so = ((size_t)(sy + LC_PAD_LO) * pitch + (sx + LC_PAD_LO)) * 2, po = ((size_t)py * pitch + px) * 2;
-        for (int t = blockIdx.z; t < nt; t += gridDim.z) {
-            T *lv = img + (size_t)t * level * 2;
-            const T a = lv[so], b = lv[so + 1];
-            if (pad) {
-                lv[po] = a;
-                lv[po + 1] = b;
-            }
-            if (t + 1 < nt) {
-                typedef T T2 __attribute__((ext_vector_type(2)));
-                LCS_PACK_STORE((T2 *)(ext + (size_t)t * level * 2 + po), ((T2){T(2) * a - lv[level * 2 + so], T(2) * b - lv[level * 2 + so + 1]}));
+        for (int t0 = blockIdx.z * PACK_LV; t0 < nt; t0 += gridDim.z * PACK_LV) {
+            T2 c[PACK_LV + 1];
+#pragma unroll
+            for (int q = 0; q <= PACK_LV; ++q) c[q] = *(const T2 *)(img + (size_t)min(t0 + q, nt - 1) * level * 2 + so);
+#pragma unroll
+            for (int q = 0; q < PACK_LV; ++q) {
+                const int t = t0 + q;
+                if (t >= nt) break;
+                if (pad) *(T2 *)(img + (size_t)t * level * 2 + po) = c[q];
+                if (t + 1 < nt) LCS_PACK_STORE((T2 *)(ext + (size_t)t * level * 2 + po), T(2) * c[q] - c[q + 1]);
             }
         }
     }
@@ -792,7 +812,8 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
     const int threads = 256;
     if (order == 1) {
         // (grid.y and grid.z are capped at 65535 blocks: the kernel loops over what is beyond)
-        hipLaunchKernelGGL(pack_fused_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nt < 65535 ? nt : 65535),
+        const int nchunk = (nt + PACK_LV - 1) / PACK_LV;
+        hipLaunchKernelGGL(pack_fused_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nchunk < 65535 ? nchunk : 65535),
                            dim3(threads), 0, ctx->stream, u, v, packed, ext, nt, ny, nx);
         LC_HIP_CHECK(hipGetLastError());
         return LC_OK;
@@ -807,7 +828,7 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
             hipLaunchKernelGGL(prefilter_fir_kernel, grid, dim3(256), 0, ctx->stream, u, v, packed, both ? ext : nullptr, nt, ny, nx,
                                cubic_fir_taps());
             if (ext && nt >= 2 && !both)  // ext = 2 img[t] - img[t+1] from the finished coefficients (pads rewritten, same values)
-                hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nt < 65535 ? nt : 65535), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
+                hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, (nt + PACK_LV - 1) / PACK_LV), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
             LC_HIP_CHECK(hipGetLastError());
             return LC_OK;
         }
@@ -849,7 +870,7 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
                            ny, nx, 1, P);
     }
     if (ext && nt >= 2)   // pads + fused-level image in one pass
-        hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nt < 65535 ? nt : 65535), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
+        hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, (nt + PACK_LV - 1) / PACK_LV), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
     else
         hipLaunchKernelGGL(fill_pads_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
     LC_HIP_CHECK(hipGetLastError());

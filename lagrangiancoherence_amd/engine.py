@@ -56,7 +56,7 @@ def common_dtype(*arrays) -> np.dtype:
 @dataclass
 class PackedField:
     """Gather-ready image(s) of a wind time series, resident on the device."""
-    lin: "torch.Tensor"            # order-1 image, always present
+    lin: "torch.Tensor | None"     # order-1 image; None when the raw planes ``u``, ``v`` below serve as the order-1 source
     cub: "torch.Tensor | None"     # B-spline coefficient image of order ``order`` (2..5), None for order 1
     ext: "torch.Tensor | None"     # 2*img[t]-img[t+1] of the image matching interp_order (fused SETTLS sample)
     nt: int
@@ -69,6 +69,9 @@ class PackedField:
     dtype: np.dtype
     wind_f32: bool = False          # float32 wind on float64 coordinates: numpy's promotion rules in lc_advect
     order: int = 1                  # interpolation order the field was prepared for (order 1 is always available)
+    u: "torch.Tensor | None" = None  # the raw planes (nt, ny_f, nx_f) the images were packed from, kept as the ORDER-1 source
+    v: "torch.Tensor | None" = None  # (lc_advect_ex: pole rows at any order, the Euler sample in float64) -- not copies: do not
+    #                                  modify them in place while the field is in use
 
 
 class Engine:
@@ -242,8 +245,15 @@ class Engine:
         return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
     # ------------------------------------------------------------------ field
-    def prepare_field(self, u, v, lat_f, lon_f, interp_order: int = 1, dtype=None, fuse_levels=None) -> PackedField:
+    def prepare_field(self, u, v, lat_f, lon_f, interp_order: int = 1, dtype=None, fuse_levels=None,
+                      lin_image=None) -> PackedField:
         """Upload (if needed) and pack a wind series.  u, v: (nt, ny_f, nx_f).
+
+        ``lin_image``: build the order-1 image too.  Default (None): only where a kernel reads it -- float32 at
+        ``interp_order=1``.  Everywhere else the raw planes themselves are the order-1 source (``lc_advect_ex``: the
+        pole seed rows at any order, LCS/tools.py:31-39, and in float64 the Euler sample): the field keeps a reference to
+        the device copies of ``u`` and ``v`` instead of a second, interleaved copy, the pack writes a third (order 1) to a
+        fifth (order 3) fewer bytes, and results are bit-identical either way.
 
         ``fuse_levels``: also build ext[t] = 2 F[t] - F[t+1] so each SETTLS iteration takes one
         gather instead of two (interpolation is linear in the field => the same value up to rounding).
@@ -278,9 +288,14 @@ class Engine:
         ext = None
         if fuse_levels and nt >= 2:
             ext = self._empty((self.lib.lc_packed_elems(nt - 1, ny_f, nx_f),), dtype)
-        lin = self._empty((n,), dtype)
-        _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f, 1,
-                                           self._ptr(lin), self._ptr(ext if interp_order == 1 else None)), self.lib)
+        if lin_image is None:
+            lin_image = dtype == f32 and interp_order == 1
+        if dtype == f32 and interp_order == 1 and not lin_image:
+            raise ValueError("float32 at interp_order=1 samples the order-1 image: lin_image cannot be False")
+        lin = self._empty((n,), dtype) if lin_image else None
+        if lin is not None or (interp_order == 1 and ext is not None):
+            _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(ud), self._ptr(vd), _NP2LC[dtype], nt, ny_f, nx_f, 1,
+                                               self._ptr(lin), self._ptr(ext if interp_order == 1 else None)), self.lib)
         cub = None
         if interp_order != 1:
             cub = self._empty((n,), dtype)
@@ -290,7 +305,7 @@ class Engine:
         la = lat_f.astype(dtype)
         lo = lon_f.astype(dtype)
         return PackedField(lin, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
-                           wind_f32, int(interp_order))
+                           wind_f32, int(interp_order), None if lin is not None else ud, None if lin is not None else vd)
 
     # ------------------------------------------------------------------ global pre-processing (LCS.py:105-118)
     def regrid(self, u, lat, lon, lats, lons):
@@ -376,14 +391,10 @@ class Engine:
             if tuple(sx.shape) != (ny, nx) or tuple(sy.shape) != (ny, nx):
                 raise ValueError(f"start positions must be two ({ny}, {nx}) arrays")
         self._use_current_stream()
-        _capi.check(self.lib.lc_advect_from(
-            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order != 1 else None),
-            self._ptr(field.ext if field.order == interp_order else None),
-            _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[dtype], field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max,
-            self._ptr(slat), ny, self._ptr(slon), nx, int(row0), ny_global, self._ptr(sx), self._ptr(sy),
-            float(timestep), int(SETTLS_order),
-            int(interp_order), x_boundary_mode(cyclic_xboundary, noncyclic_clamp, int(row0) == 0 and ny == ny_global),
-            int(t0), nsteps, self._ptr(x), self._ptr(y), self._ptr(tx), self._ptr(ty)), self.lib)
+        a = self._advect_args(field, interp_order, slat, ny, slon, nx, row0, ny_global, sx, sy, timestep, SETTLS_order,
+                              x_boundary_mode(cyclic_xboundary, noncyclic_clamp, int(row0) == 0 and ny == ny_global),
+                              t0, nsteps, 1, 0, x, y, tx, ty)
+        _capi.check(self.lib.lc_advect_ex(self.ctx, C.byref(a)), self.lib)
         if halo:
             x, y = x_buf, y_buf
         return (x, y, tx, ty) if return_traj else (x, y)
@@ -411,14 +422,32 @@ class Engine:
         x, y = (chk(t, "out") for t in out) if out is not None else (self._empty((n, ny, nx), dtype), self._empty((n, ny, nx), dtype))
         sx, sy = (chk(t, "start") for t in start) if start is not None else (None, None)
         self._use_current_stream()
-        _capi.check(self.lib.lc_advect_batch(
-            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order != 1 else None),
-            self._ptr(field.ext if field.order == interp_order else None),
-            _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[dtype], field.nt, field.ny_f, field.nx_f, field.lat_min,
-            field.lat_max, field.lon_min, field.lon_max, self._ptr(slat), ny, self._ptr(slon), nx, 0, ny,
-            self._ptr(sx), self._ptr(sy), float(timestep), int(SETTLS_order), int(interp_order), _capi.LC_X_CYCLIC,
-            int(t0), int(nsteps), n, int(t0_stride), self._ptr(x), self._ptr(y), None, None), self.lib)
+        a = self._advect_args(field, interp_order, slat, ny, slon, nx, 0, ny, sx, sy, timestep, SETTLS_order,
+                              _capi.LC_X_CYCLIC, t0, nsteps, n, t0_stride, x, y, None, None)
+        _capi.check(self.lib.lc_advect_ex(self.ctx, C.byref(a)), self.lib)
         return x, y
+
+    def _advect_args(self, field, interp_order, slat, ny, slon, nx, row0, ny_global, sx, sy, timestep, K, xmode, t0, nsteps,
+                     n_members, t0_stride, x, y, tx, ty) -> "_capi.AdvectArgs":
+        """``lc_advect_args`` of one call: the field's images, and its raw planes as the order-1 source where it has no
+        lin image."""
+        dt = _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[field.dtype]
+        if field.lin is None and field.dtype == np.dtype(np.float32) and interp_order == 1:
+            # a float32 field prepared for another order, now sampled at order 1 ("order 1 is always available"): its
+            # kernels read the order-1 image's 16-byte node pairs -- built here, once, and kept on the field
+            field.lin = self._empty((self.lib.lc_packed_elems(field.nt, field.ny_f, field.nx_f),), field.dtype)
+            _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(field.u), self._ptr(field.v), _NP2LC[field.dtype], field.nt,
+                                               field.ny_f, field.nx_f, 1, self._ptr(field.lin), None), self.lib)
+        p = lambda t: t.data_ptr() if t is not None else None
+        return _capi.AdvectArgs(
+            struct_size=C.sizeof(_capi.AdvectArgs), packed_lin=p(field.lin),
+            packed_cub=p(field.cub if interp_order != 1 else None),
+            packed_ext=p(field.ext if field.order == interp_order else None), u_raw=p(field.u), v_raw=p(field.v),
+            dtype=dt, nt=field.nt, ny_f=field.ny_f, nx_f=field.nx_f, lat_min=field.lat_min, lat_max=field.lat_max,
+            lon_min=field.lon_min, lon_max=field.lon_max, seed_lat_dev=p(slat), ny=int(ny), seed_lon_dev=p(slon), nx=int(nx),
+            row0=int(row0), ny_global=int(ny_global), x_start=p(sx), y_start=p(sy), timestep=float(timestep),
+            settls_order=int(K), interp_order=int(interp_order), cyclic_x=int(xmode), t0=int(t0), nsteps=int(nsteps),
+            n_members=int(n_members), t0_stride=int(t0_stride), x_out=p(x), y_out=p(y), traj_x=p(tx), traj_y=p(ty))
 
     def sample(self, field: PackedField, pos_x, pos_y, level=0, interp_order=1, row0=0, ny_global=None):
         """tools.xr_map_coordinates for (u, v) of one time level at positions (ny, nx) in degrees."""
@@ -432,8 +461,9 @@ class Engine:
         ou = self._empty((ny, nx), dtype)
         ov = self._empty((ny, nx), dtype)
         self._use_current_stream()
-        _capi.check(self.lib.lc_sample(
-            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order != 1 else None), _NP2LC[dtype],
+        _capi.check(self.lib.lc_sample_raw(
+            self.ctx, self._ptr(field.lin), self._ptr(field.cub if interp_order != 1 else None), self._ptr(field.u),
+            self._ptr(field.v), _NP2LC[dtype],
             field.nt, field.ny_f, field.nx_f, field.lat_min, field.lat_max, field.lon_min, field.lon_max, int(level),
             self._ptr(px), self._ptr(py), ny, nx, int(row0), ny_global, int(interp_order), self._ptr(ou),
             self._ptr(ov)), self.lib)

@@ -52,6 +52,17 @@ def test_argument_validation_needs_no_gpu(lib):
                                   1.0, 0, 1, 1, 0, 1, None, None, None, None), lib)
 
 
+def test_advect_args_structure_matches_the_library(lib):
+    """lc_advect_ex's argument structure: the ctypes mirror has the size the library was compiled with (the call checks
+    struct_size before anything else), and a wrong size is refused with both numbers in the message."""
+    import ctypes as C
+    a = _capi.AdvectArgs(struct_size=C.sizeof(_capi.AdvectArgs))
+    assert lib.lc_advect_ex(None, C.byref(a)) == _capi.LC_EINVAL and b"null context" in lib.lc_last_error()
+    a.struct_size = C.sizeof(_capi.AdvectArgs) - 8
+    assert lib.lc_advect_ex(None, C.byref(a)) == _capi.LC_EINVAL and b"struct_size" in lib.lc_last_error()
+    assert lib.lc_advect_ex(None, None) == _capi.LC_EINVAL
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _capi.load(str(tmp_path / "liblcs_hip.so"))

@@ -53,7 +53,7 @@ def _rand_field(seed, nt=4, ny=23, nx=31, dtype=np.float64, scale=20.0):
 # ------------------------------------------------------------------ field image
 def test_pack_order1_image(eng):
     u, v, lat, lon = _rand_field(1)
-    f = eng.prepare_field(u, v, lat, lon, 1)
+    f = eng.prepare_field(u, v, lat, lon, 1, lin_image=True)
     nt, ny, nx = u.shape
     img = _np(f.lin).reshape(nt, ny + 3, nx + 3, 2)
     assert np.array_equal(img[:, 1:ny + 1, 1:nx + 1, 0], u)
@@ -66,6 +66,91 @@ def test_pack_order1_image(eng):
         for px in (0, 5, nx + 1, nx + 2):
             assert img[2, py, px, 0] == u[2, mir(py - 1, ny), mir(px - 1, nx)]
     assert img[1, 4, 0, 1] == v[1, 3, 1] and img[1, 4, nx + 2, 1] == v[1, 3, nx - 3]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("nt", [1, 2, 7, 8, 9, 17])
+def test_pack_walks_levels_in_chunks_and_can_build_the_fused_level_image_alone(eng, dtype, nt):
+    """The order-1 pack carries level t+1 forward over chunks of 8 levels (each raw level read once): every level of lin and
+    of ext = 2 F[t] - F[t+1] for series lengths around the chunk size; lc_field_pack(order 1, packed_dev = NULL) writes the
+    fused-level image alone (what a float64 caller with the raw planes as the order-1 source needs), bit-identical."""
+    import ctypes as C
+    from lagrangiancoherence_amd import _capi
+    u, v, lat, lon = _rand_field(100 + nt, nt=nt, ny=9, nx=300, dtype=dtype)      # 303 padded nodes per row: two blocks in x
+    ny, nx = u.shape[1:]
+    ud, vd = eng.to_device(u, dtype), eng.to_device(v, dtype)
+    n = eng.lib.lc_packed_elems(nt, ny, nx)
+    lin = eng._empty((n,), dtype)
+    ext = eng._empty((max(eng.lib.lc_packed_elems(nt - 1, ny, nx), 1),), dtype)
+    ext2 = eng._empty(tuple(ext.shape), dtype).fill_(float("nan"))
+    lc = _capi.LC_F32 if dtype == np.float32 else _capi.LC_F64
+    eng._use_current_stream()
+    _capi.check(eng.lib.lc_field_pack(eng.ctx, eng._ptr(ud), eng._ptr(vd), lc, nt, ny, nx, 1, eng._ptr(lin),
+                                      eng._ptr(ext) if nt >= 2 else None), eng.lib)
+
+    def mir(i, m):
+        i = np.abs(i)
+        return np.where(i > m - 1, 2 * (m - 1) - i, i)
+    iy, ix = mir(np.arange(-1, ny + 2), ny), mir(np.arange(-1, nx + 2), nx)
+    want = np.stack([u[:, iy][:, :, ix], v[:, iy][:, :, ix]], axis=-1)             # (nt, ny+3, nx+3, 2)
+    assert np.array_equal(_np(lin).reshape(want.shape), want)
+    if nt >= 2:
+        two = dtype(2)
+        assert np.array_equal(_np(ext).reshape(nt - 1, ny + 3, nx + 3, 2), two * want[:-1] - want[1:])
+        _capi.check(eng.lib.lc_field_pack(eng.ctx, eng._ptr(ud), eng._ptr(vd), lc, nt, ny, nx, 1, None, eng._ptr(ext2)), eng.lib)
+        assert np.array_equal(_np(ext2), _np(ext))
+    with pytest.raises(ValueError, match="packed_dev may only be NULL"):
+        _capi.check(eng.lib.lc_field_pack(eng.ctx, eng._ptr(ud), eng._ptr(vd), lc, nt, ny, nx, 1, None, None), eng.lib)
+    with pytest.raises(ValueError, match="packed_dev may only be NULL"):
+        _capi.check(eng.lib.lc_field_pack(eng.ctx, eng._ptr(ud), eng._ptr(vd), lc, nt, ny, nx, 3, None, eng._ptr(ext2)), eng.lib)
+
+
+@pytest.mark.parametrize("dtype,order,fuse", [(np.float64, 1, True), (np.float64, 1, False), (np.float64, 3, True), (np.float64, 3, False),
+                                              (np.float64, 2, False), (np.float32, 3, True), (np.float32, 2, False)])
+@pytest.mark.parametrize("K", [0, 4])
+def test_raw_planes_as_the_order1_source_equal_the_lin_image_bit_for_bit(eng, dtype, order, fuse, K):
+    """lc_advect_ex with the raw wind planes instead of the order-1 image (the default of every field except float32 at
+    order 1): the pole seed rows' order-1 / 'constant' samples (LCS/tools.py:31-39) and, in float64 at order 1, the Euler
+    sample (LCS/trajectory.py:82-84) read the same node values through the same arithmetic -- departure points, trajectories,
+    standalone samples and the non-cyclic clamp's sub-step path are bit-identical to the legacy packed_lin form, in every
+    kernel family (LDS tiles, direct gathers, exact order)."""
+    u, v, lat, lon = flows.era5_like(nt=6, ny=40, nx=72)
+    u, v, lat, lon = (a.astype(dtype) for a in (u, v, lat, lon))
+    if order == 1:                                        # (a spline prefilter would smear them over whole lines)
+        u[2, 38:, 70:] = np.inf                           # non-finite nodes next to the last row / column (mirror pads)
+    # seeds = field nodes plus the exact last node row / column of the index map (c = n - 1: the window whose neighbour is
+    # the mirrored pad) and a denser block
+    slat = np.unique(np.concatenate([lat, np.linspace(lat[0], lat[-1], 57).astype(dtype)]))
+    slon = np.unique(np.concatenate([lon, np.linspace(lon[0], lon[-1], 101).astype(dtype)]))
+    f_raw = eng.prepare_field(u, v, lat, lon, order, fuse_levels=fuse)
+    f_lin = eng.prepare_field(u, v, lat, lon, order, fuse_levels=fuse, lin_image=True)
+    assert f_raw.lin is None and f_raw.u is not None and f_lin.lin is not None and f_lin.u is None
+    for lds in ((-1, 0) if dtype == np.float64 or order == 3 else (-1,)):
+        eng.set_lds_tiles(lds)
+        try:
+            for cyc in (True, False):
+                a = eng.advect(f_raw, slat, slon, -1800.0, K, order, cyc, return_traj=True)
+                ka = eng.last_advect_kernel()
+                b = eng.advect(f_lin, slat, slon, -1800.0, K, order, cyc, return_traj=True)
+                kb = eng.last_advect_kernel()
+                for p, q in zip(a, b):
+                    assert np.array_equal(_np(p), _np(q), equal_nan=True), (ka, kb, cyc, lds)
+                if dtype == np.float64 and order == 1 and K > 0 and cyc:
+                    assert ka.endswith(", true>") and kb.endswith(", false>"), (ka, kb)     # the raw / lin kernel variants
+        finally:
+            eng.set_lds_tiles(-1)
+    # a row block of a sharded grid (the pole rule by global row index) and the standalone sample
+    a = eng.advect(f_raw, slat[:9], slon, -1800.0, K, order, True, row0=0, ny_global=slat.size)
+    b = eng.advect(f_lin, slat[:9], slon, -1800.0, K, order, True, row0=0, ny_global=slat.size)
+    assert all(np.array_equal(_np(p), _np(q), equal_nan=True) for p, q in zip(a, b))
+    px, py = np.meshgrid(slon, slat)
+    sa = eng.sample(f_raw, px, py, level=2, interp_order=order)
+    sb = eng.sample(f_lin, px, py, level=2, interp_order=order)
+    assert all(np.array_equal(_np(p), _np(q), equal_nan=True) for p, q in zip(sa, sb))
+    if order != 1:   # "order 1 is always available" on a field prepared for another order
+        a = eng.advect(f_raw, slat, slon, -1800.0, K, 1, True)
+        b = eng.advect(f_lin, slat, slon, -1800.0, K, 1, True)
+        assert all(np.array_equal(_np(p), _np(q), equal_nan=True) for p, q in zip(a, b))
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 2e-13), (np.float32, 2e-5)])
@@ -469,7 +554,7 @@ def test_lcs_host_route_matches_engine(eng):
     # float64 at the example's size: the host route keeps numpy / scipy's operation order (LC_F64_AUTO)
     f = eng.prepare_field(u, v, lat, lon, 3, fuse_levels=False)
     r = eng.lcs(f, lat, lon, -21600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
-    assert eng.last_advect_kernel() == "advect_kernel<double, 3, false>"
+    assert eng.last_advect_kernel() == "advect_kernel<double, 3, false, false>"
     assert np.array_equal(out["x_dep"], _np(r["x_dep"])) and np.array_equal(out["sigma"], _np(r["sigma"]))
     assert out["traj_x"].shape == (8, 89, 180) and np.array_equal(out["traj_x"][-1], out["x_dep"])
     g = np.load(os.path.join(GOLD, "g1_bwd_k4_o3.npz"))
@@ -778,9 +863,9 @@ def test_float64_fused_levels_option(eng, O, order):
     f_fused = eng.prepare_field(u, v, lat, lon, order)
     assert f_exact.ext is None and f_fused.ext is not None
     xe, ye = eng.advect(f_exact, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
-    assert eng.last_advect_kernel() == "advect_kernel<double, %d, false>" % order
+    assert eng.last_advect_kernel() == {1: "advect_kernel<double, 1, false, true>", 3: "advect_kernel<double, 3, false, false>"}[order]
     xf, yf = eng.advect(f_fused, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
-    assert eng.last_advect_kernel() == ("advect_lds64_kernel<4, true>" if order == 1 else "advect_lds64_o3_kernel<4, true>")
+    assert eng.last_advect_kernel() == ("advect_lds64_kernel<4, true, true>" if order == 1 else "advect_lds64_o3_kernel<4, true>")
     xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=order,
                                   cyclic_xboundary=True)
     for got, ref in ((xf, xo), (yf, yo)):
