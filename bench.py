@@ -273,13 +273,83 @@ def watchdog(seconds: float, what: str, rank: int):
     return t
 
 
+def timed_case(torch, eng, prepare, advect, sigma, steps, warmup):
+    """`steps` passes of pack -> advect -> sigma (after `warmup` untimed ones): wall time per step and the mean HIP-event
+    time of each stage on the launch stream."""
+    def one():
+        m = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        m[0].record()
+        f = prepare()
+        m[1].record()
+        r = advect(f)
+        m[2].record()
+        s = sigma(r)
+        m[3].record()
+        return s, m
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks = []
+    for _ in range(steps):
+        s, m = one()
+        marks.append(m)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = {k: float(np.mean([m[i].elapsed_time(m[i + 1]) for m in marks])) for i, k in enumerate(("pack", "advect", "sigma"))}
+    assert bool(torch.isfinite(s).all()), "non-finite sigma in a benchmark case"
+    return el / steps, ms
+
+
+def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dlat, dlon, steps=3, warmup=1, c2_n=1024, c2_nt=201):
+    """The non-headline workloads, a few steps each, in the same process after the headline's timed region (so the driver's
+    one run records them): the reference's default interpolation order and its trajectory output on configs[2]'s field, and
+    configs[1] (float64, seeds = field nodes: the reference's own shape) at orders 1 and 3.  Each entry: whole-step rate,
+    ms per step, the advect kernel that ran, its stage times and its flop fraction of the vector peak."""
+    out = {}
+
+    def case(name, pts, K, order, s_p, prepare, advect, sigma):
+        try:
+            per_step, ms = timed_case(torch, eng, prepare, advect, sigma, steps, warmup)
+            n_k = max(eng.last_advect_launches(), 1)
+            peak = FP32_VECTOR_TFLOPS if s_p == 4 else FP64_VECTOR_TFLOPS
+            out[name] = {"value": pts / per_step, "unit": "particle-timesteps/s", "ms_per_step": per_step * 1e3, "steps": steps,
+                         "kernel": eng.last_advect_kernel(), "kernel_ms": {k: round(v, 4) for k, v in ms.items()},
+                         "advect_launches": n_k, "advect_kernel_ms": ms["advect"] / n_k,
+                         "frac": pts * flops_pts(K, order, True) / (ms["advect"] / 1e3) / 1e12 / peak}
+        except Exception as exc:      # a secondary case must not cost the run its headline
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        torch.cuda.empty_cache()
+
+    K = 4
+    nt = int(ud.shape[0])
+    ny, nx = int(slat_d.numel()), int(slon_d.numel())
+    sig32 = lambda r: eng.sigma(r[0], r[1], slat_d, dlat, dlon)
+    case("c3 order 3", ny * nx * (nt - 1), K, 3, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 3),
+         lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 3, True), sig32)
+    case("c3 return_traj", ny * nx * (nt - 1), K, 1, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 1),
+         lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 1, True, return_traj=True), sig32)
+    try:
+        u2, v2, lat2, lon2 = flows.config2_on_device(torch, eng.device, c2_n, c2_nt)
+        la_d, lo_d = eng.to_device(lat2, np.float64), eng.to_device(lon2, np.float64)
+        d2 = (float(lat2[1] - lat2[0]), float(lon2[1] - lon2[0]))
+        n2 = int(u2.shape[1]) * int(u2.shape[2]) * (int(u2.shape[0]) - 1)
+        for order in (1, 3):
+            case("c2" if order == 1 else "c2 order 3", n2, K, order, 8, lambda: eng.prepare_field(u2, v2, lat2, lon2, order),
+                 lambda f: eng.advect(f, la_d, lo_d, -900.0, K, order, True), lambda r: eng.sigma(r[0], r[1], la_d, *d2))
+    except Exception as exc:
+        out["c2"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    return out
+
+
 def run_c2(args, torch, flows, Engine, local_rank, csrc):
     """BASELINE configs[1] on one GPU (a parity config; reported for the float64 path's rate)."""
     K, order = args.settls, args.order
-    u, v, lat, lon = flows.config2()
-    nt, ny, nx = u.shape
     eng = Engine(local_rank)
-    ud, vd = eng.to_device(u, np.float64), eng.to_device(v, np.float64)
+    # the field is evaluated on the device (flows.config2_on_device: flows.config2's formula in torch, equal to ~1e-12 m/s;
+    # the numpy generator takes a minute of one host core for the 2 x 1.7 GB)
+    ud, vd, lat, lon = flows.config2_on_device(torch, eng.device)
+    nt, ny, nx = (int(n) for n in ud.shape)
     lat_d, lon_d = eng.to_device(lat, np.float64), eng.to_device(lon, np.float64)
     dlat, dlon = float(lat[1] - lat[0]), float(lon[1] - lon[0])
 
@@ -320,6 +390,7 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
         "roofline": roofline(eng.last_advect_kernel(), "valu" if "lds" in eng.last_advect_kernel() else "tcp", pts, ms["advect"], K, order, 8, 8,
                              bool(args.fuse_levels), comp, wl, csrc, eng.last_advect_launches()),
     }
+    del ud, vd
     if not args.no_cpu_baseline:
         from oracle import lcs_oracle as O
         us, vs, la, lo = flows.config2(n=256, nt=21)
@@ -345,6 +416,8 @@ def main():
     ap.add_argument("--settls", type=int, default=4)
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the non-headline workloads the default one-GPU c3 run appends under \"secondary\"")
     ap.add_argument("--traj", action="store_true",
                     help="return_traj=True: also store the positions after every step (not the headline)")
     ap.add_argument("--wind-scale", type=float, default=1.0,
@@ -716,6 +789,13 @@ def main():
         out["halo_ms"] = ms["halo"]
         out["per_rank"] = per_rank
 
+    # ---- the non-headline workloads, a few steps each, after the headline's timed region (default one-GPU run only) ----
+    plain = (wk == "c3" and world == 1 and std and order == 1 and K == 4 and not args.traj and args.wind_scale == 1.0 and not knobs)
+    if plain and not args.no_secondary:
+        last.clear()
+        del sig, x_ext, y_ext, field          # the headline's outputs: the secondary cases reuse the memory
+        torch.cuda.empty_cache()
+        out["secondary"] = secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dlat, dlon)
     # ---- CPU baseline: the oracle (numpy+scipy port) on a bounded sample, rank 0, N=1 only ----
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(flows, u, v, lat, lon, dt, K, order, nsteps)

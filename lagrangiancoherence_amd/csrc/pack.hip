@@ -609,7 +609,10 @@ __global__ void __launch_bounds__(64) prefilter_rows_stream_kernel(double *__res
 // loads of a chunk are issued together (static trip count), then the stores.
 // lin == NULL: the fused-level image alone (lc_field_pack(order 1, packed_dev = NULL): the caller samples order 1 from
 // the raw planes, lc_advect_ex).
-constexpr int PACK_LV = 8;
+#ifndef LCS_PACK_LV
+#define LCS_PACK_LV 2
+#endif
+constexpr int PACK_LV = LCS_PACK_LV;
 template <typename T>
 __global__ void __launch_bounds__(256) pack_fused_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ lin,
                                                          T *__restrict__ ext, int nt, int ny, int nx) {

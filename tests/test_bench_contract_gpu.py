@@ -129,3 +129,29 @@ def test_bench_gpus_2_fails_loudly_when_a_rank_cannot_start():
                         "--seeds", "256", "--nt", "5"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode != 0
     assert "did not finish within" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_secondary_workloads_block_of_the_default_run():
+    """What the default one-GPU run appends under "secondary" (here on miniature inputs): the reference's default
+    interpolation order and its trajectory output on configs[2]'s field, configs[1] (float64) at orders 1 and 3 -- each with
+    its rate, stage times, the advect kernel that ran and a flop fraction."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from lagrangiancoherence_amd import flows
+    from lagrangiancoherence_amd.engine import Engine
+    eng = Engine(0)
+    u, v, lat, lon = flows.era5_like(nt=5, ny=72, nx=144)
+    slat, slon = flows.seed_grid(160, 256, lat, lon)
+    sec = bench.secondary_workloads(torch, flows, eng, eng.to_device(u, np.float32), eng.to_device(v, np.float32), lat, lon,
+                                    eng.to_device(slat, np.float32), eng.to_device(slon, np.float32), float(slat[1] - slat[0]),
+                                    float(slon[1] - slon[0]), steps=2, warmup=1, c2_n=128, c2_nt=9)
+    assert list(sec) == ["c3 order 3", "c3 return_traj", "c2", "c2 order 3"]
+    for name, d in sec.items():
+        assert "error" not in d, (name, d)
+        assert d["value"] > 0 and d["ms_per_step"] > 0 and 0 < d["frac"] <= 1 and d["advect_launches"] >= 1
+        assert set(d["kernel_ms"]) == {"pack", "advect", "sigma"} and abs(d["advect_kernel_ms"] * d["advect_launches"] - d["kernel_ms"]["advect"]) < 1e-3
+    assert "o3" in sec["c3 order 3"]["kernel"] or "<3," in sec["c3 order 3"]["kernel"]
+    assert sec["c2"]["kernel"].startswith("advect_lds64_kernel") and sec["c2 order 3"]["kernel"].startswith("advect_lds64_o3_kernel")
+    eng.close()

@@ -1,6 +1,7 @@
 """Input generators: the vectorised ideal vortex equals the reference's triple
 loop (examples/ideal_vortex.py:159-201, restated in oracle.ideal_vortex_loops)."""
 import numpy as np
+import pytest
 
 from lagrangiancoherence_amd import flows
 from oracle import lcs_oracle as O
@@ -37,3 +38,14 @@ def test_seed_grid_inclusive():
     _, _, lat, lon = flows.era5_like(nt=2, ny=72, nx=144)
     slat, slon = flows.seed_grid(96, 160, lat, lon)
     assert slat[0] == lat[0] and slat[-1] == lat[-1] and slon[0] == lon[0] and slon[-1] == lon[-1]
+
+
+@pytest.mark.gpu
+def test_config2_on_device_equals_the_numpy_generator():
+    import torch
+    from lagrangiancoherence_amd import flows
+    u, v, lat, lon = flows.config2(n=96, nt=9)
+    ud, vd, lat2, lon2 = flows.config2_on_device(torch, "cuda", n=96, nt=9)
+    assert np.array_equal(lat, lat2) and np.array_equal(lon, lon2) and ud.dtype == torch.float64
+    np.testing.assert_allclose(ud.cpu().numpy(), u, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=0, atol=1e-11)
