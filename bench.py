@@ -43,7 +43,8 @@ sys.path.insert(0, ROOT)
 
 # environment variables that change which kernel runs or how it is launched without changing its name
 KERNEL_KNOBS = ("LCS_LIB", "LCS_LDS_TILES", "LCS_XCD_CHUNK_ROWS", "LCS_TILE_ORDER", "LCS_POLE_BLOCKS", "LCS_FIR_PREFILTER",
-                "LCS_SIGMA_MARCH", "LCS_LEVEL_CHUNK", "LCS_PATCH_MODE", "LCS_ENSEMBLE_CHUNK", "LCS_MEMBER_STREAMS", "LCS_NATIVE_HALO")
+                "LCS_SIGMA_MARCH", "LCS_LEVEL_CHUNK", "LCS_PATCH_MODE", "LCS_ENSEMBLE_CHUNK", "LCS_MEMBER_STREAMS", "LCS_NATIVE_HALO",
+                "LCS_EXT_IMAGE")
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_VECTOR_TFLOPS = 157.3   # same guide: peak FP32 vector
@@ -356,7 +357,8 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
     def one():
         m = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         m[0].record()
-        f = eng.prepare_field(ud, vd, lat, lon, order, fuse_levels=args.fuse_levels)
+        f = eng.prepare_field(ud, vd, lat, lon, order, fuse_levels=args.fuse_levels,
+                              ext_image=None if "LCS_EXT_IMAGE" not in os.environ else os.environ["LCS_EXT_IMAGE"] != "0")
         m[1].record()
         x, y = eng.advect(f, lat_d, lon_d, -900.0, K, order, True)
         m[2].record()

@@ -340,6 +340,12 @@ typedef struct lc_advect_args {
     int settls_order, interp_order, cyclic_x;
     int t0, nsteps, n_members, t0_stride;
     void *x_out, *y_out, *traj_x, *traj_y;
+    /* LC_F64 at interp_order 1 with u_raw / v_raw and packed_ext == NULL: 1 = take the fused-level form all the same -- the
+     * value packed_ext would hold, 2 F[t] - F[t+1], is formed from the raw planes node by node inside the kernels (the
+     * same expression, one rounding: results equal those with packed_ext bit for bit).  No packed image exists then:
+     * lc_field_pack is not called at all for such a field.  0 (and every other dtype / order): packed_ext == NULL means
+     * the reference's two-sample operation order, as in lc_advect. */
+    int fuse_levels_raw;
 } lc_advect_args;
 int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args);
 

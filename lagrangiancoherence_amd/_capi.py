@@ -93,7 +93,8 @@ class AdvectArgs(C.Structure):
                 ("timestep", _d),
                 ("settls_order", _i), ("interp_order", _i), ("cyclic_x", _i),
                 ("t0", _i), ("nsteps", _i), ("n_members", _i), ("t0_stride", _i),
-                ("x_out", _vp), ("y_out", _vp), ("traj_x", _vp), ("traj_y", _vp)]
+                ("x_out", _vp), ("y_out", _vp), ("traj_x", _vp), ("traj_y", _vp),
+                ("fuse_levels_raw", _i)]
 
 
 PROTOTYPES["lc_advect_ex"] = (_i, [_vp, C.POINTER(AdvectArgs)])

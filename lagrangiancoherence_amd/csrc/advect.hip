@@ -44,6 +44,8 @@ struct AdvectArgs {
     // not read at all).  Same node values, same arithmetic, bit-identical results -- the image the pack no longer writes.
     const T *u_raw, *v_raw;
     size_t raw_plane;  // ny_f * nx_f
+    int ext_raw;       // float64, order 1, raw planes: the fused-level value 2 F[t] - F[t+1] is formed from the planes node by node
+                       // (lc_advect_args.fuse_levels_raw): no packed image at all, ext == NULL
     size_t level_elems;
     int pitch;  // nodes per padded row
     int ny_f, nx_f;
@@ -523,6 +525,9 @@ __device__ void advect_seed(const AdvectArgs<T> &A, const T *__restrict__ image,
 // planes instead (lc_advect_ex) -- from those.  SRC: 0 = the lin image (float32 order-1 kernels: lin is their interior
 // image anyway, it always exists), 2 = the raw planes (kernel variants compiled for them), 1 = whichever the call has.
 constexpr int POLE_LIN = 0, POLE_EITHER = 1, POLE_RAW = 2;
+// float64 at order 1, where the samples come from: packed images (lin + ext) / raw planes for the Euler sample + ext image /
+// raw planes for both (the fused-level value formed node by node)
+constexpr int SRC_IMAGES = 0, SRC_RAW_EULER = 1, SRC_RAW_ALL = 2;
 template <typename T, int SRC>
 __device__ __forceinline__ void pole_seed(const AdvectArgs<T> &A, int iy, int ix) {
     if (SRC == POLE_RAW || (SRC == POLE_EITHER && A.u_raw))
@@ -2240,6 +2245,34 @@ __device__ __forceinline__ d2 sample_fast64_raw(const double *__restrict__ up, c
     return lerp_fast64(a, b, t.tx, t.ty);
 }
 
+// ... and one sample of the fused-level field 2 F[t] - F[t+1] formed from the raw planes of levels t (up) and t + 1 node by
+// node: the numbers the ext image holds (lc_field_pack: T(2) * a - b, one rounding: 2 a is exact), mirrored neighbour
+// included, so the result is the ext-image sample bit for bit -- without the image (lc_advect_args.fuse_levels_raw).
+__device__ __forceinline__ d2 sample_ext_fast64_raw(const double *__restrict__ up, const AdvectArgs<double> &A, double x, double y) {
+#pragma clang fp contract(off)
+    const Loc64 t = locate_fast64(A, x, y);
+    const double *vp = up + (A.v_raw - A.u_raw);
+    const int xa = min(t.x0, A.nx_f - 2), y1 = t.y0 + 1 < A.ny_f ? t.y0 + 1 : A.ny_f - 2;
+    const size_t r0 = (size_t)t.y0 * A.nx_f + xa, r1 = (size_t)y1 * A.nx_f + xa, lp = A.raw_plane;
+    d2 u0, v0, u1, v1, u0n, v0n, u1n, v1n;
+    __builtin_memcpy(&u0, up + r0, 16);
+    __builtin_memcpy(&v0, vp + r0, 16);
+    __builtin_memcpy(&u1, up + r1, 16);
+    __builtin_memcpy(&v1, vp + r1, 16);
+    __builtin_memcpy(&u0n, up + lp + r0, 16);
+    __builtin_memcpy(&v0n, vp + lp + r0, 16);
+    __builtin_memcpy(&u1n, up + lp + r1, 16);
+    __builtin_memcpy(&v1n, vp + lp + r1, 16);
+    u0 = 2.0 * u0 - u0n;
+    v0 = 2.0 * v0 - v0n;
+    u1 = 2.0 * u1 - u1n;
+    v1 = 2.0 * v1 - v1n;
+    const bool last = t.x0 > xa;
+    const d4 a = last ? (d4){u0.y, v0.y, u0.x, v0.x} : (d4){u0.x, v0.x, u0.y, v0.y};
+    const d4 b = last ? (d4){u1.y, v1.y, u1.x, v1.x} : (d4){u1.x, v1.x, u1.y, v1.y};
+    return lerp_fast64(a, b, t.tx, t.ty);
+}
+
 // Order 3 in the fast float64 form: scipy's cubic B-spline weights as polynomials in t (cubic_weights_p in double) and the
 // 16 taps as four fused row sums combined by a fused column sum.  Shared by the direct and the LDS-tile kernel (explicit
 // operations: a seed's result must not depend on which of the two served it).  `w` points at the window's first node
@@ -2334,9 +2367,12 @@ __device__ void advect_seed_fast64_o3(const AdvectArgs<double> &A, int iy, int i
     A.y_out[idx] = y;
 }
 
-template <bool RAW>
+// SRC: 0 = lin image + ext image; 1 = raw planes for the Euler sample + ext image; 2 = raw planes for both (the fused-level
+// value formed node by node: no image at all)
+template <int SRC>
 __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) {
 #pragma clang fp contract(fast)
+    constexpr bool RAW = SRC != SRC_IMAGES, EXTRAW = SRC == SRC_RAW_ALL;
     double x = start_x<double>(A, iy, ix), y = start_y<double>(A, iy, ix);
     const double ys = A.seed_lat[iy];
     const double cx_conv = 180.0 / ((3.141592653589793 * 6371000.0) * fabs(cos((ys * 3.141592653589793) / 180.0)));  // Q5
@@ -2349,14 +2385,14 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
     // the Euler sample's source: the lin image, or the raw planes (then img is not read at all)
     const size_t lstride = RAW ? A.raw_plane : A.level_elems;
     const double *lvl = (RAW ? A.u_raw : A.img) + (size_t)A.t0 * lstride;
-    const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const double *elv = EXTRAW ? nullptr : A.ext + (size_t)A.t0 * A.level_elems;
     for (int s = 0; s < A.nsteps; ++s) {
         const d2 e = RAW ? sample_fast64_raw(lvl, A, x, y) : sample_fast64(lvl, A, x, y);   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                        // :86
         x = fma(dtcx, e.x, x);                          // :87
         clamp_position<double>(A, x, y);                // :89-97
         for (int k = 0; k < A.K; ++k) {                 // :100
-            const d2 d = e + sample_fast64(elv, A, x, y);   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
+            const d2 d = e + (EXTRAW ? sample_ext_fast64_raw(lvl, A, x, y) : sample_fast64(elv, A, x, y));   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
             y = fma(A.hdtcy, d.y, y);
             x = fma(hdtcx, d.x, x);
             clamp_position<double>(A, x, y);
@@ -2366,7 +2402,7 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
             A.traj_y[(size_t)(s + 1) * plane + idx] = y;
         }
         lvl += lstride;
-        elv += A.level_elems;
+        if (!EXTRAW) elv += A.level_elems;
     }
     A.x_out[idx] = x;
     A.y_out[idx] = y;
@@ -2396,13 +2432,16 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
 constexpr int T64_COLS = 16, T64_ROWS = LCS_T64_ROWS, T64_PITCH = 17;  // nodes; rows shift 4 banks of 16 bytes
 // RAW: the Euler sample (and the pole rows) from the raw planes of the level instead of the lin image (lc_advect_ex) -- a
 // compile-time variant: as a run-time choice the extra uniform state cost the kernel 9 vector registers and a wave per SIMD.
-template <int KFIX, bool CYCLIC, bool RAW>
+// SRC = SRC_RAW_ALL: the tile of ext[t] itself is formed while it is staged -- each lane loads its nodes of levels t and
+// t + 1 from the raw planes (mirrored where the image has pads) and stores 2 F[t] - F[t+1]: no packed image exists at all.
+template <int KFIX, bool CYCLIC, int SRC>
 __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
 #if LCS_LDS64_NUM_SGPR > 0
     __attribute__((amdgpu_num_sgpr(LCS_LDS64_NUM_SGPR)))
 #endif
     advect_lds64_kernel(const AdvectArgs<double> A0) {
 #pragma clang fp contract(off)
+    constexpr bool RAW = SRC != SRC_IMAGES, EXTRAW = SRC == SRC_RAW_ALL;
     const AdvectArgs<double> A = for_member(A0);
     const int K = KFIX >= 0 ? KFIX : A.K;
     __shared__ __attribute__((aligned(16))) d2 s_tiles[BLOCK / 64][T64_ROWS * T64_PITCH];
@@ -2436,7 +2475,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
     // the Euler sample's source: the lin image, or the raw planes (lc_advect_ex: then img is not read at all)
     const size_t lstride = RAW ? A.raw_plane : A.level_elems;
     const double *lvl = (RAW ? A.u_raw : A.img) + (size_t)A.t0 * lstride;
-    const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const double *elv = EXTRAW ? nullptr : A.ext + (size_t)A.t0 * A.level_elems;
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
     constexpr int CENTRE = TILE_W / 2 + TILE_W * 4;  // middle seed of the wave's 8 x 8 patch
     // staging: one node (16 bytes) per lane, 16 lanes per tile row, 4 rows per pass, 4 passes
@@ -2454,9 +2493,30 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
             const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
             ox = min(max(rxm + LC_PAD_LO - (T64_COLS - 2) / 2, 0), pad_cols - T64_COLS);
             oy = min(max(rym + LC_PAD_LO - (T64_ROWS - 2) / 2, 0), pad_rows - T64_ROWS);
-            const char *src = (const char *)elv + ((size_t)oy * pad_cols + ox) * 16;
+            if (EXTRAW) {
+                // the lane's nodes of levels t and t + 1 from the raw planes; padded (row, column) -> node index, mirrored
+                // where the image has pads (lc_field_pack's rule), and 2 F[t] - F[t+1] as the pack forms it
+                const ptrdiff_t dv = A.v_raw - A.u_raw;
+                int cx = ox + st_col - LC_PAD_LO;
+                cx = cx < 0 ? -cx : (cx > A.nx_f - 1 ? 2 * (A.nx_f - 1) - cx : cx);
+                double ut[T64_ROWS / 4], vt[T64_ROWS / 4], un[T64_ROWS / 4], vn[T64_ROWS / 4];
 #pragma unroll
-            for (int r = 0; r < T64_ROWS / 4; ++r) __builtin_memcpy(&stage[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+                for (int r = 0; r < T64_ROWS / 4; ++r) {
+                    int cy = oy + r * 4 + st_row - LC_PAD_LO;
+                    cy = cy < 0 ? -cy : (cy > A.ny_f - 1 ? 2 * (A.ny_f - 1) - cy : cy);
+                    const double *p = lvl + (size_t)cy * A.nx_f + cx;
+                    ut[r] = p[0];
+                    vt[r] = p[dv];
+                    un[r] = p[A.raw_plane];
+                    vn[r] = p[A.raw_plane + dv];
+                }
+#pragma unroll
+                for (int r = 0; r < T64_ROWS / 4; ++r) stage[r] = (d2){2.0 * ut[r] - un[r], 2.0 * vt[r] - vn[r]};
+            } else {
+                const char *src = (const char *)elv + ((size_t)oy * pad_cols + ox) * 16;
+#pragma unroll
+                for (int r = 0; r < T64_ROWS / 4; ++r) __builtin_memcpy(&stage[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+            }
         }
         // ---- 2. Euler sample: direct gather from img[t] (or the raw planes of level t) ---------------------------
         const double x0p = x, y0p = y;
@@ -2494,6 +2554,26 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
                 const d2 n00 = w[0], n01 = w[1], n10 = w[T64_PITCH], n11 = w[T64_PITCH + 1];
                 a = (d4){n00.x, n00.y, n01.x, n01.y};
                 b = (d4){n10.x, n10.y, n11.x, n11.y};
+            } else if (EXTRAW) {  // the window left the tile: the same nodes from the raw planes of levels t, t + 1
+                const double *up = lvl, *vp = lvl + (A.v_raw - A.u_raw);
+                const int xa = min(t.x0, A.nx_f - 2), y1 = t.y0 + 1 < A.ny_f ? t.y0 + 1 : A.ny_f - 2;
+                const size_t r0 = (size_t)t.y0 * A.nx_f + xa, r1 = (size_t)y1 * A.nx_f + xa, lp = A.raw_plane;
+                d2 u0, v0, u1, v1, u0n, v0n, u1n, v1n;
+                __builtin_memcpy(&u0, up + r0, 16);
+                __builtin_memcpy(&v0, vp + r0, 16);
+                __builtin_memcpy(&u1, up + r1, 16);
+                __builtin_memcpy(&v1, vp + r1, 16);
+                __builtin_memcpy(&u0n, up + lp + r0, 16);
+                __builtin_memcpy(&v0n, vp + lp + r0, 16);
+                __builtin_memcpy(&u1n, up + lp + r1, 16);
+                __builtin_memcpy(&v1n, vp + lp + r1, 16);
+                u0 = 2.0 * u0 - u0n;
+                v0 = 2.0 * v0 - v0n;
+                u1 = 2.0 * u1 - u1n;
+                v1 = 2.0 * v1 - v1n;
+                const bool last = t.x0 > xa;
+                a = last ? (d4){u0.y, v0.y, u0.x, v0.x} : (d4){u0.x, v0.x, u0.y, v0.y};
+                b = last ? (d4){u1.y, v1.y, u1.x, v1.x} : (d4){u1.x, v1.x, u1.y, v1.y};
             } else {  // the window left the tile: the same taps from global memory
                 const double *p = elv + ((size_t)(t.y0 + LC_PAD_LO) * A.pitch + (t.x0 + LC_PAD_LO)) * 2;
                 __builtin_memcpy(&a, p, 32);
@@ -2509,7 +2589,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
             A.traj_y[(size_t)(s + 1) * plane + idx] = y;
         }
         lvl += lstride;
-        elv += A.level_elems;
+        if (!EXTRAW) elv += A.level_elems;
     }
     if (live) {
         A.x_out[idx] = x;
@@ -2629,18 +2709,18 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs
     }
 }
 
-// RAW (float64 at order 1 only): the order-1 source is the raw planes (lc_advect_ex; img == lin is not read)
-template <typename T, int ORDER, bool FUSED, bool RAW = false>
+// SRC != SRC_IMAGES (float64 at order 1 only): the order-1 source is the raw planes (lc_advect_ex; img == lin is not read)
+template <typename T, int ORDER, bool FUSED, int SRC = SRC_IMAGES>
 struct InteriorPath {
     static __device__ __forceinline__ void run(const AdvectArgs<T> &A, int iy, int ix) {
-        if constexpr (RAW)
+        if constexpr (SRC != SRC_IMAGES)
             advect_seed<T, 1, true, false, true>(A, A.u_raw, iy, ix);   // exact order, two samples per iteration
         else
             advect_seed<T, ORDER, true, FUSED>(A, A.img, iy, ix);
     }
 };
 template <>
-struct InteriorPath<double, 3, true, false> {
+struct InteriorPath<double, 3, true, SRC_IMAGES> {
     static __device__ __forceinline__ void run(const AdvectArgs<double> &A, int iy, int ix) {
         if (A.wind_f32)
             advect_seed<double, 3, true, true>(A, A.img, iy, ix);  // (never launched: LC_F64_WIND_F32 takes no ext)
@@ -2648,14 +2728,14 @@ struct InteriorPath<double, 3, true, false> {
             advect_seed_fast64_o3(A, iy, ix);
     }
 };
-template <bool RAW>
-struct InteriorPath<double, 1, true, RAW> {
+template <int SRC>
+struct InteriorPath<double, 1, true, SRC> {
     static __device__ __forceinline__ void run(const AdvectArgs<double> &A, int iy, int ix) {
-        advect_seed_fast64<RAW>(A, iy, ix);  // (LC_F64_WIND_F32 takes no ext: never launched in this form)
+        advect_seed_fast64<SRC>(A, iy, ix);  // (LC_F64_WIND_F32 takes no ext: never launched in this form)
     }
 };
 template <int ORDER, bool FUSED>
-struct InteriorPath<float, ORDER, FUSED, false> {
+struct InteriorPath<float, ORDER, FUSED, SRC_IMAGES> {
     static __device__ __forceinline__ void run(const AdvectArgs<float> &A, int iy, int ix) {
         if (ORDER == 1 || ORDER == 3)
             advect_seed_f32<ORDER>(A, iy, ix);  // looks at A.ext itself
@@ -2666,10 +2746,11 @@ struct InteriorPath<float, ORDER, FUSED, false> {
 
 // double, order 1 sits at 69 VGPRs (7 waves per SIMD); asking for 8 costs nothing measurable per wave and
 // lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
-template <typename T, int ORDER, bool FUSED, bool RAW = false>
+template <typename T, int ORDER, bool FUSED, int SRC = SRC_IMAGES>
 __device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A0) {
     const AdvectArgs<T> A = for_member(A0);
-    static_assert(!RAW || (sizeof(T) == 8 && ORDER == 1), "RAW variants exist for float64 at order 1 (the others choose per call)");
+    constexpr bool RAW = SRC != SRC_IMAGES;
+    static_assert(!RAW || (sizeof(T) == 8 && ORDER == 1), "raw-plane variants exist for float64 at order 1 (the others choose per call)");
     // order-1 source of the pole rows: float64 at order 1 has its own kernel variants for the raw planes (held to 64
     // registers, a run-time choice spills); float32 at order 1 always has the lin image; everything else: per call
     constexpr int PSRC = (sizeof(T) == 8 && ORDER == 1) ? (RAW ? POLE_RAW : POLE_LIN) : ((sizeof(T) == 8 || ORDER != 1) ? POLE_EITHER : POLE_LIN);
@@ -2685,14 +2766,14 @@ __device__ __forceinline__ void advect_kernel_body(const AdvectArgs<T> &A0) {
     if (pole) {
         if (!A.pole_blocks) pole_seed<T, PSRC>(A, iy, ix);  // (else the leading workgroups did them)
     } else
-        InteriorPath<T, ORDER, FUSED, RAW>::run(A, iy, ix);
+        InteriorPath<T, ORDER, FUSED, SRC>::run(A, iy, ix);
 }
 
 // double, order 1 sits at 69 VGPRs (7 waves per SIMD); asking for 8 costs nothing measurable per wave and
 // lets BASELINE config 2 (1024^2 seeds = 16 workgroups per CU) run in two full rounds instead of 7 + 7 + 2.
-template <typename T, int ORDER, bool FUSED = false, bool RAW = false>
+template <typename T, int ORDER, bool FUSED = false, int SRC = SRC_IMAGES>
 __global__ void __launch_bounds__(BLOCK, (sizeof(T) == 8 && ORDER == 1) ? 8 : 1) advect_kernel(const AdvectArgs<T> A) {
-    advect_kernel_body<T, ORDER, FUSED, RAW>(A);
+    advect_kernel_body<T, ORDER, FUSED, SRC>(A);
 }
 
 // float: 98 SGPRs as compiled would admit 6 workgroups per CU instead of 7 (MI355X_MICROARCH.md: 97-112 -> 6);
@@ -2719,23 +2800,30 @@ struct Lds64Launch<double> {
     // float64, order 1, fused levels: per-wave LDS tiles unless direct gathers are forced (lc_ctx_set_lds_tiles(0)),
     // the wind is float32-valued (numpy promotion path), K = 0, or the field is smaller than a tile
     static const char *launch(const AdvectArgs<double> &A, int grid, hipStream_t st, int mode) {
-        if (mode == 0 || A.wind_f32 || A.K == 0 || !A.ext || A.nx_f + LC_PAD < T64_COLS || A.ny_f + LC_PAD < T64_ROWS) return nullptr;
-        // (names as a profiler prints them; the last argument: order-1 source = the raw planes, lc_advect_ex)
-#define LC_LDS64(KF, CY, RW, NAME)                                                                                  \
+        if (mode == 0 || A.wind_f32 || A.K == 0 || !(A.ext || A.ext_raw) || A.nx_f + LC_PAD < T64_COLS || A.ny_f + LC_PAD < T64_ROWS) return nullptr;
+        // (names as a profiler prints them; the last argument: 0 = lin + ext images, 1 = raw planes for the Euler sample + ext
+        // image, 2 = raw planes for both, the fused-level value formed node by node: lc_advect_ex)
+#define LC_LDS64(KF, CY, SR, NAME)                                                                                  \
     {                                                                                                               \
-        hipLaunchKernelGGL((advect_lds64_kernel<KF, CY, RW>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);          \
+        hipLaunchKernelGGL((advect_lds64_kernel<KF, CY, SR>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);          \
         return NAME;                                                                                                \
     }
-        if (A.u_raw) {
-            if (A.K == 4 && A.cyclic) LC_LDS64(4, true, true, "advect_lds64_kernel<4, true, true>")
-            if (A.K == 4) LC_LDS64(4, false, true, "advect_lds64_kernel<4, false, true>")
-            if (A.cyclic) LC_LDS64(-1, true, true, "advect_lds64_kernel<-1, true, true>")
-            LC_LDS64(-1, false, true, "advect_lds64_kernel<-1, false, true>")
+        if (A.ext_raw) {
+            if (A.K == 4 && A.cyclic) LC_LDS64(4, true, 2, "advect_lds64_kernel<4, true, 2>")
+            if (A.K == 4) LC_LDS64(4, false, 2, "advect_lds64_kernel<4, false, 2>")
+            if (A.cyclic) LC_LDS64(-1, true, 2, "advect_lds64_kernel<-1, true, 2>")
+            LC_LDS64(-1, false, 2, "advect_lds64_kernel<-1, false, 2>")
         }
-        if (A.K == 4 && A.cyclic) LC_LDS64(4, true, false, "advect_lds64_kernel<4, true, false>")
-        if (A.K == 4) LC_LDS64(4, false, false, "advect_lds64_kernel<4, false, false>")
-        if (A.cyclic) LC_LDS64(-1, true, false, "advect_lds64_kernel<-1, true, false>")
-        LC_LDS64(-1, false, false, "advect_lds64_kernel<-1, false, false>")
+        if (A.u_raw) {
+            if (A.K == 4 && A.cyclic) LC_LDS64(4, true, 1, "advect_lds64_kernel<4, true, 1>")
+            if (A.K == 4) LC_LDS64(4, false, 1, "advect_lds64_kernel<4, false, 1>")
+            if (A.cyclic) LC_LDS64(-1, true, 1, "advect_lds64_kernel<-1, true, 1>")
+            LC_LDS64(-1, false, 1, "advect_lds64_kernel<-1, false, 1>")
+        }
+        if (A.K == 4 && A.cyclic) LC_LDS64(4, true, 0, "advect_lds64_kernel<4, true, 0>")
+        if (A.K == 4) LC_LDS64(4, false, 0, "advect_lds64_kernel<4, false, 0>")
+        if (A.cyclic) LC_LDS64(-1, true, 0, "advect_lds64_kernel<-1, true, 0>")
+        LC_LDS64(-1, false, 0, "advect_lds64_kernel<-1, false, 0>")
 #undef LC_LDS64
     }
     // order 3 (SETTLS_order = 0 included: the Euler sample has its own tile)
@@ -2761,15 +2849,15 @@ struct DirectLaunch {
     static const char *launch(const AdvectArgs<T> &A, int grid, hipStream_t st) {
         if constexpr (ORDER == 1 && sizeof(T) == 8) {
             if (A.u_raw) {  // exact order with the raw planes as the order-1 source (lc_advect_ex)
-                hipLaunchKernelGGL((advect_kernel<T, 1, false, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
-                return "advect_kernel<double, 1, false, true>";
+                hipLaunchKernelGGL((advect_kernel<T, 1, false, SRC_RAW_EULER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+                return "advect_kernel<double, 1, false, 1>";
             }
         }
         hipLaunchKernelGGL((advect_kernel<T, ORDER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
         // (as a profiler prints them: all four template arguments)
-        return ORDER == 1 ? "advect_kernel<double, 1, false, false>" : ORDER == 2 ? "advect_kernel<double, 2, false, false>"
-             : ORDER == 3 ? "advect_kernel<double, 3, false, false>" : ORDER == 4 ? "advect_kernel<double, 4, false, false>"
-                                                                                  : "advect_kernel<double, 5, false, false>";
+        return ORDER == 1 ? "advect_kernel<double, 1, false, 0>" : ORDER == 2 ? "advect_kernel<double, 2, false, 0>"
+             : ORDER == 3 ? "advect_kernel<double, 3, false, 0>" : ORDER == 4 ? "advect_kernel<double, 4, false, 0>"
+                                                                              : "advect_kernel<double, 5, false, 0>";
     }
 };
 template <int ORDER>
@@ -2983,7 +3071,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
                 int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, const void *x_start,
-                const void *y_start, int wind_f32 = 0, int n_members = 1, int t0_stride = 0) {
+                const void *y_start, int wind_f32 = 0, int n_members = 1, int t0_stride = 0, int fuse_levels_raw = 0) {
     AdvectArgs<T> A{};
     A.wind_f32 = wind_f32;
     A.n_members = n_members;
@@ -3004,6 +3092,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.u_raw = (const T *)u_raw;  // (lc_advect_ex validated: only where a kernel reads them)
     A.v_raw = (const T *)v_raw;
     A.raw_plane = (size_t)ny_f * nx_f;
+    A.ext_raw = fuse_levels_raw && sizeof(T) == 8 && order == 1 && u_raw && !wind_f32 && !packed_ext;
     A.level_elems = lc_level_elems(ny_f, nx_f);
     A.pitch = nx_f + LC_PAD;
     A.ny_f = ny_f;
@@ -3069,7 +3158,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // measured and dropped (it costs 5 % everywhere to save 8 % in that extreme).
     // lc_ctx_set_lds_tiles / LCS_LDS_TILES (read once at context creation) override (profiling).
     const bool use_lds = ctx->lds_tiles != 0;
-    const bool fused64 = sizeof(T) == 8 && A.ext != nullptr;  // single-sample iterations in float64
+    const bool fused64 = sizeof(T) == 8 && (A.ext != nullptr || A.ext_raw);  // single-sample iterations in float64
     const char *name = nullptr;
     auto launch = [&](const AdvectArgs<T> &A) {
         if (order == 2 || order == 4 || order == 5) {  // generic direct kernel, any dtype
@@ -3080,7 +3169,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 name = Lds64Launch<T>::launch_o3(A, grid, ctx->stream, ctx->lds_tiles);
                 if (!name) {
                     hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
-                    name = "advect_kernel<double, 3, true, false>";
+                    name = "advect_kernel<double, 3, true, 0>";
                 }
             } else if (!(use_lds && (name = LdsLaunch<T, 3>::launch(A, grid, ctx->stream, ctx->lds_tiles)))) {
                 name = DirectLaunch<T, 3>::launch(A, grid, ctx->stream);
@@ -3090,12 +3179,15 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 name = Lds64Launch<T>::launch(A, grid, ctx->stream, ctx->lds_tiles);
                 if (!name) {
                     if constexpr (sizeof(T) == 8) {
-                        if (A.u_raw) {
-                            hipLaunchKernelGGL((advect_kernel<T, 1, true, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
-                            name = "advect_kernel<double, 1, true, true>";
+                        if (A.ext_raw) {
+                            hipLaunchKernelGGL((advect_kernel<T, 1, true, SRC_RAW_ALL>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
+                            name = "advect_kernel<double, 1, true, 2>";
+                        } else if (A.u_raw) {
+                            hipLaunchKernelGGL((advect_kernel<T, 1, true, SRC_RAW_EULER>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
+                            name = "advect_kernel<double, 1, true, 1>";
                         } else {
                             hipLaunchKernelGGL((advect_kernel<T, 1, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
-                            name = "advect_kernel<double, 1, true, false>";
+                            name = "advect_kernel<double, 1, true, 0>";
                         }
                     }
                 }
@@ -3209,6 +3301,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         int rc = LC_OK;
         if (restart >= 0) {
             A.ext = nullptr;  // the exact path keeps the reference's two-sample form
+            A.ext_raw = 0;
             rc = advect_outer_impl<T>(ctx, A, restart, restart > 0 ? saved : (const T *)A.x_start,
                                       restart > 0 ? saved + plane_elems : (const T *)A.y_start);
         }
@@ -3483,9 +3576,9 @@ extern "C" int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args) {
         return advect_impl<float>(ctx, packed_lin, packed_cub, packed_ext, u_raw, v_raw, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
                                   lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                   interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start, 0,
-                                  n_members, t0_stride);
+                                  n_members, t0_stride, 0);
     return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, u_raw, v_raw, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
                                lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start,
-                               dtype == LC_F64_WIND_F32, n_members, t0_stride);
+                               dtype == LC_F64_WIND_F32, n_members, t0_stride, a.fuse_levels_raw);
 }

@@ -69,6 +69,7 @@ class PackedField:
     dtype: np.dtype
     wind_f32: bool = False          # float32 wind on float64 coordinates: numpy's promotion rules in lc_advect
     order: int = 1                  # interpolation order the field was prepared for (order 1 is always available)
+    fuse_raw: bool = False          # float64 at order 1: fused levels with NO packed image (2 F[t] - F[t+1] formed from u, v in the kernels)
     u: "torch.Tensor | None" = None  # the raw planes (nt, ny_f, nx_f) the images were packed from, kept as the ORDER-1 source
     v: "torch.Tensor | None" = None  # (lc_advect_ex: pole rows at any order, the Euler sample in float64) -- not copies: do not
     #                                  modify them in place while the field is in use
@@ -198,6 +199,9 @@ class Engine:
         return int(self.lib.lc_ctx_last_advect_launches(self.ctx))
 
     TWO_SEED_MIN = 1 << 23   # seeds per call from which lc_advect's default is the two-seeds-per-lane kernel
+    # float64 at order 1 with fused levels: build the fused-level image (True), or let the kernels form it from the raw
+    # planes (False: no pack at all).  Measured on BASELINE configs[1] (profiles/r04): see DESIGN.md section 4.
+    EXT_IMAGE_F64 = True
 
     class _Concurrent:
         """Context manager for ``n`` advect calls running side by side on different streams: what fills the machine is
@@ -246,7 +250,7 @@ class Engine:
 
     # ------------------------------------------------------------------ field
     def prepare_field(self, u, v, lat_f, lon_f, interp_order: int = 1, dtype=None, fuse_levels=None,
-                      lin_image=None) -> PackedField:
+                      lin_image=None, ext_image=None) -> PackedField:
         """Upload (if needed) and pack a wind series.  u, v: (nt, ny_f, nx_f).
 
         ``lin_image``: build the order-1 image too.  Default (None): only where a kernel reads it -- float32 at
@@ -254,6 +258,10 @@ class Engine:
         pole seed rows at any order, LCS/tools.py:31-39, and in float64 the Euler sample): the field keeps a reference to
         the device copies of ``u`` and ``v`` instead of a second, interleaved copy, the pack writes a third (order 1) to a
         fifth (order 3) fewer bytes, and results are bit-identical either way.
+
+        ``ext_image`` (float64 at ``interp_order=1`` with ``fuse_levels``): False = do not build the fused-level image
+        either -- the kernels form ``2 F[t] - F[t+1]`` from the raw planes node by node (``lc_advect_args.fuse_levels_raw``;
+        the same expression, bit-identical results): such a field needs NO pack at all.  Default: see ``EXT_IMAGE_F64``.
 
         ``fuse_levels``: also build ext[t] = 2 F[t] - F[t+1] so each SETTLS iteration takes one
         gather instead of two (interpolation is linear in the field => the same value up to rounding).
@@ -286,10 +294,13 @@ class Engine:
         if wind_f32 or interp_order in (2, 4, 5):   # general orders: generic direct kernel, two-sample form
             fuse_levels = False
         ext = None
-        if fuse_levels and nt >= 2:
-            ext = self._empty((self.lib.lc_packed_elems(nt - 1, ny_f, nx_f),), dtype)
         if lin_image is None:
             lin_image = dtype == f32 and interp_order == 1
+        fuse_raw = False
+        if fuse_levels and nt >= 2 and dtype != f32 and interp_order == 1 and not lin_image:
+            fuse_raw = not (self.EXT_IMAGE_F64 if ext_image is None else ext_image)
+        if fuse_levels and nt >= 2 and not fuse_raw:
+            ext = self._empty((self.lib.lc_packed_elems(nt - 1, ny_f, nx_f),), dtype)
         if dtype == f32 and interp_order == 1 and not lin_image:
             raise ValueError("float32 at interp_order=1 samples the order-1 image: lin_image cannot be False")
         lin = self._empty((n,), dtype) if lin_image else None
@@ -305,7 +316,7 @@ class Engine:
         la = lat_f.astype(dtype)
         lo = lon_f.astype(dtype)
         return PackedField(lin, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
-                           wind_f32, int(interp_order), None if lin is not None else ud, None if lin is not None else vd)
+                           wind_f32, int(interp_order), fuse_raw, None if lin is not None else ud, None if lin is not None else vd)
 
     # ------------------------------------------------------------------ global pre-processing (LCS.py:105-118)
     def regrid(self, u, lat, lon, lats, lons):
@@ -447,7 +458,8 @@ class Engine:
             lon_min=field.lon_min, lon_max=field.lon_max, seed_lat_dev=p(slat), ny=int(ny), seed_lon_dev=p(slon), nx=int(nx),
             row0=int(row0), ny_global=int(ny_global), x_start=p(sx), y_start=p(sy), timestep=float(timestep),
             settls_order=int(K), interp_order=int(interp_order), cyclic_x=int(xmode), t0=int(t0), nsteps=int(nsteps),
-            n_members=int(n_members), t0_stride=int(t0_stride), x_out=p(x), y_out=p(y), traj_x=p(tx), traj_y=p(ty))
+            n_members=int(n_members), t0_stride=int(t0_stride), x_out=p(x), y_out=p(y), traj_x=p(tx), traj_y=p(ty),
+            fuse_levels_raw=int(bool(field.fuse_raw and interp_order == 1)))
 
     def sample(self, field: PackedField, pos_x, pos_y, level=0, interp_order=1, row0=0, ny_global=None):
         """tools.xr_map_coordinates for (u, v) of one time level at positions (ny, nx) in degrees."""

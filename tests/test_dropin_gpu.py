@@ -14,7 +14,7 @@ from tests import labelled
 
 pytestmark = pytest.mark.gpu
 # numpy / scipy's operation order in float64 (fuse_levels=False); at order 1 with the raw planes as the order-1 source
-EXACT_ORDER_KERNEL = {1: "advect_kernel<double, 1, false, true>", 3: "advect_kernel<double, 3, false, false>"}
+EXACT_ORDER_KERNEL = {1: "advect_kernel<double, 1, false, 1>", 3: "advect_kernel<double, 3, false, 0>"}
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -217,4 +217,4 @@ def test_float64_dropin_keeps_the_reference_operation_order_at_the_example_size(
     finally:
         eng.set_f64_fidelity("auto")
     x2, _ = trajectory.parcel_propagation(ds.u, ds.v, timestep=-21600, SETTLS_order=4, cyclic_xboundary=True, verbose=False)
-    assert eng.last_advect_kernel() == "advect_kernel<double, 3, false, false>"
+    assert eng.last_advect_kernel() == "advect_kernel<double, 3, false, 0>"

@@ -98,7 +98,7 @@ def test_config2_full_size_subset_vs_oracle(eng):
     u, v, lat, lon = flows.config2()
     f = eng.prepare_field(u, v, lat, lon, 1)
     r = eng.lcs(f, lat, lon, -900.0, SETTLS_order=4, interp_order=1, cyclic_xboundary=True)
-    assert eng.last_advect_kernel() == "advect_lds64_kernel<4, true, true>", eng.last_advect_kernel()   # (order-1 source: the raw planes)
+    assert eng.last_advect_kernel() == "advect_lds64_kernel<4, true, 1>", eng.last_advect_kernel()   # (order-1 source: the raw planes)
     rows, cols = _subset(1024, 24, 1), _subset(1024, 24, 0)
     xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=1,
                                     cyclic_xboundary=True, seed_lat=lat[rows], seed_lon=lon[cols])

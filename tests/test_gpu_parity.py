@@ -136,7 +136,7 @@ def test_raw_planes_as_the_order1_source_equal_the_lin_image_bit_for_bit(eng, dt
                 for p, q in zip(a, b):
                     assert np.array_equal(_np(p), _np(q), equal_nan=True), (ka, kb, cyc, lds)
                 if dtype == np.float64 and order == 1 and K > 0 and cyc:
-                    assert ka.endswith(", true>") and kb.endswith(", false>"), (ka, kb)     # the raw / lin kernel variants
+                    assert ka.endswith(", 1>") and kb.endswith(", 0>"), (ka, kb)     # the raw / lin kernel variants
         finally:
             eng.set_lds_tiles(-1)
     # a row block of a sharded grid (the pole rule by global row index) and the standalone sample
@@ -151,6 +151,48 @@ def test_raw_planes_as_the_order1_source_equal_the_lin_image_bit_for_bit(eng, dt
         a = eng.advect(f_raw, slat, slon, -1800.0, K, 1, True)
         b = eng.advect(f_lin, slat, slon, -1800.0, K, 1, True)
         assert all(np.array_equal(_np(p), _np(q), equal_nan=True) for p, q in zip(a, b))
+
+
+@pytest.mark.parametrize("K,cyclic", [(4, True), (2, True), (4, False), (1, False)])
+def test_float64_fused_levels_without_any_packed_image_equal_the_ext_image_bit_for_bit(eng, K, cyclic):
+    """lc_advect_args.fuse_levels_raw: float64 at order 1 with the fused-level value 2 F[t] - F[t+1] formed from the raw
+    planes inside the kernels (tile staging, out-of-tile gathers, the direct kernel) -- the expression lc_field_pack
+    evaluates, one rounding -- so a field prepared with ext_image=False holds NO packed image and still gives the bits of
+    the ext-image form: LDS-tile and direct kernels, trajectories, a row block with a continuation, pole rows, seeds on
+    the last node row / column (mirrored neighbour), a seed grid sparser and one denser than the field."""
+    u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
+    u, v, lat, lon = (a.astype(np.float64) for a in (u * 2.0, v, lat, lon))
+    f_img = eng.prepare_field(u, v, lat, lon, 1, ext_image=True)
+    f_raw = eng.prepare_field(u, v, lat, lon, 1, ext_image=False)
+    assert f_raw.lin is None and f_raw.ext is None and f_raw.cub is None and f_raw.fuse_raw and f_img.ext is not None
+    for sny, snx in ((150, 200), (40, 60), (300, 512), (72, 144)):
+        slat, slon = (a.astype(np.float64) for a in flows.seed_grid(sny, snx, lat, lon))
+        try:
+            for mode in (-1, 0):
+                eng.set_lds_tiles(mode)
+                out = []
+                for f in (f_img, f_raw):
+                    r = eng.advect(f, slat, slon, -1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+                                   noncyclic_clamp="pointwise", return_traj=True)
+                    name = eng.last_advect_kernel()
+                    lo, hi = 0, sny // 2
+                    rb = eng.advect(f, slat[lo:hi], slon, -1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+                                    noncyclic_clamp="pointwise", row0=lo, ny_global=sny, t0=3, nsteps=5, start=(r[2][3][lo:hi], r[3][3][lo:hi]))
+                    out.append(([_np(t) for t in r] + [_np(t) for t in rb], name))
+                (a, na), (b, nb) = out
+                assert na.endswith(", 1>") and nb.endswith(", 2>") and ("lds64" in nb) == (mode == -1), (na, nb)
+                for p, q in zip(a, b):
+                    assert np.array_equal(p, q), (sny, snx, mode, na, nb)
+        finally:
+            eng.set_lds_tiles(-1)
+    # the reference's outer-product clamp falls back to the two-sample sub-step path from the same field
+    rng = np.random.default_rng(3)
+    la, lo_ = np.linspace(-40, 40, 41), np.linspace(-60, 50, 56)
+    uu, vv = 30 + 25 * rng.standard_normal((5, 41, 56)), 8 * rng.standard_normal((5, 41, 56))
+    xa, ya = eng.advect(eng.prepare_field(uu, vv, la, lo_, 1, ext_image=True), la, lo_, 7200.0, 2, 1, False)
+    ka = eng.last_advect_kernel()
+    xb, yb = eng.advect(eng.prepare_field(uu, vv, la, lo_, 1, ext_image=False), la, lo_, 7200.0, 2, 1, False)
+    assert ka == eng.last_advect_kernel() == "outer_substep_kernel" and np.array_equal(_np(xa), _np(xb)) and np.array_equal(_np(ya), _np(yb))
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 2e-13), (np.float32, 2e-5)])
@@ -554,7 +596,7 @@ def test_lcs_host_route_matches_engine(eng):
     # float64 at the example's size: the host route keeps numpy / scipy's operation order (LC_F64_AUTO)
     f = eng.prepare_field(u, v, lat, lon, 3, fuse_levels=False)
     r = eng.lcs(f, lat, lon, -21600, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
-    assert eng.last_advect_kernel() == "advect_kernel<double, 3, false, false>"
+    assert eng.last_advect_kernel() == "advect_kernel<double, 3, false, 0>"
     assert np.array_equal(out["x_dep"], _np(r["x_dep"])) and np.array_equal(out["sigma"], _np(r["sigma"]))
     assert out["traj_x"].shape == (8, 89, 180) and np.array_equal(out["traj_x"][-1], out["x_dep"])
     g = np.load(os.path.join(GOLD, "g1_bwd_k4_o3.npz"))
@@ -863,9 +905,9 @@ def test_float64_fused_levels_option(eng, O, order):
     f_fused = eng.prepare_field(u, v, lat, lon, order)
     assert f_exact.ext is None and f_fused.ext is not None
     xe, ye = eng.advect(f_exact, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
-    assert eng.last_advect_kernel() == {1: "advect_kernel<double, 1, false, true>", 3: "advect_kernel<double, 3, false, false>"}[order]
+    assert eng.last_advect_kernel() == {1: "advect_kernel<double, 1, false, 1>", 3: "advect_kernel<double, 3, false, 0>"}[order]
     xf, yf = eng.advect(f_fused, lat, lon, -900.0, SETTLS_order=4, interp_order=order)
-    assert eng.last_advect_kernel() == ("advect_lds64_kernel<4, true, true>" if order == 1 else "advect_lds64_o3_kernel<4, true>")
+    assert eng.last_advect_kernel() == ("advect_lds64_kernel<4, true, 1>" if order == 1 else "advect_lds64_o3_kernel<4, true>")
     xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=order,
                                   cyclic_xboundary=True)
     for got, ref in ((xf, xo), (yf, yo)):
