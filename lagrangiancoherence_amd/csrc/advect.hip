@@ -20,6 +20,8 @@
 // the 2x2 (order 1) or 4x4 (order 3) tap window of a wrapped coordinate is
 // always in range and its (u,v) pairs are contiguous along x, so one sample
 // position costs 2 (order 1, float) wide loads per level instead of 8 scalars.
+#include <type_traits>
+
 #include "lcs_common.h"
 #include "launch_plan.h"
 
@@ -2601,16 +2603,32 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
 // tiles: a 16 x 16-node tile of img[t] around the patch's current position serves the Euler sample, one of ext[t] anchored on
 // the predicted travel the K iterations; 4 x 4 windows read row by row (cubic_taps_fast64, the function the direct kernel
 // uses: bit-identical); lanes whose window left a tile take the same taps from global memory.  8 x 8 seeds per wave.
+// Tile shapes (nodes).  Iteration tile of ext[t]: 16 x 16 at pitch 24 -- 384-byte rows put the four patch rows of a
+// ds_read_b128 lane group into different bank quarters (conflicts 161 M -> 96 M per launch on config 2, the wave's LDS wait
+// halved).  Euler tile of img[t]: 12 rows (the patch where it is: 8 rows + the window) at pitch 20, so that both fit 39 KB
+// per workgroup = four workgroups per CU.  Measured on config 2 at order 3 (profiles/r04/c2_o3_lds_pitch_ab.txt): pitch 20
+// for both 16-row tiles 6.39 ms, this 6.24-6.33; pitch 24 for both 16-row tiles (48 KB, three workgroups per CU) 6.79
+// although each wave runs 18 % shorter; round 2-3: pitch 17 8.46, 20 7.90, 24 (48 KB) 8.25.
 #ifndef LCS_T64O3_PITCH
-#define LCS_T64O3_PITCH 20  // nodes; 320-byte rows: the 8 + 8 lanes of a 16-lane read group (two patch rows) overlap in half of the banks instead of 7/8 (pitch 17: 8.46 ms on config 2, 20: 7.90, 24 -- no overlap, but 48 KB of LDS = 3 workgroups per CU -- 8.25)
+#define LCS_T64O3_PITCH 24
 #endif
-constexpr int T64O3 = 16, T64O3_PITCH = LCS_T64O3_PITCH;
+#ifndef LCS_T64O3_EROWS
+#define LCS_T64O3_EROWS 12   // rows of the Euler tile (img[t]: the patch where it is, 8 rows + the window = 11 at least)
+#endif
+#ifndef LCS_T64O3_EPITCH
+#define LCS_T64O3_EPITCH 20
+#endif
+constexpr int T64O3 = 16, T64O3_PITCH = LCS_T64O3_PITCH, T64O3_EROWS = LCS_T64O3_EROWS, T64O3_EPITCH = LCS_T64O3_EPITCH;
+static_assert(T64O3_EROWS % 4 == 0 && T64O3_EROWS >= 12 && T64O3_EROWS <= T64O3, "Euler tile rows");
+#ifndef LCS_LDS64_O3_MINWAVES
+#define LCS_LDS64_O3_MINWAVES 4   // 128 vector registers: the kernel compiles to 126-129 depending on the tile shapes, and 129 is a wave per SIMD less
+#endif
 template <int KFIX, bool CYCLIC>
-__global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs<double> A0) {
+__global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_kernel(const AdvectArgs<double> A0) {
 #pragma clang fp contract(off)
     const AdvectArgs<double> A = for_member(A0);
     const int K = KFIX >= 0 ? KFIX : A.K;
-    __shared__ __attribute__((aligned(16))) d2 s_tiles[BLOCK / 64][2][T64O3 * T64O3_PITCH];
+    __shared__ __attribute__((aligned(16))) d2 s_tiles[BLOCK / 64][T64O3_EROWS * T64O3_EPITCH + T64O3 * T64O3_PITCH];
     if (pole_block(A)) return;
     const int tile_id = xcd_tile_id(A);
     if (tile_id >= A.ntiles) return;  // whole block
@@ -2618,7 +2636,7 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs
     const int ix = txi * TILE_W + (threadIdx.x % TILE_W);
     const int iy = tyi * TILE_H + (threadIdx.x / TILE_W);
     const int lane = threadIdx.x & 63;
-    d2 *etile = s_tiles[threadIdx.x >> 6][0], *gtile = s_tiles[threadIdx.x >> 6][1];
+    d2 *etile = s_tiles[threadIdx.x >> 6], *gtile = s_tiles[threadIdx.x >> 6] + T64O3_EROWS * T64O3_EPITCH;
     bool live = ix < A.nx && iy < A.ny;
     if (live) {
         const int grow = A.row0 + iy;
@@ -2647,35 +2665,42 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs
     const double kpred = 0.5 * (double)(K > 0 ? K - 1 : 0);
     const d2 zero = {0.0, 0.0};
     // window origins (padded (y0, x0)) a tile with padded origin (oy, ox) serves: [ox, ox + 16 - 4] x [oy, oy + 16 - 4]
-    auto stage_tile = [&](const double *level, int ox, int oy, d2 *tile) {
-        d2 st[T64O3 / 4];
+    // (ROWS, PITCH: the tile's shape -- the Euler tile may be lower than the iteration tile: it serves the patch where it is)
+    auto stage_tile = [&](const double *level, int ox, int oy, d2 *tile, auto rows_c, auto pitch_c) {
+        constexpr int ROWS = decltype(rows_c)::value, PITCH = decltype(pitch_c)::value;
+        d2 st[ROWS / 4];
         const char *src = (const char *)level + ((size_t)oy * pad_cols + ox) * 16;
 #pragma unroll
-        for (int r = 0; r < T64O3 / 4; ++r) __builtin_memcpy(&st[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+        for (int r = 0; r < ROWS / 4; ++r) __builtin_memcpy(&st[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
         __builtin_amdgcn_wave_barrier();  // the previous level's reads of this tile are done (LDS ops of a wave are in order)
 #pragma unroll
-        for (int r = 0; r < T64O3 / 4; ++r) tile[(r * 4 + st_row) * T64O3_PITCH + st_col] = st[r];
+        for (int r = 0; r < ROWS / 4; ++r) tile[(r * 4 + st_row) * PITCH + st_col] = st[r];
         __builtin_amdgcn_wave_barrier();
     };
-    auto sample = [&](const double *level, const d2 *tile, int ox, int oy, bool have, double px, double py, d2 start) {
+    auto sample = [&](const double *level, const d2 *tile, int ox, int oy, bool have, double px, double py, d2 start, auto rows_c, auto pitch_c) {
+        constexpr int ROWS = decltype(rows_c)::value, PITCH = decltype(pitch_c)::value;
         const Loc64 t = locate_fast64(A, px, py);
         double wx[4], wy[4];
         cubic_weights_fast64(t.tx, wx);
         cubic_weights_fast64(t.ty, wy);
         const int rx = t.x0 - ox, ry = t.y0 - oy;
-        if (have && (unsigned)rx <= (unsigned)(T64O3 - 4) && (unsigned)ry <= (unsigned)(T64O3 - 4))
-            return cubic_taps_lds64<T64O3_PITCH>(lds_address(tile) + (unsigned)(ry * T64O3_PITCH + rx) * 16u, wx, wy, start);
+        if (have && (unsigned)rx <= (unsigned)(T64O3 - 4) && (unsigned)ry <= (unsigned)(ROWS - 4))
+            return cubic_taps_lds64<PITCH>(lds_address(tile) + (unsigned)(ry * PITCH + rx) * 16u, wx, wy, start);
         return cubic_taps_fast64((const d2 *)level + ((size_t)t.y0 * A.pitch + t.x0), (size_t)A.pitch, wx, wy, start);
     };
+    typedef std::integral_constant<int, T64O3_EROWS> ERows;
+    typedef std::integral_constant<int, T64O3_EPITCH> EPitch;
+    typedef std::integral_constant<int, T64O3> GRows;
+    typedef std::integral_constant<int, T64O3_PITCH> GPitch;
     for (int s = 0; s < A.nsteps; ++s) {
         // ---- 1. Euler sample out of a tile of img[t] centred on the patch's current position -------------------------
         const double c0x = (x - A.lon_min) * A.sx, c0y = (y - A.lat_min) * A.sy;
         const int exm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(c0x, -4.0), 1.0e9)), CENTRE);
         const int eym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(c0y, -4.0), 1.0e9)), CENTRE);
-        const int eox = min(max(exm - (T64O3 - 4) / 2, 0), pad_cols - T64O3), eoy = min(max(eym - (T64O3 - 4) / 2, 0), pad_rows - T64O3);
-        stage_tile(lvl, eox, eoy, etile);
+        const int eox = min(max(exm - (T64O3 - 4) / 2, 0), pad_cols - T64O3), eoy = min(max(eym - (T64O3_EROWS - 4) / 2, 0), pad_rows - T64O3_EROWS);
+        stage_tile(lvl, eox, eoy, etile, ERows(), EPitch());
         const double x0p = x, y0p = y;
-        const d2 e = sample(lvl, etile, eox, eoy, true, x, y, zero);   // trajectory.py:82-84
+        const d2 e = sample(lvl, etile, eox, eoy, true, x, y, zero, ERows(), EPitch());   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                                        // :86
         x = fma(dtcx, e.x, x);                                          // :87
         clamp_position<double>(A, x, y);                                // :89-97
@@ -2687,11 +2712,11 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64_o3_kernel(const AdvectArgs
             const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
             ox = min(max(rxm - (T64O3 - 4) / 2, 0), pad_cols - T64O3);
             oy = min(max(rym - (T64O3 - 4) / 2, 0), pad_rows - T64O3);
-            stage_tile(elv, ox, oy, gtile);
+            stage_tile(elv, ox, oy, gtile, GRows(), GPitch());
         }
         // ---- 3. K iterations out of LDS ---------------------------------------------------------------------------------
         for (int k = 0; k < K; ++k) {
-            const d2 d = sample(elv, gtile, ox, oy, true, x, y, e);   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
+            const d2 d = sample(elv, gtile, ox, oy, true, x, y, e, GRows(), GPitch());   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
             y = fma(A.hdtcy, d.y, y);
             x = fma(hdtcx, d.x, x);
             clamp_position<double>(A, x, y);
