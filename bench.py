@@ -672,13 +672,28 @@ def main():
         a, b = lo - n_lo, hi + n_hi
         xr, yr = eng.advect(field, slat_d[a:b], slon_d, dt, K, order, True, 0, nsteps, row0=a, ny_global=ny_global)
 
+        mismatch = {}
+
         def rows_equal(xe, ye):
             ok = bool(torch.equal(xe, xr) and torch.equal(ye, yr))
+            if not ok:   # what differs, for the line: rows of this rank's extended block, NaN = a row that was never filled
+                bad = ((xe != xr) | (ye != yr)).any(dim=1).nonzero().flatten().tolist()
+                if os.environ.get("LCS_HALO_DEBUG"):   # which of the two is unstable: the redundant advect once more, and the block once more
+                    xr2, yr2 = eng.advect(field, slat_d[a:b], slon_d, dt, K, order, True, 0, nsteps, row0=a, ny_global=ny_global)
+                    xm, ym = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo, ny_global=ny_global)
+                    sys.stderr.write(f"bench.py: rank {rank}: redundant twice equal {torch.equal(xr, xr2) and torch.equal(yr, yr2)}; "
+                                     f"block again == redundant {torch.equal(xm, xr[n_lo:n_lo + hi - lo])}; "
+                                     f"block again == timed block {torch.equal(xm, xe[n_lo:n_lo + hi - lo])}; max |dx| {float((xe - xr).abs().max())}\n")
+                mismatch[rank] = {"rows_of_extended_block": bad[:8], "n_rows": len(bad), "nan": bool(torch.isnan(xe).any() or torch.isnan(ye).any()),
+                                  "block": [a, b], "halo": [n_lo, n_hi]}
             t = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item())
         halo_check = {"rows_per_neighbour": sharded.HALO, "timed_path": "lc_halo_exchange" if native else "torch.distributed",
                       "timed_path_ok": rows_equal(x_ext, y_ext)}
+        if mismatch:
+            sys.stderr.write(f"bench.py: rank {rank}: halo check failed: {mismatch[rank]}\n")
+            halo_check["mismatch_rank%d" % rank] = mismatch[rank]
         # LCS_HALO_CHECK_BOTH=1: also run the OTHER exchange path once and check it the same way (off by default: the
         # C ABI's own RCCL communicator has only ever been created on one-GPU boxes, and a stuck ncclCommInitRank in
         # an untimed extra must not cost the run its result)
