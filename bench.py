@@ -443,6 +443,14 @@ def main():
         if not os.environ.get("LCS_BENCH_ONE_GPU"):
             have = visible_gpu_count()                     # from /dev: no torch import, no HIP / HSA runtime in the parent
             if have < args.gpus:
+                # the /dev heuristic says too few: before refusing, ask the runtime itself (only on this path does the
+                # launcher load it; a container whose device nodes are laid out differently must not be turned away)
+                try:
+                    import torch
+                    have = max(have, int(torch.cuda.device_count()))
+                except Exception:
+                    pass
+            if have < args.gpus:
                 raise SystemExit(f"--gpus {args.gpus}: this machine shows {have} GPU(s) (one rank per GPU; "
                                  "LCS_BENCH_BACKEND=gloo LCS_BENCH_ONE_GPU=1 rehearses the N>1 path on one)")
         limit = float(os.environ.get("LCS_BENCH_TIMEOUT", "900"))
