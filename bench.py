@@ -274,31 +274,45 @@ def watchdog(seconds: float, what: str, rank: int):
     return t
 
 
-def timed_case(torch, eng, prepare, advect, sigma, steps, warmup):
+def timed_case(torch, eng, prepare, advect, sigma, steps, warmup, pack_and_advect=None):
     """`steps` passes of pack -> advect -> sigma (after `warmup` untimed ones): wall time per step and the mean HIP-event
-    time of each stage on the launch stream."""
-    def one():
+    time of each stage on the launch stream.  `pack_and_advect` (Engine.pack_and_advect where its pipelined form is the
+    default: chunk k+1 packed on a side stream while chunk k is advected): the TIMED passes run that one call instead of
+    prepare + advect, `pack_advect_overlapped` is its event time, and the stage times `pack` / `advect` come from serial
+    passes (prepare, advect one after the other) run after the timed region -- they overlap in the timed passes."""
+    def one(serial):
         m = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         m[0].record()
-        f = prepare()
-        m[1].record()
-        r = advect(f)
+        if pack_and_advect is not None and not serial:
+            m[1].record()
+            r = pack_and_advect()
+        else:
+            f = prepare()
+            m[1].record()
+            r = advect(f)
         m[2].record()
         s = sigma(r)
         m[3].record()
         return s, m
     for _ in range(warmup):
-        one()
+        one(False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks = []
     for _ in range(steps):
-        s, m = one()
+        s, m = one(False)
         marks.append(m)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ms = {k: float(np.mean([m[i].elapsed_time(m[i + 1]) for m in marks])) for i, k in enumerate(("pack", "advect", "sigma"))}
     assert bool(torch.isfinite(s).all()), "non-finite sigma in a benchmark case"
+    if pack_and_advect is not None:
+        ms["pack_advect_overlapped"] = ms["advect"]
+        one(True)
+        serial = [one(True)[1] for _ in range(max(2, min(steps, 3)))]
+        torch.cuda.synchronize()
+        ms["pack"] = float(np.mean([m[0].elapsed_time(m[1]) for m in serial]))
+        ms["advect"] = float(np.mean([m[1].elapsed_time(m[2]) for m in serial]))
     return el / steps, ms
 
 
@@ -309,9 +323,9 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
     ms per step, the advect kernel that ran, its stage times and its flop fraction of the vector peak."""
     out = {}
 
-    def case(name, pts, K, order, s_p, prepare, advect, sigma):
+    def case(name, pts, K, order, s_p, prepare, advect, sigma, pack_and_advect=None):
         try:
-            per_step, ms = timed_case(torch, eng, prepare, advect, sigma, steps, warmup)
+            per_step, ms = timed_case(torch, eng, prepare, advect, sigma, steps, warmup, pack_and_advect)
             n_k = max(eng.last_advect_launches(), 1)
             peak = FP32_VECTOR_TFLOPS if s_p == 4 else FP64_VECTOR_TFLOPS
             out[name] = {"value": pts / per_step, "unit": "particle-timesteps/s", "ms_per_step": per_step * 1e3, "steps": steps,
@@ -336,8 +350,10 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
         d2 = (float(lat2[1] - lat2[0]), float(lon2[1] - lon2[0]))
         n2 = int(u2.shape[1]) * int(u2.shape[2]) * (int(u2.shape[0]) - 1)
         for order in (1, 3):
+            piped = eng.pipeline_pays(np.float64, order, True, int(u2.shape[0]) - 1, int(u2.shape[1]) * int(u2.shape[2]), True)
             case("c2" if order == 1 else "c2 order 3", n2, K, order, 8, lambda: eng.prepare_field(u2, v2, lat2, lon2, order),
-                 lambda f: eng.advect(f, la_d, lo_d, -900.0, K, order, True), lambda r: eng.sigma(r[0], r[1], la_d, *d2))
+                 lambda f: eng.advect(f, la_d, lo_d, -900.0, K, order, True), lambda r: eng.sigma(r[0], r[1], la_d, *d2),
+                 (lambda: eng.pack_and_advect(u2, v2, lat2, lon2, la_d, lo_d, -900.0, K, order, True)[1:]) if piped else None)
     except Exception as exc:
         out["c2"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     return out
@@ -354,28 +370,18 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
     lat_d, lon_d = eng.to_device(lat, np.float64), eng.to_device(lon, np.float64)
     dlat, dlon = float(lat[1] - lat[0]), float(lon[1] - lon[0])
 
-    def one():
-        m = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        m[0].record()
-        f = eng.prepare_field(ud, vd, lat, lon, order, fuse_levels=args.fuse_levels,
-                              ext_image=None if "LCS_EXT_IMAGE" not in os.environ else os.environ["LCS_EXT_IMAGE"] != "0")
-        m[1].record()
-        x, y = eng.advect(f, lat_d, lon_d, -900.0, K, order, True)
-        m[2].record()
-        s = eng.sigma(x, y, lat_d, dlat, dlon)
-        m[3].record()
-        return s, m
-    for _ in range(args.warmup):
-        one()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    marks = []
-    for _ in range(args.steps):
-        s, m = one()
-        marks.append(m)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    ms = {k: float(np.mean([m[i].elapsed_time(m[i + 1]) for m in marks])) for i, k in enumerate(("pack", "advect", "sigma"))}
+    ext_image = None if "LCS_EXT_IMAGE" not in os.environ else os.environ["LCS_EXT_IMAGE"] != "0"
+    # the pipelined form (chunk k+1 packed on a side stream while chunk k is advected) where the engine makes it the default:
+    # float64 at order 3; --no-pipeline: pack, then advect
+    piped = (not args.no_pipeline and ext_image is None
+             and eng.pipeline_pays(np.float64, order, args.fuse_levels, nt - 1, ny * nx, True))
+    per_step, ms = timed_case(
+        torch, eng, lambda: eng.prepare_field(ud, vd, lat, lon, order, fuse_levels=args.fuse_levels, ext_image=ext_image),
+        lambda f: eng.advect(f, lat_d, lon_d, -900.0, K, order, True), lambda r: eng.sigma(r[0], r[1], lat_d, dlat, dlon),
+        args.steps, args.warmup,
+        (lambda: eng.pack_and_advect(ud, vd, lat, lon, lat_d, lon_d, -900.0, K, order, True, fuse_levels=args.fuse_levels)[1:])
+        if piped else None)
+    el = per_step * args.steps
     pts = ny * nx * (nt - 1)
     wl = {"workload": "c2", "order": order, "K": K, "dtype": "f64", "fuse_levels": bool(args.fuse_levels)}
     img = 2 * (ny + 3) * (nx + 3) * 8
@@ -387,7 +393,10 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {ny}x{nx} seeds = field nodes, moving ideal vortex, {nt} levels, "
                                f"dt=-900 s, fp64", "SETTLS_order": K, "interp_order": order,
-                   "fuse_levels": bool(args.fuse_levels), "build_id": csrc},
+                   "fuse_levels": bool(args.fuse_levels), "build_id": csrc,
+                   "step": ("pack and advect PIPELINED: the images of level chunk k+1 are packed on a side stream while chunk k is "
+                            "advected (Engine.pack_and_advect; kernel_ms.pack_advect_overlapped = their joint event time, "
+                            "kernel_ms.pack / advect = serial passes after the timed region)") if piped else "pack + advect + sigma"},
         "kernel_ms": ms,
         "roofline": roofline(eng.last_advect_kernel(), "valu" if "lds" in eng.last_advect_kernel() else "tcp", pts, ms["advect"], K, order, 8, 8,
                              bool(args.fuse_levels), comp, wl, csrc, eng.last_advect_launches()),
@@ -418,6 +427,8 @@ def main():
     ap.add_argument("--settls", type=int, default=4)
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="c2 only: pack the whole series, then advect (default at order 3: the two pipelined on two streams)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the non-headline workloads the default one-GPU c3 run appends under \"secondary\"")
     ap.add_argument("--traj", action="store_true",

@@ -125,10 +125,10 @@ def parcel_propagation(U, V, timestep=1, propdim="time", verbose=True, return_tr
         times.reverse()                                     # labels only (Q6)
     eng = get_engine()
     verboseprint(f"Propagating {len(times) - 1} time levels on {eng.device}")
-    field = eng.prepare_field(u, v, lat, lon, interp_order,
-                              fuse_levels=eng.f64_fuse_levels(common_dtype(u, v, lat, lon), lat.size * lon.size))
-    res = eng.advect(field, lat, lon, timestep, SETTLS_order=SETTLS_order, interp_order=interp_order,
-                     cyclic_xboundary=cyclic_xboundary, return_traj=return_traj)
+    # pack + advect in one call (large float64 order-3 series: the pack of chunk k+1 overlaps the advect of chunk k)
+    res = eng.pack_and_advect(u, v, lat, lon, lat, lon, timestep, SETTLS_order=SETTLS_order, interp_order=interp_order,
+                              cyclic_xboundary=cyclic_xboundary, return_traj=return_traj,
+                              fuse_levels=eng.f64_fuse_levels(common_dtype(u, v, lat, lon), lat.size * lon.size))[1:]
     coords2d = {"latitude": lat, "longitude": lon}
     if return_traj:
         assert type(times[0]).__name__ != "Datetime360Day", \
@@ -249,13 +249,12 @@ class LCS:
             cyclic_xboundary = False
 
         verboseprint("*---- Parcel propagation ----*")
-        field = eng.prepare_field(uu, vv, lat, lon, traj_interp_order,
-                                  fuse_levels=eng.f64_fuse_levels(common_dtype(uu, vv, lat, lon), lat.size * lon.size))
-        dtype = field.dtype
+        dtype = common_dtype(uu, vv, lat, lon)
         lat_t, lon_t = lat.astype(dtype), lon.astype(dtype)
-        res = eng.lcs(field, lat_t, lon_t, timestep, SETTLS_order=self.SETTLS_order,
-                      interp_order=traj_interp_order, cyclic_xboundary=cyclic_xboundary,
-                      gauss_sigma=self.gauss_sigma, return_traj=return_traj)               # LCS.py:129-154
+        res = eng.lcs_wind(uu, vv, lat, lon, lat_t, lon_t, timestep, SETTLS_order=self.SETTLS_order,
+                           interp_order=traj_interp_order, cyclic_xboundary=cyclic_xboundary,
+                           fuse_levels=eng.f64_fuse_levels(dtype, lat.size * lon.size),
+                           gauss_sigma=self.gauss_sigma, return_traj=return_traj)          # LCS.py:129-154
         verboseprint("*---- Done eigenvalues ----*")
 
         sig = _to_np(res["sigma"])

@@ -600,17 +600,108 @@ class Engine:
                                                 self._ptr(tmp), self._ptr(out)), self.lib)
         return out
 
+    # ------------------------------------------------------------------ pack and advect, pipelined
+    PIPELINE_CHUNK = 16      # time levels per pack / advect stage of the pipelined form (measured: profiles/r04/pipelined_pack_ab.txt)
+
+    def pipeline_pays(self, dtype, interp_order, fuse_levels, nsteps, n_seeds, cyclic_xboundary, return_traj=False) -> bool:
+        """Where packing chunk k+1 on a side stream while chunk k is advected is the default: float64 at order 3 in the
+        fused-level form (the pack's prefilter sweeps run at half the HBM rate and the float64 order-3 advect kernel is
+        latency-bound: 11.0 -> 9.9 ms per step on BASELINE configs[1] at order 3); not float32 (its advect kernels saturate
+        the VALU: nothing to hide behind, measured) and not float64 at order 1 (measured equal)."""
+        return (np.dtype(dtype) == np.dtype(np.float64) and interp_order == 3 and bool(fuse_levels) and cyclic_xboundary
+                and not return_traj and nsteps > self.PIPELINE_CHUNK and n_seeds > _capi.LC_EXACT_ORDER_MAX_SEEDS)
+
+    def pack_and_advect(self, u, v, lat_f, lon_f, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
+                        cyclic_xboundary=True, fuse_levels=None, pipeline=None, chunk=None, return_traj=False,
+                        noncyclic_clamp=None):
+        """:meth:`prepare_field` + :meth:`advect` of the whole series in one call.  Returns ``(field, x, y[, traj_x, traj_y])``.
+
+        ``pipeline`` (None: where it pays, :meth:`pipeline_pays`): the series is cut into chunks of ``chunk`` time levels;
+        the images of chunk k+1 are packed on a side HIP stream while the advect kernel works through chunk k on the
+        current stream (an event per chunk), each advect continuing in place from the previous one (``lc_advect_from``:
+        bit-identical to one call, LCS/trajectory.py:80-126 carries only positions from level to level).  The level shared
+        by two chunks is packed by both (same values; the earlier chunk's advect never reads it).  Results are
+        bit-identical to the serial form; the field returned is complete and reusable."""
+        torch = self.torch
+        lat_f, lon_f = np.asarray(lat_f), np.asarray(lon_f)
+        dtype = common_dtype(u, v, lat_f, lon_f)
+        if fuse_levels is None:
+            fuse_levels = True
+        nt = int(u.shape[0])
+        ny, nx = len(seed_lat), len(seed_lon)
+        if pipeline is None:
+            pipeline = self.pipeline_pays(dtype, interp_order, fuse_levels, nt - 1, ny * nx, cyclic_xboundary, return_traj)
+        chunk = self.PIPELINE_CHUNK if chunk is None else int(chunk)
+        f32 = np.dtype(np.float32)
+        wind_f32 = dtype != f32 and common_dtype(u, v) == f32
+        can = (cyclic_xboundary and not return_traj and interp_order in (1, 3) and fuse_levels and not wind_f32 and nt - 1 > chunk >= 1
+               and not (dtype == f32 and interp_order == 1))      # (float32 at order 1 carries a lin image too: serial form)
+        if not (pipeline and can):
+            field = self.prepare_field(u, v, lat_f, lon_f, interp_order, fuse_levels=fuse_levels)
+            res = self.advect(field, seed_lat, seed_lon, timestep, SETTLS_order, interp_order, cyclic_xboundary,
+                              return_traj=return_traj, noncyclic_clamp=noncyclic_clamp)
+            return (field, *res)
+        if tuple(u.shape) != tuple(v.shape) or len(u.shape) != 3 or lat_f.shape != (u.shape[1],) or lon_f.shape != (u.shape[2],):
+            raise ValueError("u and v must both be (time, latitude, longitude) with matching coordinates")
+        if not (np.all(np.diff(lat_f) > 0) and np.all(np.diff(lon_f) > 0)):
+            raise ValueError("latitude and longitude must be ascending (sort first)")
+        ny_f, nx_f = int(u.shape[1]), int(u.shape[2])
+        ud, vd = self.to_device(u, dtype), self.to_device(v, dtype)
+        le = self.lib.lc_packed_elems(1, ny_f, nx_f)
+        cub = self._empty((le * nt,), dtype) if interp_order == 3 else None
+        ext = self._empty((le * (nt - 1),), dtype)
+        la, lo = lat_f.astype(dtype), lon_f.astype(dtype)
+        field = PackedField(None, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
+                            False, int(interp_order), False, ud, vd)
+        slat, slon = self.to_device(seed_lat, dtype), self.to_device(seed_lon, dtype)
+        x, y = self._empty((ny, nx), dtype), self._empty((ny, nx), dtype)
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        side = self._side_stream
+        side.wait_stream(cur)                  # the wind, the seeds and the buffers above belong to the current stream
+        # (no record_stream on the images: every pack on the side stream is awaited by the current stream below, so by the
+        #  time the field can be freed -- in the current stream's order -- the side stream is done with it; recording the
+        #  6.8 GB of images instead made the caching allocator hold the blocks back and cudaMalloc new ones every step)
+        events, starts = [], list(range(0, nt - 1, chunk))
+        with torch.cuda.stream(side):
+            self._use_current_stream()
+            for t0 in starts:
+                n = min(chunk, nt - 1 - t0)         # image levels [t0, t0 + n], ext levels [t0, t0 + n)
+                _capi.check(self.lib.lc_field_pack(
+                    self.ctx, C.c_void_p(ud[t0:].data_ptr()), C.c_void_p(vd[t0:].data_ptr()), _NP2LC[dtype], n + 1, ny_f, nx_f,
+                    int(interp_order), C.c_void_p(cub[le * t0:].data_ptr()) if cub is not None else None,
+                    C.c_void_p(ext[le * t0:].data_ptr())), self.lib)
+                e = torch.cuda.Event()
+                e.record(side)
+                events.append(e)
+        try:
+            for e, t0 in zip(events, starts):
+                cur.wait_event(e)
+                n = min(chunk, nt - 1 - t0)
+                self.advect(field, slat, slon, timestep, SETTLS_order, interp_order, True, t0=t0, nsteps=n,
+                            start=(x, y) if t0 else None, out=(x, y))
+        finally:
+            cur.wait_stream(side)              # whatever happened above: nothing of this call is left running behind the current stream
+        return field, x, y
+
     # ------------------------------------------------------------------ whole path
-    def lcs(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
-            cyclic_xboundary=True, t0=0, nsteps=None, gauss_sigma=None, fd_fp32_cast=True,
-            tensor_layout="reference", return_traj=False, noncyclic_clamp=None):
-        """advect -> (smooth) -> sigma on one GPU.  Returns dict of device tensors."""
-        dtype = field.dtype
-        seed_lat = np.asarray(seed_lat, dtype=dtype)
-        seed_lon = np.asarray(seed_lon, dtype=dtype)
-        res = self.advect(field, seed_lat, seed_lon, timestep, SETTLS_order, interp_order, cyclic_xboundary, t0,
-                          nsteps, return_traj, noncyclic_clamp=noncyclic_clamp)
-        x, y = res[0], res[1]
+    def lcs_wind(self, u, v, lat_f, lon_f, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1, cyclic_xboundary=True,
+                 fuse_levels=None, gauss_sigma=None, fd_fp32_cast=True, tensor_layout="reference", return_traj=False,
+                 noncyclic_clamp=None, pipeline=None):
+        """:meth:`pack_and_advect` -> (smooth) -> sigma: the whole path from the raw wind series (what the drop-in surface
+        calls).  Returns the dict of :meth:`lcs` plus ``"field"``."""
+        dtype = common_dtype(u, v, np.asarray(lat_f), np.asarray(lon_f))
+        seed_lat, seed_lon = np.asarray(seed_lat, dtype=dtype), np.asarray(seed_lon, dtype=dtype)
+        res = self.pack_and_advect(u, v, lat_f, lon_f, seed_lat, seed_lon, timestep, SETTLS_order, interp_order,
+                                   cyclic_xboundary, fuse_levels, pipeline, None, return_traj, noncyclic_clamp)
+        out = self._sigma_of(res[1], res[2], seed_lat, seed_lon, gauss_sigma, fd_fp32_cast, tensor_layout)
+        out["field"] = res[0]
+        if return_traj:
+            out["traj_x"], out["traj_y"] = res[3], res[4]
+        return out
+
+    def _sigma_of(self, x, y, seed_lat, seed_lon, gauss_sigma, fd_fp32_cast, tensor_layout):
         xs, ys = x, y
         # scipy's gaussian_filter returns an unsmoothed copy for sigma = 0 (LCS/LCS.py:187-190): skip the filter
         if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool) and gauss_sigma > 1e-15:
@@ -620,7 +711,18 @@ class Engine:
         dlat = float(seed_lat[1] - seed_lat[0])
         dlon = float(seed_lon[1] - seed_lon[0])
         sig = self.sigma(xs, ys, seed_lat, dlat, dlon, fd_fp32_cast=fd_fp32_cast, tensor_layout=tensor_layout)
-        out = {"sigma": sig, "x_dep": x, "y_dep": y}
+        return {"sigma": sig, "x_dep": x, "y_dep": y}
+
+    def lcs(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
+            cyclic_xboundary=True, t0=0, nsteps=None, gauss_sigma=None, fd_fp32_cast=True,
+            tensor_layout="reference", return_traj=False, noncyclic_clamp=None):
+        """advect -> (smooth) -> sigma on one GPU.  Returns dict of device tensors."""
+        dtype = field.dtype
+        seed_lat = np.asarray(seed_lat, dtype=dtype)
+        seed_lon = np.asarray(seed_lon, dtype=dtype)
+        res = self.advect(field, seed_lat, seed_lon, timestep, SETTLS_order, interp_order, cyclic_xboundary, t0,
+                          nsteps, return_traj, noncyclic_clamp=noncyclic_clamp)
+        out = self._sigma_of(res[0], res[1], seed_lat, seed_lon, gauss_sigma, fd_fp32_cast, tensor_layout)
         if return_traj:
             out["traj_x"], out["traj_y"] = res[2], res[3]
         return out

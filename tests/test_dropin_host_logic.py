@@ -52,6 +52,19 @@ class OracleEngine:
             return tuple(torch.as_tensor(a) for a in (tx[-1], ty[-1], tx, ty))
         return tuple(torch.as_tensor(a) for a in r)
 
+    # the calls dropin makes since round 4: pack + advect (+ sigma) from the raw wind in one call
+    def pack_and_advect(self, u, v, lat, lon, slat, slon, timestep, SETTLS_order=0, interp_order=1, cyclic_xboundary=True,
+                        fuse_levels=None, pipeline=None, chunk=None, return_traj=False, noncyclic_clamp=None):
+        f = self.prepare_field(u, v, lat, lon, interp_order, fuse_levels=fuse_levels)
+        return (f, *self.advect(f, slat, slon, timestep, SETTLS_order, interp_order, cyclic_xboundary, return_traj=return_traj))
+
+    def lcs_wind(self, u, v, lat, lon, slat, slon, timestep, SETTLS_order=0, interp_order=1, cyclic_xboundary=True,
+                 fuse_levels=None, gauss_sigma=None, fd_fp32_cast=True, tensor_layout="reference", return_traj=False,
+                 noncyclic_clamp=None, pipeline=None):
+        f = self.prepare_field(u, v, lat, lon, interp_order, fuse_levels=fuse_levels)
+        return self.lcs(f, slat, slon, timestep, SETTLS_order, interp_order, cyclic_xboundary, gauss_sigma=gauss_sigma,
+                        fd_fp32_cast=fd_fp32_cast, tensor_layout=tensor_layout, return_traj=return_traj)
+
     def lcs(self, f, slat, slon, timestep, SETTLS_order=0, interp_order=1, cyclic_xboundary=True, t0=0, nsteps=None,
             gauss_sigma=None, fd_fp32_cast=True, tensor_layout="reference", return_traj=False):
         res = self.advect(f, slat, slon, timestep, SETTLS_order, interp_order, cyclic_xboundary, t0, nsteps, return_traj)

@@ -195,6 +195,45 @@ def test_float64_fused_levels_without_any_packed_image_equal_the_ext_image_bit_f
     assert ka == eng.last_advect_kernel() == "outer_substep_kernel" and np.array_equal(_np(xa), _np(xb)) and np.array_equal(_np(ya), _np(yb))
 
 
+@pytest.mark.parametrize("dtype,order", [(np.float64, 3), (np.float64, 1), (np.float32, 3)])
+@pytest.mark.parametrize("chunk", [1, 3, 4, 7])
+def test_pipelined_pack_and_advect_equals_the_serial_form_bit_for_bit(eng, O, dtype, order, chunk):
+    """Engine.pack_and_advect(pipeline=True): the images of level chunk k+1 packed on a side stream while chunk k is advected,
+    each advect continuing in place (lc_advect_from) -- the images and the departure points of prepare_field + advect, bit
+    for bit, for chunk sizes that divide the series, do not, and leave a last chunk of one level; the field it returns is
+    complete (a second advect from it gives the same answer).  The default (pipeline=None) takes the pipelined form only
+    where it was measured to pay (float64, order 3, more than 2^18 seeds); what cannot be pipelined falls back."""
+    u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
+    u, v, lat, lon = (a.astype(dtype) for a in (u, v, lat, lon))
+    slat, slon = (a.astype(dtype) for a in flows.seed_grid(150, 200, lat, lon))
+    f0 = eng.prepare_field(u, v, lat, lon, order)
+    x0, y0 = eng.advect(f0, slat, slon, -1800.0, 4, order, True)
+    f1, x1, y1 = eng.pack_and_advect(u, v, lat, lon, slat, slon, -1800.0, 4, order, True, pipeline=True, chunk=chunk)
+    assert np.array_equal(_np(x0), _np(x1)) and np.array_equal(_np(y0), _np(y1)), (dtype, order, chunk)
+    assert f1.lin is None and np.array_equal(_np(f1.ext), _np(f0.ext))
+    if order == 3:
+        assert np.array_equal(_np(f1.cub), _np(f0.cub))
+    x2, y2 = eng.advect(f1, slat, slon, -1800.0, 4, order, True)
+    assert np.array_equal(_np(x2), _np(x0)) and np.array_equal(_np(y2), _np(y0))
+    if dtype == np.float64:
+        xo, yo = O.parcel_propagation(u, v, lat, lon, timestep=-1800.0, SETTLS_order=4, interp_order=order, cyclic_xboundary=True,
+                                      seed_lat=slat, seed_lon=slon)
+        d = np.abs(_np(x1) - xo)
+        assert np.minimum(d, np.abs(d - 360)).max() < POS_ATOL64 and np.abs(_np(y1) - yo).max() < POS_ATOL64
+    if chunk == 3:
+        # the default form on this small grid is the serial one; trajectories, the non-cyclic clamp and the exact order fall back
+        assert not eng.pipeline_pays(dtype, order, True, 8, 150 * 200, True) and eng.pipeline_pays(np.float64, 3, True, 200, 1 << 20, True)
+        assert not eng.pipeline_pays(np.float64, 1, True, 200, 1 << 20, True) and not eng.pipeline_pays(np.float32, 3, True, 200, 1 << 24, True)
+        r = eng.pack_and_advect(u, v, lat, lon, slat, slon, -1800.0, 4, order, True, pipeline=True, chunk=chunk, return_traj=True)
+        assert len(r) == 5 and np.array_equal(_np(r[1]), _np(x0)) and np.array_equal(_np(r[3][-1]), _np(x0))
+        r = eng.pack_and_advect(u, v, lat, lon, slat, slon, -1800.0, 4, order, False, pipeline=True, chunk=chunk, noncyclic_clamp="pointwise")
+        xa, _ = eng.advect(f0, slat, slon, -1800.0, 4, order, False, noncyclic_clamp="pointwise")
+        assert np.array_equal(_np(r[1]), _np(xa))
+        w = eng.lcs_wind(u, v, lat, lon, slat, slon, -1800.0, 4, order, True, pipeline=True)
+        l = eng.lcs(f0, slat, slon, -1800.0, 4, order, True)
+        assert np.array_equal(_np(w["sigma"]), _np(l["sigma"])) and np.array_equal(_np(w["x_dep"]), _np(x0))
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 2e-13), (np.float32, 2e-5)])
 def test_prefilter_matches_scipy(eng, O, dtype, tol):
     u, v, lat, lon = _rand_field(2, nt=2, ny=19, nx=37, dtype=dtype, scale=1.0)
