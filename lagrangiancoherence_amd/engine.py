@@ -601,7 +601,7 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ pack and advect, pipelined
-    PIPELINE_CHUNK = 16      # time levels per pack / advect stage of the pipelined form (measured: profiles/r04/pipelined_pack_ab.txt)
+    PIPELINE_CHUNK = 24      # time levels per pack / advect stage of the pipelined form (measured: profiles/r04/pipelined_pack_ab.txt)
 
     def pipeline_pays(self, dtype, interp_order, fuse_levels, nsteps, n_seeds, cyclic_xboundary, return_traj=False) -> bool:
         """Where packing chunk k+1 on a side stream while chunk k is advected is the default: float64 at order 3 in the
