@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 # environment variables that change which kernel runs or how it is launched without changing its name
 KERNEL_KNOBS = ("LCS_LIB", "LCS_LDS_TILES", "LCS_XCD_CHUNK_ROWS", "LCS_TILE_ORDER", "LCS_POLE_BLOCKS", "LCS_FIR_PREFILTER",
                 "LCS_SIGMA_MARCH", "LCS_LEVEL_CHUNK", "LCS_PATCH_MODE", "LCS_ENSEMBLE_CHUNK", "LCS_MEMBER_STREAMS", "LCS_NATIVE_HALO",
-                "LCS_EXT_IMAGE")
+                "LCS_EXT_IMAGE", "LCS_PIPELINE", "LCS_PIPELINE_CHUNK")
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_VECTOR_TFLOPS = 157.3   # same guide: peak FP32 vector
@@ -375,11 +375,15 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
     # float64 at order 3; --no-pipeline: pack, then advect
     piped = (not args.no_pipeline and ext_image is None
              and eng.pipeline_pays(np.float64, order, args.fuse_levels, nt - 1, ny * nx, True))
+    if os.environ.get("LCS_PIPELINE"):                      # A/B: force the pipelined form on (1) or off (0), LCS_PIPELINE_CHUNK levels
+        piped = os.environ["LCS_PIPELINE"] != "0" and bool(args.fuse_levels)
+    pchunk = int(os.environ["LCS_PIPELINE_CHUNK"]) if os.environ.get("LCS_PIPELINE_CHUNK") else None
     per_step, ms = timed_case(
         torch, eng, lambda: eng.prepare_field(ud, vd, lat, lon, order, fuse_levels=args.fuse_levels, ext_image=ext_image),
         lambda f: eng.advect(f, lat_d, lon_d, -900.0, K, order, True), lambda r: eng.sigma(r[0], r[1], lat_d, dlat, dlon),
         args.steps, args.warmup,
-        (lambda: eng.pack_and_advect(ud, vd, lat, lon, lat_d, lon_d, -900.0, K, order, True, fuse_levels=args.fuse_levels)[1:])
+        (lambda: eng.pack_and_advect(ud, vd, lat, lon, lat_d, lon_d, -900.0, K, order, True, fuse_levels=args.fuse_levels,
+                                     pipeline=True, chunk=pchunk)[1:])
         if piped else None)
     el = per_step * args.steps
     pts = ny * nx * (nt - 1)
