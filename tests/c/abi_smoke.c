@@ -55,6 +55,46 @@ static int continuation_check(lc_ctx *ctx, const double *u_uniform, const double
         moved += xa[k] != lon[k % NX];
     }
     printf("lc_build_id = %s; lc_advect_from continuation: %d differences, %d of %d seeds moved\n", lc_build_id(), diff, moved, NY * NX);
+    /* lc_advect_ex from C: the argument structure as this compiler lays it out, with the RAW planes as the order-1 source and
+     * NO packed_lin (float64: Euler sample and pole rows straight from u, v) -- the bits of the packed_lin call above */
+    {
+        lc_advect_args a = {0};
+        a.struct_size = sizeof a;
+        a.packed_ext = ext;
+        a.u_raw = du;
+        a.v_raw = dv;
+        a.dtype = LC_F64;
+        a.nt = NT;
+        a.ny_f = NY;
+        a.nx_f = NX;
+        a.lat_min = lat[0];
+        a.lat_max = lat[NY - 1];
+        a.lon_min = lon[0];
+        a.lon_max = lon[NX - 1];
+        a.seed_lat_dev = dlat;
+        a.ny = NY;
+        a.seed_lon_dev = dlon;
+        a.nx = NX;
+        a.row0 = 0;
+        a.ny_global = NY;
+        a.timestep = 900.0;
+        a.settls_order = 2;
+        a.interp_order = 1;
+        a.cyclic_x = LC_X_CYCLIC;
+        a.t0 = 0;
+        a.nsteps = NT - 1;
+        a.n_members = 1;
+        a.x_out = x2;
+        a.y_out = y2;
+        int s2 = lc_advect_ex(ctx, &a) | lc_sync(ctx) | lc_memcpy_d2h(ctx, xb, x2, sb) | lc_memcpy_d2h(ctx, yb, y2, sb);
+        int rawdiff = 0;
+        for (int k = 0; k < NY * NX; ++k) rawdiff += xa[k] != xb[k] || ya[k] != yb[k];
+        a.struct_size = sizeof a - 8;                      /* a client compiled against another layout is refused */
+        const int refused = lc_advect_ex(ctx, &a) == LC_EINVAL;
+        printf("lc_advect_ex with raw planes: status %d, %d differences from the packed_lin form, wrong struct_size refused: %d\n",
+               s2, rawdiff, refused);
+        diff += (s2 != LC_OK) + rawdiff + !refused;
+    }
     void *all[] = {du, dv, lin, ext, dlat, dlon, x1, y1, x2, y2};
     for (unsigned k = 0; k < sizeof all / sizeof all[0]; ++k) lc_free(ctx, all[k]);
     return diff != 0 || moved < NY * NX / 2;

@@ -34,3 +34,4 @@ def test_c_client_runs_known_answer(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mismatches" in r.stdout and "status -2" in r.stdout
     assert "continuation: 0 differences" in r.stdout and "lc_build_id = " in r.stdout
+    assert "lc_advect_ex with raw planes: status 0, 0 differences from the packed_lin form, wrong struct_size refused: 1" in r.stdout
