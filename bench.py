@@ -701,17 +701,21 @@ def main():
             ok = bool(torch.equal(xe, xr) and torch.equal(ye, yr))
             if not ok:   # what differs, for the line: rows of this rank's extended block, NaN = a row that was never filled
                 bad = ((xe != xr) | (ye != yr)).any(dim=1).nonzero().flatten().tolist()
-                if os.environ.get("LCS_HALO_DEBUG"):   # which of the two is unstable: the redundant advect once more, and the block once more
-                    xr2, yr2 = eng.advect(field, slat_d[a:b], slon_d, dt, K, order, True, 0, nsteps, row0=a, ny_global=ny_global)
-                    xm, ym = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo, ny_global=ny_global)
-                    sys.stderr.write(f"bench.py: rank {rank}: redundant twice equal {torch.equal(xr, xr2) and torch.equal(yr, yr2)}; "
-                                     f"block again == redundant {torch.equal(xm, xr[n_lo:n_lo + hi - lo])}; "
-                                     f"block again == timed block {torch.equal(xm, xe[n_lo:n_lo + hi - lo])}; max |dx| {float((xe - xr).abs().max())}\n")
+                # which of the two is unstable: the redundant advect once more, and this rank's block once more
+                xr2, yr2 = eng.advect(field, slat_d[a:b], slon_d, dt, K, order, True, 0, nsteps, row0=a, ny_global=ny_global)
+                xm, ym = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo, ny_global=ny_global)
+                mid = slice(n_lo, n_lo + hi - lo)
                 mismatch[rank] = {"rows_of_extended_block": bad[:8], "n_rows": len(bad), "nan": bool(torch.isnan(xe).any() or torch.isnan(ye).any()),
-                                  "block": [a, b], "halo": [n_lo, n_hi]}
+                                  "block": [a, b], "halo": [n_lo, n_hi],
+                                  "max_abs_dx": float(torch.nan_to_num(xe - xr).abs().max()),
+                                  "redundant_repeats": bool(torch.equal(xr, xr2) and torch.equal(yr, yr2)),
+                                  "block_again_equals_redundant": bool(torch.equal(xm, xr[mid]) and torch.equal(ym, yr[mid])),
+                                  "block_again_equals_timed": bool(torch.equal(xm, xe[mid]) and torch.equal(ym, ye[mid]))}
             t = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item())
+        if os.environ.get("LCS_BENCH_CORRUPT_HALO_CHECK") and rank == 0:   # test hook: the failure report itself is tested
+            x_ext[n_lo + 3, 5] += 1.0
         halo_check = {"rows_per_neighbour": sharded.HALO, "timed_path": "lc_halo_exchange" if native else "torch.distributed",
                       "timed_path_ok": rows_equal(x_ext, y_ext)}
         if mismatch:

@@ -85,7 +85,7 @@ def test_bench_two_ranks_rehearsal_carries_a_halo_check(wk, extra, units, scalin
         return _bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", wk, *extra,
                       launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                                 "127.0.0.1", "--master-port", str(port)),
-                      env={"LCS_BENCH_BACKEND": "gloo", "LCS_BENCH_ONE_GPU": "1", "LCS_HALO_DEBUG": "1"})
+                      env={"LCS_BENCH_BACKEND": "gloo", "LCS_BENCH_ONE_GPU": "1"})
     d = run(port)
     if wk != "c5" and d["halo_check"]["timed_path_ok"] is not True:
         # Round 4: on two of ~12 pool boxes this rehearsal (two PROCESSES time-sharing one GPU) reported a handful of INTERIOR
@@ -106,6 +106,24 @@ def test_bench_two_ranks_rehearsal_carries_a_halo_check(wk, extra, units, scalin
         hc = d["halo_check"]
         assert hc["timed_path"] == "torch.distributed" and hc["timed_path_ok"] is True
     assert abs(d["value"] - units / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+
+
+def test_bench_reports_a_failed_halo_check_with_its_diagnosis():
+    """A halo check that fails is REPORTED in the JSON line next to the number it discredits (not an assert, not a crash),
+    with what differs and which of the two calls is unstable: here one interior element of rank 0's timed result is changed
+    after the fact, so both re-runs agree with the redundant advect and not with the timed block."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LCS_BENCH_BACKEND="gloo", LCS_BENCH_ONE_GPU="1", LCS_BENCH_CORRUPT_HALO_CHECK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--seeds", "256", "--nt", "5"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    hc = d["halo_check"]
+    assert hc["timed_path_ok"] is False
+    m = hc["mismatch_rank0"]
+    assert m["rows_of_extended_block"] == [3] and m["n_rows"] == 1 and m["nan"] is False and abs(m["max_abs_dx"] - 1.0) < 1e-3
+    assert m["redundant_repeats"] is True and m["block_again_equals_redundant"] is True and m["block_again_equals_timed"] is False
+    assert "halo check failed" in r.stderr
 
 
 @pytest.mark.parametrize("wk,extra,units", [
