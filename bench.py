@@ -373,8 +373,7 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
     ext_image = None if "LCS_EXT_IMAGE" not in os.environ else os.environ["LCS_EXT_IMAGE"] != "0"
     # the pipelined form (chunk k+1 packed on a side stream while chunk k is advected) where the engine makes it the default:
     # float64 at order 3; --no-pipeline: pack, then advect
-    piped = (not args.no_pipeline and ext_image is None
-             and eng.pipeline_pays(np.float64, order, args.fuse_levels, nt - 1, ny * nx, True))
+    piped = (not args.no_pipeline and eng.pipeline_pays(np.float64, order, args.fuse_levels, nt - 1, ny * nx, True))
     if os.environ.get("LCS_PIPELINE"):                      # A/B: force the pipelined form on (1) or off (0), LCS_PIPELINE_CHUNK levels
         piped = os.environ["LCS_PIPELINE"] != "0" and bool(args.fuse_levels)
     pchunk = int(os.environ["LCS_PIPELINE_CHUNK"]) if os.environ.get("LCS_PIPELINE_CHUNK") else None
@@ -383,13 +382,14 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
         lambda f: eng.advect(f, lat_d, lon_d, -900.0, K, order, True), lambda r: eng.sigma(r[0], r[1], lat_d, dlat, dlon),
         args.steps, args.warmup,
         (lambda: eng.pack_and_advect(ud, vd, lat, lon, lat_d, lon_d, -900.0, K, order, True, fuse_levels=args.fuse_levels,
-                                     pipeline=True, chunk=pchunk)[1:])
+                                     pipeline=True, chunk=pchunk, ext_image=ext_image)[1:])
         if piped else None)
     el = per_step * args.steps
     pts = ny * nx * (nt - 1)
     wl = {"workload": "c2", "order": order, "K": K, "dtype": "f64", "fuse_levels": bool(args.fuse_levels)}
     img = 2 * (ny + 3) * (nx + 3) * 8
-    comp = img * (nt if not args.fuse_levels else 2 * nt - 1) + 4 * ny * nx * 8
+    no_ext = order == 3 and not (eng.EXT_IMAGE_F64_O3 if ext_image is None else ext_image)   # the kernels form 2 c[t] - c[t+1] themselves
+    comp = img * (nt if (not args.fuse_levels or no_ext) else 2 * nt - 1) + 4 * ny * nx * 8
     out = {
         "metric": "particle-timesteps/sec, BASELINE configs[1] (float64)", "value": pts * args.steps / el,
         "unit": "particle-timesteps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -416,6 +416,77 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
                                "sample": f"the same vortex at 256x256 nodes x 20 steps, float64, advect+sigma, "
                                          f"oracle/lcs_oracle.py, single thread, {c1 - c0:.1f} s"}
     print(json.dumps(out), flush=True)
+
+
+def mismatch_report(torch, eng, field, slat_d, slon_d, dt, K, order, nsteps, ny_global, rank, ext, own, halo, xe, ye, xr, yr):
+    """The halo check failed on this rank: the timed call's extended block (xe, ye: rows [a, b) with the neighbours' rows
+    received) differs from the same rows advected redundantly in one call (xr, yr).  Everything that can be said about it
+    from this process, once: WHICH seeds differ (row, column, the workgroup / wave / lane that computed each in either
+    call's tiling), by how much, which of the two calls is the one that is off (a third answer from the direct-gather
+    kernel, which stages nothing in LDS, is the arbiter), whether either call repeats, and -- if the repeats still differ
+    -- the first time level at which they part (return_traj on up to 8 of the seeds).  Returned for the JSON line and
+    written to $LCS_BENCH_DIAG_DIR (default gpurun_out/) as halo_mismatch_rank<r>.json."""
+    (a, b), (lo, hi), (n_lo, n_hi) = ext, own, halo
+    kernel = eng.last_advect_kernel()          # of the redundant call (the timed one ran the same: same size class)
+    kw = dict(row0=a, ny_global=ny_global)
+    diff = (xe != xr) | (ye != yr)
+    idx = diff.nonzero()
+    rows = sorted(set(idx[:, 0].tolist()))
+    received = [r for r in rows if r < n_lo or r >= n_lo + hi - lo]
+    nan = bool(torch.isnan(xe).any() or torch.isnan(ye).any())
+    # the arbiter: direct gathers, no LDS tiles (bit-identical to the tile kernels by construction and by test)
+    prev = eng.lds_tiles_mode
+    eng.set_lds_tiles(0)
+    try:
+        xt, yt = eng.advect(field, slat_d[a:b], slon_d, dt, K, order, True, 0, nsteps, **kw)
+        direct_kernel = eng.last_advect_kernel()
+    finally:
+        eng.set_lds_tiles(prev)
+    timed_off = int(((xe != xt) | (ye != yt))[n_lo:n_lo + hi - lo].sum())
+    redundant_off = int(((xr != xt) | (yr != yt)).sum())
+    # do the two calls repeat?  (with trajectories, so that repeats that still differ show the level at which they part)
+    x2, y2, tx2, ty2 = eng.advect(field, slat_d[a:b], slon_d, dt, K, order, True, 0, nsteps, return_traj=True, **kw)
+    xm, ym, txm, tym = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo, ny_global=ny_global,
+                                  return_traj=True)
+    mid = slice(n_lo, n_lo + hi - lo)
+    part = None
+    again = ((tx2[:, mid] != txm) | (ty2[:, mid] != tym))
+    if bool(again.any()):
+        lv = again.flatten(1).any(dim=1).nonzero().flatten()
+        part = {"first_level": int(lv[0]), "seeds_at_that_level": again[int(lv[0])].nonzero()[:8].tolist()}
+
+    def where(r_ext, c, row_origin):       # the one-seed kernel's 8 x 32-seed workgroups of four stacked 8 x 8 waves
+        r = r_ext - row_origin
+        return {"tile_row": r // 32, "tile_col": c // 8, "wave": (r % 32) // 8, "lane_row": r % 8, "lane_col": c % 8}
+    seeds = []
+    for r, c in idx[:64].tolist():
+        seeds.append({"row_ext": r, "col": c, "global_row": a + r,
+                      "timed": [float(xe[r, c]), float(ye[r, c])], "redundant": [float(xr[r, c]), float(yr[r, c])],
+                      "direct": [float(xt[r, c]), float(yt[r, c])],
+                      "timed_equals_direct": bool(xe[r, c] == xt[r, c] and ye[r, c] == yt[r, c]),
+                      "redundant_equals_direct": bool(xr[r, c] == xt[r, c] and yr[r, c] == yt[r, c]),
+                      "in_timed_call": None if (r < n_lo or r >= n_lo + hi - lo) else where(r, c, n_lo),
+                      "in_redundant_call": where(r, c, 0)})
+    rep = {"rank": rank, "block": [a, b], "own_rows": [lo, hi], "halo": [n_lo, n_hi], "n_seeds": int(diff.sum()), "n_rows": len(rows),
+           "rows_of_extended_block": rows[:32], "received_rows_among_them": received, "nan": nan,
+           "max_abs_dx": float(torch.nan_to_num(xe - xr).abs().max()), "max_abs_dy": float(torch.nan_to_num(ye - yr).abs().max()),
+           "arbiter": direct_kernel, "timed_seeds_off_the_arbiter": timed_off, "redundant_seeds_off_the_arbiter": redundant_off,
+           "redundant_repeats": bool(torch.equal(xr, x2) and torch.equal(yr, y2)),
+           "block_again_equals_redundant": bool(torch.equal(xm, xr[mid]) and torch.equal(ym, yr[mid])),
+           "block_again_equals_timed": bool(torch.equal(xm, xe[mid]) and torch.equal(ym, ye[mid])),
+           "repeats_part_at": part, "kernel": kernel,
+           "wave_state_audit": eng.read_verify(reset=False) if eng.verify_mode else None, "seeds": seeds}
+    out_dir = os.environ.get("LCS_BENCH_DIAG_DIR", os.path.join(ROOT, "gpurun_out"))
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, f"halo_mismatch_rank{rank}.json")
+        json.dump(rep, open(path, "w"), indent=1)
+        rep["file"] = os.path.relpath(path, ROOT)
+    except OSError as exc:
+        rep["file"] = f"not written: {exc}"
+    brief = {k: v for k, v in rep.items() if k != "seeds"}
+    brief["seeds"] = seeds[:8]
+    return brief
 
 
 def main():
@@ -551,6 +622,12 @@ def main():
         u, v = (u * np.float32(args.wind_scale)), (v * np.float32(args.wind_scale))
     slat, slon = flows.seed_grid(ny_global, nx, lat, lon)
     eng = Engine(local_rank)
+    # Ranks time-sharing ONE GPU (the rehearsal layout, not a measurement) or LCS_VERIFY=1: the one-seed LDS kernel's verify
+    # instances audit every wave's LDS tile and hardware slot level by level (lc_ctx_set_verify) --
+    # that layout is where two lc_advect calls on identical inputs once differed, and the counters say whether a
+    # wave's state was changed under it.  Results are bit-identical to the plain instances.
+    if (world > 1 and os.environ.get("LCS_BENCH_ONE_GPU")) or os.environ.get("LCS_VERIFY"):
+        eng.set_verify(1)
     ud = eng.to_device(u, np.float32)
     vd = eng.to_device(v, np.float32)
     if wk == "c5":
@@ -699,18 +776,9 @@ def main():
 
         def rows_equal(xe, ye):
             ok = bool(torch.equal(xe, xr) and torch.equal(ye, yr))
-            if not ok:   # what differs, for the line: rows of this rank's extended block, NaN = a row that was never filled
-                bad = ((xe != xr) | (ye != yr)).any(dim=1).nonzero().flatten().tolist()
-                # which of the two is unstable: the redundant advect once more, and this rank's block once more
-                xr2, yr2 = eng.advect(field, slat_d[a:b], slon_d, dt, K, order, True, 0, nsteps, row0=a, ny_global=ny_global)
-                xm, ym = eng.advect(field, slat_d[lo:hi], slon_d, dt, K, order, True, 0, nsteps, row0=lo, ny_global=ny_global)
-                mid = slice(n_lo, n_lo + hi - lo)
-                mismatch[rank] = {"rows_of_extended_block": bad[:8], "n_rows": len(bad), "nan": bool(torch.isnan(xe).any() or torch.isnan(ye).any()),
-                                  "block": [a, b], "halo": [n_lo, n_hi],
-                                  "max_abs_dx": float(torch.nan_to_num(xe - xr).abs().max()),
-                                  "redundant_repeats": bool(torch.equal(xr, xr2) and torch.equal(yr, yr2)),
-                                  "block_again_equals_redundant": bool(torch.equal(xm, xr[mid]) and torch.equal(ym, yr[mid])),
-                                  "block_again_equals_timed": bool(torch.equal(xm, xe[mid]) and torch.equal(ym, ye[mid]))}
+            if not ok:   # what differs, seed by seed, and which of the two calls is off: into the line and into a file
+                mismatch[rank] = mismatch_report(torch, eng, field, slat_d, slon_d, dt, K, order, nsteps, ny_global, rank,
+                                                 (a, b), (lo, hi), (n_lo, n_hi), xe, ye, xr, yr)
             t = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item())
@@ -748,8 +816,18 @@ def main():
                 "kernel_ms": {k: round(v, 4) for k, v in ms.items()}, "kernel": advect_kernel,
                 "roofline_frac": (pts_launch * flops_pts(K, order, True) / (adv_ms / 1e3) / 1e12 / FP32_VECTOR_TFLOPS)
                 if adv_ms > 0 else None}
+        if eng.verify_mode:          # lc_ctx_set_verify was on for every call of this rank (see above)
+            mine["wave_state_audit"] = eng.read_verify(reset=False)
+        if halo_check is not None and mismatch:
+            mine["halo_mismatch"] = mismatch[rank]
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
+        if halo_check is not None:   # every rank's report, not only rank 0's own
+            for pr in per_rank:
+                if pr.get("halo_mismatch"):
+                    halo_check["mismatch_rank%d" % pr["rank"]] = pr.pop("halo_mismatch")
+            if any("wave_state_audit" in pr for pr in per_rank):
+                halo_check["wave_state_audit"] = {"rank%d" % pr["rank"]: pr.get("wave_state_audit") for pr in per_rank}
     if rank != 0:                                   # only rank 0 reports
         if world > 1:
             dist.destroy_process_group()

@@ -38,7 +38,7 @@ extern "C" {
  * client built against 100 must be rebuilt), lc_ctx_get_level_chunk, lc_ctx_set/get_f64_fidelity, lc_advect_ex and
  * lc_sample_raw added, lc_field_pack accepts packed_dev == NULL at order 1 (fused-level image only).  lc_version() returns the value the LIBRARY
  * was built with: compare it with this macro before any other call (tests/c/abi_smoke.c, _capi.load do). */
-#define LC_VERSION 101 /* 0.1.1 */
+#define LC_VERSION 102 /* 0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify */
 
 typedef struct lc_ctx lc_ctx;
 
@@ -163,6 +163,23 @@ const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx);
 int lc_ctx_last_advect_launches(const lc_ctx *ctx);
 /* The same for the context's last lc_sigma / lc_flowmap_gradient call. */
 const char *lc_ctx_last_sigma_kernel(const lc_ctx *ctx);
+/* Wave-state audit (diagnostic; no reference counterpart).  mode 1: float32 lc_advect calls that dispatch to the one-seed
+ * LDS-tile kernels (orders 1 and 3 below 2^23 seeds per call, SETTLS_order > 0, no whole-line trajectory stores) run their "verify" instances:
+ * after the iterations of every time level each wave reads back the tile of the wind image it staged in LDS for that
+ * level and compares it, 16 bytes per lane, with the registers it staged it from, and compares HW_REG_HW_ID /
+ * HW_REG_XCC_ID with the values it read when it started.  A wave's tile and registers are written by that wave only,
+ * so a non-zero count means the wave's state was changed from OUTSIDE the kernel: its context saved and restored by
+ * the driver (several processes time-sharing one GPU) with something lost on the way, or a hardware fault.  Results
+ * are bit-identical to the plain instances (a few percent slower).  mode 2 additionally overwrites one tile entry once
+ * (tile 5, wave 1, second level) so that a test can see the audit fire; mode 0 frees the counters.
+ * lc_ctx_read_verify synchronises the context's stream and copies the LC_VERIFY_WORDS counters:
+ *   [0] wave-levels whose tile differed, [1] 16-byte entries that differed, [2] wave-levels at which the wave sat in
+ *   another hardware slot than one level earlier (a context switch; harmless by itself), [3] wave-levels audited,
+ *   [4..11] the first event: workgroup, tile, wave, time level, HW_ID before / after, lane mask low / high word.
+ * `reset` != 0 zeroes them afterwards. */
+#define LC_VERIFY_WORDS 16
+int lc_ctx_set_verify(lc_ctx *ctx, int mode);
+int lc_ctx_read_verify(lc_ctx *ctx, unsigned *out16, int reset);
 
 /* ---- device memory (so a ctypes-only host needs nothing else) ---------- */
 int lc_malloc(lc_ctx *ctx, size_t bytes, void **dev_out);
@@ -343,8 +360,13 @@ typedef struct lc_advect_args {
     /* LC_F64 at interp_order 1 with u_raw / v_raw and packed_ext == NULL: 1 = take the fused-level form all the same -- the
      * value packed_ext would hold, 2 F[t] - F[t+1], is formed from the raw planes node by node inside the kernels (the
      * same expression, one rounding: results equal those with packed_ext bit for bit).  No packed image exists then:
-     * lc_field_pack is not called at all for such a field.  0 (and every other dtype / order): packed_ext == NULL means
-     * the reference's two-sample operation order, as in lc_advect. */
+     * lc_field_pack is not called at all for such a field.
+     * LC_F64 at interp_order 3 with packed_cub and packed_ext == NULL: 1 = the same for the spline coefficients -- the
+     * kernels form 2 c[t] - c[t+1] from packed_cub node by node (lc_field_pack's own expression: bit-identical to a call
+     * with packed_ext), so lc_field_pack(order 3, ext_dev = NULL) is the whole pack: it neither reads the coefficients back
+     * nor writes a second image, and the advect kernel streams one image series from memory instead of two.
+     * 0 (and every other dtype / order): packed_ext == NULL means the reference's two-sample operation order, as in
+     * lc_advect. */
     int fuse_levels_raw;
 } lc_advect_args;
 int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args);

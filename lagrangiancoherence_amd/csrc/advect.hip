@@ -48,6 +48,8 @@ struct AdvectArgs {
     size_t raw_plane;  // ny_f * nx_f
     int ext_raw;       // float64, order 1, raw planes: the fused-level value 2 F[t] - F[t+1] is formed from the planes node by node
                        // (lc_advect_args.fuse_levels_raw): no packed image at all, ext == NULL
+    int ext_cub;       // float64, order 3: the fused-level COEFFICIENTS 2 img[t] - img[t+1] are formed from the coefficient image
+                       // node by node (lc_advect_args.fuse_levels_raw at order 3): no ext image, ext == NULL
     size_t level_elems;
     int pitch;  // nodes per padded row
     int ny_f, nx_f;
@@ -81,6 +83,7 @@ struct AdvectArgs {
     int tile_order_two_seed;  // host side only: what the two-seed kernel's launch puts into tile_order
     int pole_blocks, pole_lo, pole_hi;  // leading workgroups that take the pole rows (first pole_lo / last pole_hi local rows); 0: the tiles do
     unsigned *clamp_flag;  // NULL, or set to 1 when the non-cyclic longitude clamp moves any parcel (Q9)
+    unsigned *verify;      // NULL, or the context's 16 wave-state counters (lc_ctx_set_verify: the one-seed order-1 LDS kernel's VERIFY instances)
 };
 
 // Tile of a workgroup.  Hardware deals workgroups to the 8 XCDs round-robin (blockIdx % 8), each with its own L2.
@@ -1018,7 +1021,15 @@ __device__ __forceinline__ void traj_store_line(float *dst, f4 v) {
 // longitude (32 x 8 seeds) instead of stacked (8 x 32), put their positions into an LDS slab after each time level, meet at
 // one workgroup barrier, and waves 0 and 1 write the longitudes' and the latitudes' 8 rows x 32 columns as whole 128-byte
 // lines, non-temporal -- the two-seed kernels' PATCH_LINES (see there for the counters) for launches below their size.
-template <int ORDER, int KFIX, bool CYCLIC, bool LINES>
+// VERIFY (lc_ctx_set_verify; without LINES only): the same kernel with a wave-state audit after each level's iterations
+// -- does the tile in LDS still hold what this wave staged, is the wave still in the hardware slot it started in -- counted
+// into A.verify.  A wave's tile and registers are its own for the whole launch (no other wave writes them), so a count can only
+// come from outside the kernel: the wave's context having been saved and restored by the driver (two processes time-sharing
+// a GPU), or hardware.  Results are bit-identical to the plain instance; DESIGN.md section 8 says what it is for.
+// A.verify[LC_VERIFY_WORDS]: [0] wave-levels whose tile changed, [1] 16-byte entries changed, [2] wave slot changes, [3] wave-levels audited,
+// [4..11] first event: block, tile, wave, level, HW_ID before / after, lane mask lo / hi, [12] first-event latch, [15] 0xBAD: inject one (test hook)
+static_assert(LC_VERIFY_WORDS >= 16, "lc_ctx_read_verify's counter block");
+template <int ORDER, int KFIX, bool CYCLIC, bool LINES, bool VERIFY = false>
 __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
 #if LCS_LDS_NUM_SGPR > 0
     __attribute__((amdgpu_num_sgpr(LCS_LDS_NUM_SGPR)))
@@ -1115,6 +1126,12 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     constexpr bool PREFETCH = ORDER == 1;
 #endif
     constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
+    // VERIFY: where this wave runs -- HW_REG_HW_ID (wave slot, SIMD, CU, SE, queue, VMID) and HW_REG_XCC_ID
+    unsigned hw_id = 0, xcc_id = 0;
+    if constexpr (VERIFY) {
+        hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
     for (int s = 0; s < A.nsteps; ++s) {
         f2 c0 = to_index(p);
         // ---- 1. anchor the tile and issue its loads ------------------------------------------------
@@ -1192,6 +1209,11 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
 #pragma unroll
             for (int r = 0; r < NPASS; ++r) *(f4 *)(tile + (r * G::ROWS_PER_PASS + st_row) * LT_PITCH + st_col) = stage[r];
             __builtin_amdgcn_wave_barrier();
+            if constexpr (VERIFY) {  // test hook: one entry of one tile overwritten behind the wave's back
+                if (A.verify && A.verify[15] == 0xBADu && tile_id == 5 && wave == 1 && s == 1 && lane == 5)
+                    *(volatile f2 *)(tile + ((LT_ROWS - WIN) / 2) * LT_PITCH + (LT_COLS - WIN) / 2) = (f2){1.0e3f, -1.0e3f};  // the centre lane's window origin
+                __builtin_amdgcn_wave_barrier();
+            }
             // window origins floor(c) the common case accepts: inside the tile AND in [0, n-2] (no wrap)
             const int sox = ox - WOFF, soy = oy - WOFF;
             const int hx = min(sox + LT_COLS - WIN, A.nx_f - 2), hy = min(soy + LT_ROWS - WIN, A.ny_f - 2);
@@ -1245,6 +1267,43 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
             p = pn;
         }
         p.y = __builtin_amdgcn_fmed3f(p.y, A.y_min, ymax_v);  // the level's one latitude clamp (stores, next Euler sample)
+        if constexpr (VERIFY) {
+            if (A.verify && K > 0) {
+                // the audit: every lane reads back the 16 bytes it staged for this level, after the last window read
+                bool changed = false;
+#pragma unroll
+                for (int r = 0; r < NPASS; ++r) {
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    const u4 back = *(volatile u4 *)(tile + (r * G::ROWS_PER_PASS + st_row) * LT_PITCH + st_col);
+                    u4 was;
+                    __builtin_memcpy(&was, &stage[r], 16);
+                    changed |= (back.x != was.x) | (back.y != was.y) | (back.z != was.z) | (back.w != was.w);
+                }
+                const unsigned long long m = __ballot(changed);
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                const bool moved = hw != hw_id || xc != xcc_id;
+                if (lane == 0) {
+                    atomicAdd(&A.verify[3], 1u);
+                    if (moved) atomicAdd(&A.verify[2], 1u);
+                    if (m) {
+                        atomicAdd(&A.verify[0], 1u);
+                        atomicAdd(&A.verify[1], (unsigned)__popcll(m));
+                    }
+                    if ((m || moved) && atomicCAS(&A.verify[12], 0u, 1u) == 0u) {
+                        A.verify[4] = blockIdx.x;
+                        A.verify[5] = (unsigned)tile_id;
+                        A.verify[6] = (unsigned)wave;
+                        A.verify[7] = (unsigned)(A.t0 + s);
+                        A.verify[8] = hw_id;
+                        A.verify[9] = hw;
+                        A.verify[10] = (unsigned)m;
+                        A.verify[11] = (unsigned)(m >> 32);
+                    }
+                }
+                hw_id = hw;
+                xcc_id = xc;
+            }
+        }
         if (LINES && lines) {
             float *sx = s_slab1[s & 1][0], *sy = s_slab1[s & 1][1];
             const int o = (lane / TILE_W) * SLAB1_PITCH + wave * TILE_W + (lane % TILE_W);
@@ -2154,6 +2213,18 @@ struct LdsLaunch<float, ORDER> {
             if (A.cyclic) LC_LDS1(-1, true, true, ORDER == 3 ? "advect_lds_kernel<3, -1, true, lines>" : "advect_lds_kernel<1, -1, true, lines>")
             LC_LDS1(-1, false, true, ORDER == 3 ? "advect_lds_kernel<3, -1, false, lines>" : "advect_lds_kernel<1, -1, false, lines>")
         }
+        if (A.verify) {  // lc_ctx_set_verify: the instances that audit each wave's tile and slot level by level
+#define LC_LDS1V(KF, CY, NAME)                                                                                           \
+    {                                                                                                                    \
+        hipLaunchKernelGGL((advect_lds_kernel<ORDER, KF, CY, false, true>), dim3(g1, nmem(A)), dim3(BLOCK), 0, st, A);   \
+        return NAME;                                                                                                     \
+    }
+            if (A.K == 4 && A.cyclic) LC_LDS1V(4, true, ORDER == 3 ? "advect_lds_kernel<3, 4, true, verify>" : "advect_lds_kernel<1, 4, true, verify>")
+            if (A.K == 4) LC_LDS1V(4, false, ORDER == 3 ? "advect_lds_kernel<3, 4, false, verify>" : "advect_lds_kernel<1, 4, false, verify>")
+            if (A.cyclic) LC_LDS1V(-1, true, ORDER == 3 ? "advect_lds_kernel<3, -1, true, verify>" : "advect_lds_kernel<1, -1, true, verify>")
+            LC_LDS1V(-1, false, ORDER == 3 ? "advect_lds_kernel<3, -1, false, verify>" : "advect_lds_kernel<1, -1, false, verify>")
+#undef LC_LDS1V
+        }
         if (A.K == 4 && A.cyclic) LC_LDS1(4, true, false, ORDER == 3 ? "advect_lds_kernel<3, 4, true>" : "advect_lds_kernel<1, 4, true>")
         if (A.K == 4) LC_LDS1(4, false, false, ORDER == 3 ? "advect_lds_kernel<3, 4, false>" : "advect_lds_kernel<1, 4, false>")
         if (A.cyclic) LC_LDS1(-1, true, false, ORDER == 3 ? "advect_lds_kernel<3, -1, true>" : "advect_lds_kernel<1, -1, true>")
@@ -2310,6 +2381,28 @@ __device__ __forceinline__ d2 cubic_taps_fast64(const d2 *w, size_t rs, const do
         for (int b = 0; b < 4; ++b) q[a][b] = w[(size_t)a * rs + b];
     return cubic_apply_fast64(q, wx, wy, start);
 }
+// ... the same window of the fused-level coefficients 2 c[t] - c[t+1] formed node by node from the coefficient images of
+// levels t (w) and t + 1 (wn): the numbers the ext image holds (lc_field_pack: T(2) * a - b, one rounding since 2 a is
+// exact), so the sum is the ext-image sample bit for bit -- without the image (AdvectArgs::ext_cub).  Row by row, in
+// cubic_apply_fast64's operation order (32 loads: eight in flight at a time keep the registers of the kernel's cap).
+__device__ __forceinline__ d2 cubic_taps_fast64_fused(const d2 *w, const d2 *wn, size_t rs, const double (&wx)[4], const double (&wy)[4], d2 start) {
+#pragma clang fp contract(off)
+    d2 acc = start;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        d2 q[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const d2 c0 = w[(size_t)a * rs + b], c1 = wn[(size_t)a * rs + b];
+            q[b] = (d2){2.0 * c0.x - c1.x, 2.0 * c0.y - c1.y};
+        }
+        const double rx = fma(wx[3], q[3].x, fma(wx[2], q[2].x, fma(wx[1], q[1].x, wx[0] * q[0].x)));
+        const double ry = fma(wx[3], q[3].y, fma(wx[2], q[2].y, fma(wx[1], q[1].y, wx[0] * q[0].y)));
+        acc.x = fma(wy[a], rx, acc.x);
+        acc.y = fma(wy[a], ry, acc.y);
+    }
+    return acc;
+}
 // ... and from an LDS tile (byte address of the window origin; PITCH nodes per row): ds_read_b128 with immediate
 // offsets.  (Through one generic pointer for both, hipcc 7.2 merged the tails of the two branches and read the
 // window's last row with flat_load_dwordx4 -- LDS through the flat path.)
@@ -2333,6 +2426,16 @@ __device__ __forceinline__ d2 sample_fast64_o3(const double *__restrict__ lvl, c
     return cubic_taps_fast64((const d2 *)lvl + ((size_t)t.y0 * A.pitch + t.x0), (size_t)A.pitch, wx, wy, start);
 }
 
+// one sample of the fused-level coefficients formed from img[t], img[t+1] (lvl = img[t]; AdvectArgs::ext_cub)
+__device__ __forceinline__ d2 sample_fast64_o3_fused(const double *__restrict__ lvl, const AdvectArgs<double> &A, double x, double y, d2 start) {
+    const Loc64 t = locate_fast64(A, x, y);
+    double wx[4], wy[4];
+    cubic_weights_fast64(t.tx, wx);
+    cubic_weights_fast64(t.ty, wy);
+    const d2 *w = (const d2 *)lvl + ((size_t)t.y0 * A.pitch + t.x0);
+    return cubic_taps_fast64_fused(w, w + A.level_elems / 2, (size_t)A.pitch, wx, wy, start);
+}
+
 __device__ void advect_seed_fast64_o3(const AdvectArgs<double> &A, int iy, int ix) {
 #pragma clang fp contract(off)
     double x = start_x<double>(A, iy, ix), y = start_y<double>(A, iy, ix);
@@ -2345,7 +2448,7 @@ __device__ void advect_seed_fast64_o3(const AdvectArgs<double> &A, int iy, int i
         A.traj_y[idx] = y;
     }
     const double *lvl = A.img + (size_t)A.t0 * A.level_elems;
-    const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const double *elv = A.ext_cub ? nullptr : A.ext + (size_t)A.t0 * A.level_elems;
     const d2 zero = {0.0, 0.0};
     for (int s = 0; s < A.nsteps; ++s) {
         const d2 e = sample_fast64_o3(lvl, A, x, y, zero);   // trajectory.py:82-84
@@ -2353,7 +2456,7 @@ __device__ void advect_seed_fast64_o3(const AdvectArgs<double> &A, int iy, int i
         x = fma(dtcx, e.x, x);                               // :87
         clamp_position<double>(A, x, y);                     // :89-97
         for (int k = 0; k < A.K; ++k) {                      // :100
-            const d2 d = sample_fast64_o3(elv, A, x, y, e);  // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
+            const d2 d = A.ext_cub ? sample_fast64_o3_fused(lvl, A, x, y, e) : sample_fast64_o3(elv, A, x, y, e);  // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
             y = fma(A.hdtcy, d.y, y);
             x = fma(hdtcx, d.x, x);
             clamp_position<double>(A, x, y);
@@ -2363,7 +2466,7 @@ __device__ void advect_seed_fast64_o3(const AdvectArgs<double> &A, int iy, int i
             A.traj_y[(size_t)(s + 1) * plane + idx] = y;
         }
         lvl += A.level_elems;
-        elv += A.level_elems;
+        if (elv) elv += A.level_elems;
     }
     A.x_out[idx] = x;
     A.y_out[idx] = y;
@@ -2623,7 +2726,11 @@ static_assert(T64O3_EROWS % 4 == 0 && T64O3_EROWS >= 12 && T64O3_EROWS <= T64O3,
 #ifndef LCS_LDS64_O3_MINWAVES
 #define LCS_LDS64_O3_MINWAVES 4   // 128 vector registers: the kernel compiles to 126-129 depending on the tile shapes, and 129 is a wave per SIMD less
 #endif
-template <int KFIX, bool CYCLIC>
+// EXTCUB: no ext image -- the iteration tile is staged from the coefficient images of levels t and t + 1 as
+// 2 img[t] - img[t+1] node by node (the pack's own expression: bit-identical), and a window that left the tile takes its
+// taps from both levels.  The pack then neither reads the coefficients back nor writes a second image (float64 config 2:
+// 8.5 GB of 22 per step), and the advect kernel streams ONE image series from HBM instead of two.
+template <int KFIX, bool CYCLIC, bool EXTCUB = false>
 __global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_kernel(const AdvectArgs<double> A0) {
 #pragma clang fp contract(off)
     const AdvectArgs<double> A = for_member(A0);
@@ -2657,7 +2764,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_
         A.traj_y[idx] = y;
     }
     const double *lvl = A.img + (size_t)A.t0 * A.level_elems;
-    const double *elv = A.ext + (size_t)A.t0 * A.level_elems;
+    const double *elv = EXTCUB ? lvl : A.ext + (size_t)A.t0 * A.level_elems;  // EXTCUB: "ext[t]" is formed from lvl and lvl + level_elems
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
     constexpr int CENTRE = TILE_W / 2 + TILE_W * 4;  // middle seed of the wave's 8 x 8 patch
     const int st_row = lane >> 4, st_col = lane & 15;  // staging: one node per lane, 16 lanes per tile row, 4 rows per pass
@@ -2666,19 +2773,29 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_
     const d2 zero = {0.0, 0.0};
     // window origins (padded (y0, x0)) a tile with padded origin (oy, ox) serves: [ox, ox + 16 - 4] x [oy, oy + 16 - 4]
     // (ROWS, PITCH: the tile's shape -- the Euler tile may be lower than the iteration tile: it serves the patch where it is)
-    auto stage_tile = [&](const double *level, int ox, int oy, d2 *tile, auto rows_c, auto pitch_c) {
+    auto stage_tile = [&](const double *level, int ox, int oy, d2 *tile, auto rows_c, auto pitch_c, auto fused_c) {
         constexpr int ROWS = decltype(rows_c)::value, PITCH = decltype(pitch_c)::value;
+        constexpr bool FUSED2 = decltype(fused_c)::value;  // 2 level[t] - level[t+1] while staging (EXTCUB's iteration tile)
         d2 st[ROWS / 4];
         const char *src = (const char *)level + ((size_t)oy * pad_cols + ox) * 16;
 #pragma unroll
         for (int r = 0; r < ROWS / 4; ++r) __builtin_memcpy(&st[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+        if constexpr (FUSED2) {
+            d2 nx[ROWS / 4];
+            const char *srcn = src + A.level_elems * sizeof(double);
+#pragma unroll
+            for (int r = 0; r < ROWS / 4; ++r) __builtin_memcpy(&nx[r], srcn + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+#pragma unroll
+            for (int r = 0; r < ROWS / 4; ++r) st[r] = (d2){2.0 * st[r].x - nx[r].x, 2.0 * st[r].y - nx[r].y};
+        }
         __builtin_amdgcn_wave_barrier();  // the previous level's reads of this tile are done (LDS ops of a wave are in order)
 #pragma unroll
         for (int r = 0; r < ROWS / 4; ++r) tile[(r * 4 + st_row) * PITCH + st_col] = st[r];
         __builtin_amdgcn_wave_barrier();
     };
-    auto sample = [&](const double *level, const d2 *tile, int ox, int oy, bool have, double px, double py, d2 start, auto rows_c, auto pitch_c) {
+    auto sample = [&](const double *level, const d2 *tile, int ox, int oy, bool have, double px, double py, d2 start, auto rows_c, auto pitch_c, auto fused_c) {
         constexpr int ROWS = decltype(rows_c)::value, PITCH = decltype(pitch_c)::value;
+        constexpr bool FUSED2 = decltype(fused_c)::value;
         const Loc64 t = locate_fast64(A, px, py);
         double wx[4], wy[4];
         cubic_weights_fast64(t.tx, wx);
@@ -2686,37 +2803,76 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_
         const int rx = t.x0 - ox, ry = t.y0 - oy;
         if (have && (unsigned)rx <= (unsigned)(T64O3 - 4) && (unsigned)ry <= (unsigned)(ROWS - 4))
             return cubic_taps_lds64<PITCH>(lds_address(tile) + (unsigned)(ry * PITCH + rx) * 16u, wx, wy, start);
-        return cubic_taps_fast64((const d2 *)level + ((size_t)t.y0 * A.pitch + t.x0), (size_t)A.pitch, wx, wy, start);
+        const d2 *w = (const d2 *)level + ((size_t)t.y0 * A.pitch + t.x0);
+        if constexpr (FUSED2) return cubic_taps_fast64_fused(w, w + A.level_elems / 2, (size_t)A.pitch, wx, wy, start);
+        return cubic_taps_fast64(w, (size_t)A.pitch, wx, wy, start);
     };
+    typedef std::integral_constant<bool, false> OneLevel;
+    typedef std::integral_constant<bool, EXTCUB> IterLevels;
     typedef std::integral_constant<int, T64O3_EROWS> ERows;
     typedef std::integral_constant<int, T64O3_EPITCH> EPitch;
     typedef std::integral_constant<int, T64O3> GRows;
     typedef std::integral_constant<int, T64O3_PITCH> GPitch;
+#ifdef LCS_O3CUB_PREFETCH
+    double dprev_x = 0.0, dprev_y = 0.0;  // previous level's Euler displacement in index space
+#endif
     for (int s = 0; s < A.nsteps; ++s) {
         // ---- 1. Euler sample out of a tile of img[t] centred on the patch's current position -------------------------
         const double c0x = (x - A.lon_min) * A.sx, c0y = (y - A.lat_min) * A.sy;
+#ifdef LCS_O3CUB_PREFETCH
+        // EXPERIMENT (EXTCUB): the iteration tile's loads of both levels issued HERE, anchored on the travel the PREVIOUS
+        // level's displacement predicts, so that they fly together with the Euler tile's (one exposed round trip per level)
+        int pox = 0, poy = 0;
+        d2 pst[T64O3 / 4], pnx[T64O3 / 4];
+        if (EXTCUB && K > 0) {
+            const double cax = c0x + dprev_x * (1.0 + kpred), cay = c0y + dprev_y * (1.0 + kpred);
+            const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);
+            const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
+            pox = min(max(rxm - (T64O3 - 4) / 2, 0), pad_cols - T64O3);
+            poy = min(max(rym - (T64O3 - 4) / 2, 0), pad_rows - T64O3);
+            const char *src = (const char *)lvl + ((size_t)poy * pad_cols + pox) * 16, *srcn = src + A.level_elems * sizeof(double);
+#pragma unroll
+            for (int r = 0; r < T64O3 / 4; ++r) {
+                __builtin_memcpy(&pst[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+                __builtin_memcpy(&pnx[r], srcn + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+            }
+        }
+#endif
         const int exm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(c0x, -4.0), 1.0e9)), CENTRE);
         const int eym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(c0y, -4.0), 1.0e9)), CENTRE);
         const int eox = min(max(exm - (T64O3 - 4) / 2, 0), pad_cols - T64O3), eoy = min(max(eym - (T64O3_EROWS - 4) / 2, 0), pad_rows - T64O3_EROWS);
-        stage_tile(lvl, eox, eoy, etile, ERows(), EPitch());
+        stage_tile(lvl, eox, eoy, etile, ERows(), EPitch(), OneLevel());
         const double x0p = x, y0p = y;
-        const d2 e = sample(lvl, etile, eox, eoy, true, x, y, zero, ERows(), EPitch());   // trajectory.py:82-84
+        const d2 e = sample(lvl, etile, eox, eoy, true, x, y, zero, ERows(), EPitch(), OneLevel());   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                                        // :86
         x = fma(dtcx, e.x, x);                                          // :87
         clamp_position<double>(A, x, y);                                // :89-97
         // ---- 2. tile of ext[t] anchored on the travel this level's Euler displacement predicts -----------------------
         int ox = 0, oy = 0;
+#ifdef LCS_O3CUB_PREFETCH
+        dprev_x = (x - x0p) * A.sx;
+        dprev_y = (y - y0p) * A.sy;
+        if (EXTCUB && K > 0) {
+            ox = pox;
+            oy = poy;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < T64O3 / 4; ++r)
+                gtile[(r * 4 + st_row) * T64O3_PITCH + st_col] = (d2){2.0 * pst[r].x - pnx[r].x, 2.0 * pst[r].y - pnx[r].y};
+            __builtin_amdgcn_wave_barrier();
+        } else
+#endif
         if (K > 0) {
             const double cax = c0x + (x - x0p) * A.sx * (1.0 + kpred), cay = c0y + (y - y0p) * A.sy * (1.0 + kpred);
             const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);
             const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
             ox = min(max(rxm - (T64O3 - 4) / 2, 0), pad_cols - T64O3);
             oy = min(max(rym - (T64O3 - 4) / 2, 0), pad_rows - T64O3);
-            stage_tile(elv, ox, oy, gtile, GRows(), GPitch());
+            stage_tile(elv, ox, oy, gtile, GRows(), GPitch(), IterLevels());
         }
         // ---- 3. K iterations out of LDS ---------------------------------------------------------------------------------
         for (int k = 0; k < K; ++k) {
-            const d2 d = sample(elv, gtile, ox, oy, true, x, y, e, GRows(), GPitch());   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
+            const d2 d = sample(elv, gtile, ox, oy, true, x, y, e, GRows(), GPitch(), IterLevels());   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
             y = fma(A.hdtcy, d.y, y);
             x = fma(hdtcx, d.x, x);
             clamp_position<double>(A, x, y);
@@ -2853,7 +3009,21 @@ struct Lds64Launch<double> {
     }
     // order 3 (SETTLS_order = 0 included: the Euler sample has its own tile)
     static const char *launch_o3(const AdvectArgs<double> &A, int grid, hipStream_t st, int mode) {
-        if (mode == 0 || A.wind_f32 || !A.ext || A.nx_f + LC_PAD < T64O3 || A.ny_f + LC_PAD < T64O3) return nullptr;
+        if (mode == 0 || A.wind_f32 || !(A.ext || A.ext_cub) || A.nx_f + LC_PAD < T64O3 || A.ny_f + LC_PAD < T64O3) return nullptr;
+        if (A.ext_cub) {  // no ext image: the iteration tile is formed from img[t], img[t+1] while it is staged
+            if (A.K == 4 && A.cyclic) {
+                hipLaunchKernelGGL((advect_lds64_o3_kernel<4, true, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+                return "advect_lds64_o3_kernel<4, true, cub>";
+            } else if (A.K == 4) {
+                hipLaunchKernelGGL((advect_lds64_o3_kernel<4, false, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+                return "advect_lds64_o3_kernel<4, false, cub>";
+            } else if (A.cyclic) {
+                hipLaunchKernelGGL((advect_lds64_o3_kernel<-1, true, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+                return "advect_lds64_o3_kernel<-1, true, cub>";
+            }
+            hipLaunchKernelGGL((advect_lds64_o3_kernel<-1, false, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
+            return "advect_lds64_o3_kernel<-1, false, cub>";
+        }
         if (A.K == 4 && A.cyclic) {
             hipLaunchKernelGGL((advect_lds64_o3_kernel<4, true>), dim3(grid, nmem(A)), dim3(BLOCK), 0, st, A);
             return "advect_lds64_o3_kernel<4, true>";
@@ -3118,6 +3288,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.v_raw = (const T *)v_raw;
     A.raw_plane = (size_t)ny_f * nx_f;
     A.ext_raw = fuse_levels_raw && sizeof(T) == 8 && order == 1 && u_raw && !wind_f32 && !packed_ext;
+    A.ext_cub = fuse_levels_raw && sizeof(T) == 8 && order == 3 && packed_cub && !wind_f32 && !packed_ext;
     A.level_elems = lc_level_elems(ny_f, nx_f);
     A.pitch = nx_f + LC_PAD;
     A.ny_f = ny_f;
@@ -3147,6 +3318,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     const bool outer = cyclic == LC_X_CLAMP_REFERENCE_OUTER;
     A.cyclic = cyclic == LC_X_CYCLIC;
     A.clamp_flag = nullptr;
+    A.verify = sizeof(T) == 4 ? ctx->verify_dev : nullptr;
     unsigned *clamp_flag = nullptr;
     if (outer) {
         // fused kernel first, with a flag that says whether the clamp ever moved a parcel; if not, per-point and
@@ -3183,7 +3355,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // measured and dropped (it costs 5 % everywhere to save 8 % in that extreme).
     // lc_ctx_set_lds_tiles / LCS_LDS_TILES (read once at context creation) override (profiling).
     const bool use_lds = ctx->lds_tiles != 0;
-    const bool fused64 = sizeof(T) == 8 && (A.ext != nullptr || A.ext_raw);  // single-sample iterations in float64
+    const bool fused64 = sizeof(T) == 8 && (A.ext != nullptr || A.ext_raw || A.ext_cub);  // single-sample iterations in float64
     const char *name = nullptr;
     auto launch = [&](const AdvectArgs<T> &A) {
         if (order == 2 || order == 4 || order == 5) {  // generic direct kernel, any dtype
@@ -3192,7 +3364,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         } else if (order == 3) {
             if (fused64) {
                 name = Lds64Launch<T>::launch_o3(A, grid, ctx->stream, ctx->lds_tiles);
-                if (!name) {
+                if (!name) {  // (with ext_cub too: advect_seed_fast64_o3 looks at it)
                     hipLaunchKernelGGL((advect_kernel<T, 3, sizeof(T) == 8>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
                     name = "advect_kernel<double, 3, true, 0>";
                 }
@@ -3327,6 +3499,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         if (restart >= 0) {
             A.ext = nullptr;  // the exact path keeps the reference's two-sample form
             A.ext_raw = 0;
+            A.ext_cub = 0;
             rc = advect_outer_impl<T>(ctx, A, restart, restart > 0 ? saved : (const T *)A.x_start,
                                       restart > 0 ? saved + plane_elems : (const T *)A.y_start);
         }

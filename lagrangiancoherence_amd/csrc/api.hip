@@ -69,6 +69,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->last_advect_kernel = "";
     c->last_advect_launches = 0;
     c->last_sigma_kernel = "";
+    c->verify_dev = nullptr;
     c->trunc = nullptr;
     *out = c;
     return LC_OK;
@@ -171,6 +172,45 @@ extern "C" int lc_ctx_set_level_chunk(lc_ctx *ctx, int levels) {
     return LC_OK;
 }
 
+// Wave-state audit of the one-seed order-1 LDS kernel (advect.hip, VERIFY instances): 16 counters in device memory.
+extern "C" int lc_ctx_set_verify(lc_ctx *ctx, int mode) {
+    LC_REQUIRE(ctx, "lc_ctx_set_verify: null context");
+    LC_REQUIRE(mode >= 0 && mode <= 2, "lc_ctx_set_verify: mode must be 0 (off), 1 (audit) or 2 (audit + one injected corruption)");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (mode == 0) {
+        if (ctx->verify_dev) LC_HIP_CHECK(hipFree(ctx->verify_dev));
+        ctx->verify_dev = nullptr;
+        return LC_OK;
+    }
+    if (!ctx->verify_dev) {
+        hipError_t e = hipMalloc((void **)&ctx->verify_dev, LC_VERIFY_WORDS * sizeof(unsigned));
+        if (e != hipSuccess) {
+            ctx->verify_dev = nullptr;
+            lc_set_error("lc_ctx_set_verify: hipMalloc failed: %s", hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? LC_ENOMEM : LC_EHIP;
+        }
+    }
+    unsigned init[LC_VERIFY_WORDS] = {};
+    init[15] = mode == 2 ? 0xBADu : 0u;
+    LC_HIP_CHECK(hipMemcpy(ctx->verify_dev, init, sizeof(init), hipMemcpyHostToDevice));
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_read_verify(lc_ctx *ctx, unsigned *out16, int reset) {
+    LC_REQUIRE(ctx && out16, "lc_ctx_read_verify: null pointer");
+    LC_REQUIRE(ctx->verify_dev, "lc_ctx_read_verify: the audit is off (lc_ctx_set_verify)");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    LC_HIP_CHECK(hipMemcpy(out16, ctx->verify_dev, LC_VERIFY_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (reset) {
+        unsigned init[LC_VERIFY_WORDS] = {};
+        init[15] = out16[15];
+        LC_HIP_CHECK(hipMemcpy(ctx->verify_dev, init, sizeof(init), hipMemcpyHostToDevice));
+    }
+    return LC_OK;
+}
+
 extern "C" const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_advect_kernel : ""; }
 extern "C" int lc_ctx_last_advect_launches(const lc_ctx *ctx) { return ctx ? ctx->last_advect_launches : 0; }
 extern "C" const char *lc_ctx_last_sigma_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_sigma_kernel : ""; }
@@ -180,6 +220,7 @@ extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     lc_trunc_cache_free(ctx->trunc);
+    if (ctx->verify_dev) (void)hipFree(ctx->verify_dev);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return LC_OK;

@@ -29,6 +29,7 @@ struct lc_ctx {
     int last_advect_launches;  // kernel launches the last lc_advect made (level chunks)
     const char *last_advect_kernel;
     const char *last_sigma_kernel;
+    unsigned *verify_dev;  // NULL, or 16 uint32 wave-state counters in device memory (lc_ctx_set_verify)
     lc_trunc_cache *trunc;
 };
 

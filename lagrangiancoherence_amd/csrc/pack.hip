@@ -39,25 +39,29 @@ __global__ void pack_interior_kernel(const T *__restrict__ u, const T *__restric
     }
 }
 
-// pad nodes <- mirrored interior nodes (runs after the interior is final)
+// pad nodes <- mirrored interior nodes (runs after the interior is final): the 3 (ny + nx + 3) pad nodes of a level,
+// one thread per pad node (grid: pad chunks x levels)
 template <typename T>
-__global__ void fill_pads_kernel(T *__restrict__ packed, int nt, int ny, int nx) {
-    const int pitch = nx + LC_PAD;
-    const int prow = ny + LC_PAD;
-    const size_t level = (size_t)prow * pitch;
-    const size_t total = level * nt;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const size_t t = i / level;
-        const size_t r = i - t * level;
-        const int py = (int)(r / pitch);
-        const int px = (int)(r - (size_t)py * pitch);
-        const int y = py - LC_PAD_LO, x = px - LC_PAD_LO;
-        if (y >= 0 && y < ny && x >= 0 && x < nx) continue;
-        const int sy = mirror_index(y, ny), sx = mirror_index(x, nx);
-        const size_t s = (t * level + (size_t)(sy + LC_PAD_LO) * pitch + (sx + LC_PAD_LO)) * 2;
-        packed[2 * i] = packed[s];
-        packed[2 * i + 1] = packed[s + 1];
+__global__ void __launch_bounds__(256) pads_only_kernel(T *__restrict__ packed, int nt, int ny, int nx) {
+    const int pitch = nx + LC_PAD, nrowpad = LC_PAD * pitch, npad = nrowpad + LC_PAD * ny;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    int py, px;
+    if (i < nrowpad) {  // the LC_PAD whole pad rows: padded row 0, then ny + 1, ny + 2
+        const int k = i / pitch;
+        px = i - k * pitch;
+        py = k < LC_PAD_LO ? k : ny + k;
+    } else {            // the LC_PAD pad columns of the interior rows: padded column 0, then nx + 1, nx + 2
+        const int j = i - nrowpad, y = j / LC_PAD, k = j - y * LC_PAD;
+        py = y + LC_PAD_LO;
+        px = k < LC_PAD_LO ? k : nx + k;
+    }
+    const int sy = mirror_index(py - LC_PAD_LO, ny), sx = mirror_index(px - LC_PAD_LO, nx);
+    const size_t level = (size_t)(ny + LC_PAD) * pitch;
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    for (int t = blockIdx.y; t < nt; t += gridDim.y) {
+        T2 *img = (T2 *)packed + (size_t)t * level;
+        img[(size_t)py * pitch + px] = img[(size_t)(sy + LC_PAD_LO) * pitch + (sx + LC_PAD_LO)];
     }
 }
 
@@ -397,7 +401,10 @@ __global__ void __launch_bounds__(64) prefilter_rows_lds_kernel(T *__restrict__ 
 // 32 nodes ahead of the nodes being finished and only finished coefficients are written.  The last window of a line
 // starts from scipy's exact mirror formula at n-1 (bit-identical tail).  LCS_FIR_PREFILTER=0: the two-march kernels.
 // ======================================================================================
-constexpr int PS_C = 16, PS_H = 32, PS_W = PS_C + PS_H;  // latitude sweep: nodes finished per round, lookahead, register window
+#ifndef LCS_PS_C
+#define LCS_PS_C 16
+#endif
+constexpr int PS_C = LCS_PS_C, PS_H = 32, PS_W = PS_C + PS_H;  // latitude sweep: nodes finished per round, lookahead, register window
 
 __global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const double *__restrict__ u, const double *__restrict__ v,
                                                                     double *__restrict__ packed, int nt, int ny, int nx) {
@@ -488,7 +495,10 @@ __global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const double
 // values of chunks k and k+1; the lane starts the anticausal walk at the end of chunk k+1, walks chunk k+1 without
 // writing, finishes chunk k in place; the wave stores chunk k as whole 512-byte row segments, drops chunk k+2 (loaded
 // into registers before the walk, so its latency is behind it) into the freed half and runs the causal march over it.
-constexpr int RS_ROWS = 32, RS_C = 32, RS_RING = 2 * RS_C;
+#ifndef LCS_RS_ROWS
+#define LCS_RS_ROWS 32
+#endif
+constexpr int RS_ROWS = LCS_RS_ROWS, RS_C = 32, RS_RING = 2 * RS_C;  // RS_ROWS < 32: the recursion runs on the first 2 RS_ROWS lanes, the copies on all 64
 
 __global__ void __launch_bounds__(64) prefilter_rows_stream_kernel(double *__restrict__ packed, int ny, int nx) {
     __shared__ double ring[RS_ROWS][2 * RS_RING + 1];
@@ -498,8 +508,8 @@ __global__ void __launch_bounds__(64) prefilter_rows_stream_kernel(double *__res
     const int t = blockIdx.y;
     const int r0 = blockIdx.x * RS_ROWS;
     const int lane = threadIdx.x;
-    const int row = lane >> 1, comp = lane & 1;
-    const bool line_ok = r0 + row < ny;
+    const int row = (lane >> 1) % RS_ROWS, comp = lane & 1;
+    const bool line_ok = lane < 2 * RS_ROWS && r0 + row < ny;
     double *base = packed + (size_t)t * level + ((size_t)(r0 + LC_PAD_LO) * pitch + LC_PAD_LO) * 2;  // row r0, node 0
     const int nrows = min(RS_ROWS, ny - r0);
     double *mine = &ring[row][comp];  // node i of this lane's line: mine[2 * (i & 63)]
@@ -647,7 +657,7 @@ __global__ void __launch_bounds__(256) pack_fused_kernel(const T *__restrict__ u
 
 // Pads of img and the whole of ext = 2*img[t] - img[t+1] in one pass over the padded levels: every padded node
 // reads its mirrored interior source at levels t and t+1 (interior nodes are final by now), writes its own pad
-// of img[t] if it is one, and its node of ext[t].  Replaces fill_pads_kernel + extrapolate_kernel.  Level t+1 is
+// of img[t] if it is one, and its node of ext[t].  (Without ext: pads_only_kernel.)  Level t+1 is
 // carried forward over PACK_LV levels as in pack_fused_kernel: each level of the image is read once (float64 config 2 at
 // order 3: 10.4 -> 7.0 GB moved).
 template <typename T>
@@ -830,8 +840,10 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
             const dim3 grid((nx + FT - 1) / FT, (ny + FT - 1) / FT, nt * (both ? 2 : 1));
             hipLaunchKernelGGL(prefilter_fir_kernel, grid, dim3(256), 0, ctx->stream, u, v, packed, both ? ext : nullptr, nt, ny, nx,
                                cubic_fir_taps());
-            if (ext && nt >= 2 && !both)  // ext = 2 img[t] - img[t+1] from the finished coefficients (pads rewritten, same values)
-                hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, (nt + PACK_LV - 1) / PACK_LV), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
+            if (ext && nt >= 2 && !both) {  // ext = 2 img[t] - img[t+1] from the finished coefficients (pads rewritten, same values)
+                const int nchunk = (nt + PACK_LV - 1) / PACK_LV;
+                hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nchunk < 65535 ? nchunk : 65535), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
+            }
             LC_HIP_CHECK(hipGetLastError());
             return LC_OK;
         }
@@ -872,10 +884,11 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
         hipLaunchKernelGGL(prefilter_general_kernel<T>, dim3((unsigned)((l1 + 63) / 64)), dim3(64), 0, ctx->stream, packed, nt,
                            ny, nx, 1, P);
     }
+    const int nchunk = (nt + PACK_LV - 1) / PACK_LV;   // (grid.y and grid.z are capped at 65535 blocks: the kernels loop over what is beyond)
     if (ext && nt >= 2)   // pads + fused-level image in one pass
-        hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, (nt + PACK_LV - 1) / PACK_LV), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
-    else
-        hipLaunchKernelGGL(fill_pads_kernel<T>, dim3(8192), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
+        hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nchunk < 65535 ? nchunk : 65535), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
+    else                  // the pads alone (no fused-level image: lc_advect_args.fuse_levels_raw, or the reference's two-sample form)
+        hipLaunchKernelGGL(pads_only_kernel<T>, dim3((LC_PAD * (nx + LC_PAD) + LC_PAD * ny + 255) / 256, nt < 65535 ? nt : 65535), dim3(threads), 0, ctx->stream, packed, nt, ny, nx);
     LC_HIP_CHECK(hipGetLastError());
     return LC_OK;
 }

@@ -72,7 +72,8 @@ class PackedField:
     fuse_raw: bool = False          # float64 at order 1: fused levels with NO packed image (2 F[t] - F[t+1] formed from u, v in the kernels)
     u: "torch.Tensor | None" = None  # the raw planes (nt, ny_f, nx_f) the images were packed from, kept as the ORDER-1 source
     v: "torch.Tensor | None" = None  # (lc_advect_ex: pole rows at any order, the Euler sample in float64) -- not copies: do not
-    #                                  modify them in place while the field is in use
+    #                                  modify them in place while the field is in use (Engine._ensure_lin refuses if you did)
+    planes_version: "tuple | None" = None  # (u._version, v._version) when the field was prepared
 
 
 class Engine:
@@ -90,6 +91,8 @@ class Engine:
         ctx = C.c_void_p()
         _capi.check(self.lib.lc_ctx_create(self.device_index, C.byref(ctx)), self.lib)
         self.lds_tiles_mode = -1      # what set_lds_tiles was last given (-1: the library's default, or LCS_LDS_TILES)
+        self.verify_mode = 0          # lc_ctx_set_verify
+        self._poison = bool(os.environ.get("LCS_DEBUG_POISON"))
         self.ctx = ctx
 
     def close(self):
@@ -194,6 +197,26 @@ class Engine:
         """Name of the kernel the last :meth:`advect` call launched (as a profiler shows it)."""
         return self.lib.lc_ctx_last_advect_kernel(self.ctx).decode()
 
+    def set_verify(self, mode: int = 1):
+        """Wave-state audit of the one-seed order-1 LDS kernel (``lc_ctx_set_verify``): 1 on, 2 on with one injected
+        corruption (test hook), 0 off.  Results are bit-identical; :meth:`read_verify` returns the counters."""
+        _capi.check(self.lib.lc_ctx_set_verify(self.ctx, int(mode)), self.lib)
+        self.verify_mode = int(mode)
+
+    def read_verify(self, reset: bool = True) -> dict:
+        """The audit's counters (synchronises): ``tile_changed`` wave-levels whose LDS tile no longer held what the wave
+        staged, ``entries_changed`` 16-byte entries, ``slot_changes`` wave-levels at which the wave sat in another hardware
+        slot than a level earlier (its context was switched out and back in), ``audited`` wave-levels checked, and the
+        first event (workgroup, tile, wave, level, HW_ID before / after, lane mask)."""
+        out = (C.c_uint * 16)()
+        _capi.check(self.lib.lc_ctx_read_verify(self.ctx, out, int(bool(reset))), self.lib)
+        v = [int(x) for x in out]
+        d = {"tile_changed": v[0], "entries_changed": v[1], "slot_changes": v[2], "audited": v[3]}
+        if v[12]:
+            d["first_event"] = {"workgroup": v[4], "tile": v[5], "wave": v[6], "level": v[7], "hw_id_before": hex(v[8]),
+                                "hw_id_after": hex(v[9]), "lane_mask": hex(v[10] | (v[11] << 32))}
+        return d
+
     def last_advect_launches(self) -> int:
         """Kernel launches the last :meth:`advect` call made (level chunks)."""
         return int(self.lib.lc_ctx_last_advect_launches(self.ctx))
@@ -202,6 +225,11 @@ class Engine:
     # float64 at order 1 with fused levels: build the fused-level image (True), or let the kernels form it from the raw
     # planes (False: no pack at all).  Measured on BASELINE configs[1] (profiles/r04): see DESIGN.md section 4.
     EXT_IMAGE_F64 = True
+    # float64 at order 3 with fused levels: build the fused-level COEFFICIENT image ext = 2 cub[t] - cub[t+1] (True), or let
+    # the kernels form it from cub node by node (False: the pack neither reads the coefficients back nor writes a second
+    # image, the advect kernel streams one image series instead of two).  Measured on BASELINE configs[1] at order 3
+    # (profiles/r05): see DESIGN.md section 4.
+    EXT_IMAGE_F64_O3 = False
 
     class _Concurrent:
         """Context manager for ``n`` advect calls running side by side on different streams: what fills the machine is
@@ -242,7 +270,13 @@ class Engine:
         return t.contiguous()
 
     def _empty(self, shape, dtype):
-        return self.torch.empty(shape, dtype=getattr(self.torch, np.dtype(dtype).name), device=self.device)
+        t = self.torch.empty(shape, dtype=getattr(self.torch, np.dtype(dtype).name), device=self.device)
+        if self._poison and t.is_floating_point():
+            # LCS_DEBUG_POISON=1 (read once, at Engine creation): every buffer the engine allocates starts as NaN instead of
+            # whatever the caching allocator hands back -- typically the previous call's identical results, which would make
+            # an element that a kernel forgot to write look right.  The GPU suite runs green with it.
+            t.fill_(float("nan"))
+        return t
 
     @staticmethod
     def _ptr(t):
@@ -262,6 +296,9 @@ class Engine:
         ``ext_image`` (float64 at ``interp_order=1`` with ``fuse_levels``): False = do not build the fused-level image
         either -- the kernels form ``2 F[t] - F[t+1]`` from the raw planes node by node (``lc_advect_args.fuse_levels_raw``;
         the same expression, bit-identical results): such a field needs NO pack at all.  Default: see ``EXT_IMAGE_F64``.
+        At ``interp_order=3`` (float64): False = the kernels form the fused-level coefficients ``2 cub[t] - cub[t+1]`` from
+        the coefficient image node by node (bit-identical too): the pack is the two prefilter sweeps and the pads, nothing
+        more.  Default: see ``EXT_IMAGE_F64_O3``.
 
         ``fuse_levels``: also build ext[t] = 2 F[t] - F[t+1] so each SETTLS iteration takes one
         gather instead of two (interpolation is linear in the field => the same value up to rounding).
@@ -299,6 +336,8 @@ class Engine:
         fuse_raw = False
         if fuse_levels and nt >= 2 and dtype != f32 and interp_order == 1 and not lin_image:
             fuse_raw = not (self.EXT_IMAGE_F64 if ext_image is None else ext_image)
+        if fuse_levels and nt >= 2 and dtype != f32 and interp_order == 3:
+            fuse_raw = not (self.EXT_IMAGE_F64_O3 if ext_image is None else ext_image)
         if fuse_levels and nt >= 2 and not fuse_raw:
             ext = self._empty((self.lib.lc_packed_elems(nt - 1, ny_f, nx_f),), dtype)
         if dtype == f32 and interp_order == 1 and not lin_image:
@@ -315,8 +354,10 @@ class Engine:
         # coordinate extremes in the arithmetic dtype (what .min()/.max() give numpy)
         la = lat_f.astype(dtype)
         lo = lon_f.astype(dtype)
+        keep = lin is None
         return PackedField(lin, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
-                           wind_f32, int(interp_order), fuse_raw, None if lin is not None else ud, None if lin is not None else vd)
+                           wind_f32, int(interp_order), fuse_raw, ud if keep else None, vd if keep else None,
+                           (ud._version, vd._version) if keep else None)
 
     # ------------------------------------------------------------------ global pre-processing (LCS.py:105-118)
     def regrid(self, u, lat, lon, lats, lons):
@@ -443,12 +484,7 @@ class Engine:
         """``lc_advect_args`` of one call: the field's images, and its raw planes as the order-1 source where it has no
         lin image."""
         dt = _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[field.dtype]
-        if field.lin is None and field.dtype == np.dtype(np.float32) and interp_order == 1:
-            # a float32 field prepared for another order, now sampled at order 1 ("order 1 is always available"): its
-            # kernels read the order-1 image's 16-byte node pairs -- built here, once, and kept on the field
-            field.lin = self._empty((self.lib.lc_packed_elems(field.nt, field.ny_f, field.nx_f),), field.dtype)
-            _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(field.u), self._ptr(field.v), _NP2LC[field.dtype], field.nt,
-                                               field.ny_f, field.nx_f, 1, self._ptr(field.lin), None), self.lib)
+        self._ensure_lin(field, interp_order)
         p = lambda t: t.data_ptr() if t is not None else None
         return _capi.AdvectArgs(
             struct_size=C.sizeof(_capi.AdvectArgs), packed_lin=p(field.lin),
@@ -459,12 +495,32 @@ class Engine:
             row0=int(row0), ny_global=int(ny_global), x_start=p(sx), y_start=p(sy), timestep=float(timestep),
             settls_order=int(K), interp_order=int(interp_order), cyclic_x=int(xmode), t0=int(t0), nsteps=int(nsteps),
             n_members=int(n_members), t0_stride=int(t0_stride), x_out=p(x), y_out=p(y), traj_x=p(tx), traj_y=p(ty),
-            fuse_levels_raw=int(bool(field.fuse_raw and interp_order == 1)))
+            fuse_levels_raw=int(bool(field.fuse_raw and interp_order == field.order)))
+
+    def _ensure_lin(self, field: PackedField, interp_order: int):
+        """The order-1 source of a call on ``field``, checked and -- where it is an image that does not exist yet -- built.
+
+        A float32 field prepared for another order and now used at order 1 ("order 1 is always available"): its kernels
+        read the order-1 image's 16-byte node pairs, so the image is packed here, once, and kept on the field (``advect``
+        and ``sample`` alike).  Everywhere else the raw planes ``field.u`` / ``field.v`` are the order-1 source; they are
+        BORROWED from the caller when ``prepare_field`` was handed device tensors, so an in-place write to them since
+        then (a time loop refilling its buffers) would silently change what the pole rows and the float64 Euler sample
+        read while the packed images still hold the old wind: refused here by the tensors' version counters."""
+        if field.u is not None and field.planes_version is not None and \
+                (field.u._version, field.v._version) != field.planes_version:
+            raise RuntimeError("the wind tensors given to prepare_field were modified in place afterwards: the field's packed "
+                               "images no longer match them (prepare the field again, or pass copies)")
+        if field.lin is None and field.dtype == np.dtype(np.float32) and interp_order == 1:
+            field.lin = self._empty((self.lib.lc_packed_elems(field.nt, field.ny_f, field.nx_f),), field.dtype)
+            self._use_current_stream()
+            _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(field.u), self._ptr(field.v), _NP2LC[field.dtype], field.nt,
+                                               field.ny_f, field.nx_f, 1, self._ptr(field.lin), None), self.lib)
 
     def sample(self, field: PackedField, pos_x, pos_y, level=0, interp_order=1, row0=0, ny_global=None):
         """tools.xr_map_coordinates for (u, v) of one time level at positions (ny, nx) in degrees."""
         if interp_order != 1 and field.order != interp_order:
             raise ValueError(f"field was prepared for interp_order={field.order}")
+        self._ensure_lin(field, interp_order)
         dtype = field.dtype
         px = self.to_device(pos_x, dtype)
         py = self.to_device(pos_y, dtype)
@@ -613,7 +669,7 @@ class Engine:
 
     def pack_and_advect(self, u, v, lat_f, lon_f, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
                         cyclic_xboundary=True, fuse_levels=None, pipeline=None, chunk=None, return_traj=False,
-                        noncyclic_clamp=None):
+                        noncyclic_clamp=None, ext_image=None):
         """:meth:`prepare_field` + :meth:`advect` of the whole series in one call.  Returns ``(field, x, y[, traj_x, traj_y])``.
 
         ``pipeline`` (None: where it pays, :meth:`pipeline_pays`): the series is cut into chunks of ``chunk`` time levels;
@@ -637,7 +693,7 @@ class Engine:
         can = (cyclic_xboundary and not return_traj and interp_order in (1, 3) and fuse_levels and not wind_f32 and nt - 1 > chunk >= 1
                and not (dtype == f32 and interp_order == 1))      # (float32 at order 1 carries a lin image too: serial form)
         if not (pipeline and can):
-            field = self.prepare_field(u, v, lat_f, lon_f, interp_order, fuse_levels=fuse_levels)
+            field = self.prepare_field(u, v, lat_f, lon_f, interp_order, fuse_levels=fuse_levels, ext_image=ext_image)
             res = self.advect(field, seed_lat, seed_lon, timestep, SETTLS_order, interp_order, cyclic_xboundary,
                               return_traj=return_traj, noncyclic_clamp=noncyclic_clamp)
             return (field, *res)
@@ -649,10 +705,11 @@ class Engine:
         ud, vd = self.to_device(u, dtype), self.to_device(v, dtype)
         le = self.lib.lc_packed_elems(1, ny_f, nx_f)
         cub = self._empty((le * nt,), dtype) if interp_order == 3 else None
-        ext = self._empty((le * (nt - 1),), dtype)
+        no_ext = dtype != f32 and interp_order == 3 and not (self.EXT_IMAGE_F64_O3 if ext_image is None else ext_image)   # the kernels form it from cub (prepare_field)
+        ext = None if no_ext else self._empty((le * (nt - 1),), dtype)
         la, lo = lat_f.astype(dtype), lon_f.astype(dtype)
         field = PackedField(None, cub, ext, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
-                            False, int(interp_order), False, ud, vd)
+                            False, int(interp_order), no_ext, ud, vd, (ud._version, vd._version))
         slat, slon = self.to_device(seed_lat, dtype), self.to_device(seed_lon, dtype)
         x, y = self._empty((ny, nx), dtype), self._empty((ny, nx), dtype)
         cur = torch.cuda.current_stream(self.device)
@@ -664,25 +721,27 @@ class Engine:
         #  time the field can be freed -- in the current stream's order -- the side stream is done with it; recording the
         #  6.8 GB of images instead made the caching allocator hold the blocks back and cudaMalloc new ones every step)
         events, starts = [], list(range(0, nt - 1, chunk))
-        with torch.cuda.stream(side):
-            self._use_current_stream()
-            for t0 in starts:
-                n = min(chunk, nt - 1 - t0)         # image levels [t0, t0 + n], ext levels [t0, t0 + n)
-                _capi.check(self.lib.lc_field_pack(
-                    self.ctx, C.c_void_p(ud[t0:].data_ptr()), C.c_void_p(vd[t0:].data_ptr()), _NP2LC[dtype], n + 1, ny_f, nx_f,
-                    int(interp_order), C.c_void_p(cub[le * t0:].data_ptr()) if cub is not None else None,
-                    C.c_void_p(ext[le * t0:].data_ptr())), self.lib)
-                e = torch.cuda.Event()
-                e.record(side)
-                events.append(e)
         try:
+            with torch.cuda.stream(side):
+                self._use_current_stream()
+                for t0 in starts:
+                    n = min(chunk, nt - 1 - t0)         # image levels [t0, t0 + n], ext levels [t0, t0 + n)
+                    _capi.check(self.lib.lc_field_pack(
+                        self.ctx, C.c_void_p(ud[t0:].data_ptr()), C.c_void_p(vd[t0:].data_ptr()), _NP2LC[dtype], n + 1, ny_f, nx_f,
+                        int(interp_order), C.c_void_p(cub[le * t0:].data_ptr()) if cub is not None else None,
+                        C.c_void_p(ext[le * t0:].data_ptr()) if ext is not None else None), self.lib)
+                    e = torch.cuda.Event()
+                    e.record(side)
+                    events.append(e)
             for e, t0 in zip(events, starts):
                 cur.wait_event(e)
                 n = min(chunk, nt - 1 - t0)
                 self.advect(field, slat, slon, timestep, SETTLS_order, interp_order, True, t0=t0, nsteps=n,
                             start=(x, y) if t0 else None, out=(x, y))
         finally:
-            cur.wait_stream(side)              # whatever happened above: nothing of this call is left running behind the current stream
+            # whatever happened above -- a pack refused half way through the loop included -- nothing of this call is left
+            # running behind the current stream: the images were allocated on it and deliberately not record_stream'd
+            cur.wait_stream(side)
         return field, x, y
 
     # ------------------------------------------------------------------ whole path

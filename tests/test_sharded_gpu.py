@@ -19,29 +19,32 @@ def _free_port():
 
 
 def _run_ranks(worker, world, extra_args, timeout=300):
-    """`world` spawned processes of `worker(rank, world, port, *extra_args, queue)`; their queue entries.
-    These tests put several PROCESSES on one GPU (time-shared).  On two pool boxes of round 4 that layout produced, rarely,
-    a handful of differing rows between two lc_advect calls on identical inputs (never reproduced in
-    one process, nor on other boxes); a run whose only complaint is such a mismatch is therefore repeated ONCE, loudly --
-    what these tests are about is the sharding logic, which a second clean run establishes as well as a first."""
-    def once():
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=worker, args=(r, world, port, *extra_args, q)) for r in range(world)]
-        for p in procs:
-            p.start()
-        res = [q.get(timeout=timeout) for _ in procs]
-        for p in procs:
-            p.join(timeout=60)
-        return res
-    res = once()
-    if any(isinstance(r[1], str) and r[1] != "ok" and "Traceback" not in r[1] for r in res):
-        import warnings
-        warnings.warn(f"multi-process GPU test: mismatch on the first run, repeating once: {res}")
-        print("mismatch on the first run, repeating once:", res)
-        res = once()
+    """`world` spawned processes of `worker(rank, world, port, *extra_args, queue)`; their queue entries.  Run ONCE
+    (round 4 repeated a run whose only complaint was a bit-mismatch; tests/_multiproc.py says what happens instead)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, *extra_args, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
     return res
+
+
+def _differences(pairs, eng):
+    """What differs between tensors that must be bit-identical: per pair the count and the first (row, col)s with both
+    values, plus the wave-state audit of every call this process made (lc_ctx_set_verify)."""
+    rep = {}
+    for name, (got, want) in pairs.items():
+        d = (got != want) | (torch.isnan(got) != torch.isnan(want))
+        if bool(d.any()):
+            idx = d.nonzero()[:8].tolist()
+            rep[name] = {"n": int(d.sum()), "rows": sorted(set(i[0] for i in d.nonzero().tolist()))[:16],
+                         "first": [{"at": i, "got": float(got[tuple(i)]), "want": float(want[tuple(i)])} for i in idx]}
+    rep["wave_state_audit"] = eng.read_verify(reset=False) if eng.verify_mode else None
+    return rep
 
 
 def _worker(rank, world, port, order, q):
@@ -53,6 +56,7 @@ def _worker(rank, world, port, order, q):
         from lagrangiancoherence_amd.engine import Engine
         torch.cuda.set_device(0)
         eng = Engine(0)
+        eng.set_verify(1)       # processes time-sharing a GPU: every wave audits its LDS tile and slot (tests/_multiproc.py)
         u, v, lat, lon = flows.era5_like(nt=7, ny=72, nx=144)
         slat, slon = flows.seed_grid(203, 320, lat, lon)          # rows do not divide evenly
         f = eng.prepare_field(u, v, lat, lon, order)
@@ -63,7 +67,10 @@ def _worker(rank, world, port, order, q):
         lo, hi = out["rows"]
         ok = (torch.equal(out["sigma"], full["sigma"][lo:hi]) and torch.equal(out["x_dep"], full["x_dep"][lo:hi])
               and torch.equal(red["sigma"], out["sigma"]) and bool(torch.isfinite(out["sigma"]).all()))
-        q.put((rank, "ok" if ok else f"mismatch rows {lo}:{hi}"))
+        q.put((rank, "ok" if ok else _differences({"sigma vs unsharded": (out["sigma"], full["sigma"][lo:hi]),
+                                                   "x_dep vs unsharded": (out["x_dep"], full["x_dep"][lo:hi]),
+                                                   "y_dep vs unsharded": (out["y_dep"], full["y_dep"][lo:hi]),
+                                                   "sigma, redundant halo vs exchanged": (red["sigma"], out["sigma"])}, eng)))
         eng.close()
     except Exception:  # pragma: no cover
         import traceback
@@ -74,9 +81,8 @@ def _worker(rank, world, port, order, q):
 
 @pytest.mark.parametrize("world,order", [(2, 1), (3, 3)])
 def test_sharded_engine_bit_identical_to_unsharded(world, order):
-    res = _run_ranks(_worker, world, (order,))
-    for rank, msg in res:
-        assert msg == "ok", f"rank {rank}: {msg}"
+    from tests._multiproc import judge_worker_results
+    judge_worker_results(_run_ranks(_worker, world, (order,)))
 
 
 def test_native_rccl_communicator_single_rank():
