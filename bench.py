@@ -356,6 +356,40 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
                  (lambda: eng.pack_and_advect(u2, v2, lat2, lon2, la_d, lo_d, -900.0, K, order, True)[1:]) if piped else None)
     except Exception as exc:
         out["c2"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    # The other BASELINE configurations and north_star's own target shape on ONE GPU, one or two steps each (C4 is 96 ms a
+    # step, C5 285): the long series is evaluated on the device (flows.era5_like_on_device: the headline's field
+    # continued to 385 levels; a value may differ from the host generator's in the last float32 bit -- throughput only).
+    try:
+        u2 = v2 = None
+        torch.cuda.empty_cache()
+        from lagrangiancoherence_amd import sharded
+        u5, v5, lat5, lon5 = flows.era5_like_on_device(torch, eng.device, nt=385, ny=int(ud.shape[1]), nx=int(ud.shape[2]))
+        steps, warmup = 2, 1
+        # north_star: "4096^2 seeds x 200 steps"
+        case("c3 x 200 steps", ny * nx * 200, K, 1, 4, lambda: eng.prepare_field(u5[:201], v5[:201], lat5, lon5, 1),
+             lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 1, True), sig32)
+        # configs[3] whole on one GPU: 8192^2 seeds x 384 steps
+        s4lat, s4lon = flows.seed_grid(8192, 8192, lat5, lon5)
+        s4lat_d, s4lon_d = eng.to_device(s4lat, np.float32), eng.to_device(s4lon, np.float32)
+        d4 = (float(s4lat[1] - s4lat[0]), float(s4lon[1] - s4lon[0]))
+        case("c4 on one GPU", 8192 * 8192 * 384, K, 1, 4, lambda: eng.prepare_field(u5, v5, lat5, lon5, 1),
+             lambda f: eng.advect(f, s4lat_d, s4lon_d, -900.0, K, 1, True), lambda r: eng.sigma(r[0], r[1], s4lat_d, *d4))
+        del s4lat_d, s4lon_d
+        # configs[4] whole on one GPU: 64 start times x 2048^2 seeds x 200 steps on the first 264 levels
+        s5lat, s5lon = flows.seed_grid(2048, 2048, lat5, lon5)
+        s5lat_d, s5lon_d = eng.to_device(s5lat, np.float32), eng.to_device(s5lon, np.float32)
+        d5 = (float(s5lat[1] - s5lat[0]), float(s5lon[1] - s5lon[0]))
+
+        def c5_sigma(pos):
+            sg = None
+            for x, y in pos:
+                sg = eng.sigma(x, y, s5lat_d, *d5)
+            return sg
+        steps = 1
+        case("c5 on one GPU", 64 * 2048 * 2048 * 200, K, 1, 4, lambda: eng.prepare_field(u5[:264], v5[:264], lat5, lon5, 1),
+             lambda f: sharded.ensemble_advect(eng, f, s5lat_d, s5lon_d, -900.0, list(range(64)), 200, K, 1, True), c5_sigma)
+    except Exception as exc:
+        out["c4 on one GPU"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     return out
 
 

@@ -795,11 +795,7 @@ struct TileGeom {
 #endif
 template <int ORDER>
 struct EulerGeom {
-#ifdef LCS_NO_EULER_TILE
-    static constexpr bool ON = false;
-#else
     static constexpr bool ON = ORDER == 3;
-#endif
     static constexpr int COLS = 16, ROWS = LCS_E_ROWS, PITCH = LCS_E_PITCH;
     static constexpr int LANES_PER_ROW = COLS / 2, ROWS_PER_PASS = 64 / LANES_PER_ROW, NPASS = ROWS / ROWS_PER_PASS;
     static constexpr int ELEMS = ON ? ROWS * PITCH : 0;
@@ -847,15 +843,11 @@ __device__ __forceinline__ unsigned lds_address(const void *shared_ptr) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)shared_ptr;
 }
 
-#ifdef LCS_LDS_READ2
-typedef lds_f2 lds_node;
-#else
 // One ds_read_b64 per node, not ds_read2_b64 pairs: on gfx950 a wave's ds_read_b64 takes 2 LDS cycles (64
 // banks, 32-lane groups) while ds_read2_b64 takes 8 for twice the bytes (32 banks, 16-lane groups) -- half
 // the bandwidth, and conflicts between a node and its lower-left neighbour at these pitches (order 3 on C3:
 // LDS busy 81 % -> 52 % of the cycles).  The load/store optimiser pairs plain loads; volatile ones are left alone.
 typedef volatile lds_f2 lds_node;
-#endif
 
 template <int LT_PITCH>
 __device__ __forceinline__ lds_node *window_origin(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry) {
@@ -922,9 +914,7 @@ __device__ __forceinline__ f2 window_lds3(unsigned tile_addr, unsigned pitch_byt
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) q[a][b] = p[a * LT_PITCH + b];
-#ifndef LCS_O3_NO_HOIST
     __builtin_amdgcn_sched_barrier(0);  // all 16 reads in flight before the weights are formed
-#endif
     return cubic_apply(q, t, start);
 }
 
@@ -1120,11 +1110,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     // With the Euler sample gathered directly (order 3 without its Euler tile) the tile loads stay behind it:
     // 16 more live VGPRs across the 8 gathers cost two waves per SIMD (measured: 21.7 vs 21.0-21.2 ms)
     // (order 3 with its Euler tile: prefetching costs 14 VGPRs = one wave per SIMD, 18.1 vs 17.84 ms without)
-#ifdef LCS_O3_PREFETCH
-    constexpr bool PREFETCH = ORDER == 1 || E::ON;
-#else
     constexpr bool PREFETCH = ORDER == 1;
-#endif
     constexpr int CENTRE = TILE_W / 2 + TILE_W * ((64 / TILE_W) / 2);  // middle seed of the wave's patch
     // VERIFY: where this wave runs -- HW_REG_HW_ID (wave slot, SIMD, CU, SE, queue, VMID) and HW_REG_XCC_ID
     unsigned hw_id = 0, xcc_id = 0;
@@ -1236,22 +1222,6 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
             // absolute index coordinate: its rounding must not depend on where the tile sits (row-sharded runs
             // place tiles differently and must stay bit-identical to unsharded ones)
             TapL t = tap_of(to_index(p));
-#ifdef LCS_EXP_SALU  // sensitivity experiment: LCS_EXP_SALU dummy scalar instructions per sample
-            {
-                unsigned dummy = (unsigned)k;
-#pragma unroll
-                for (int q = 0; q < LCS_EXP_SALU; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy) : : "scc");
-                asm volatile("" : : "s"(dummy));
-            }
-#endif
-#ifdef LCS_EXP_VALU  // ... and LCS_EXP_VALU dummy 4-cycle vector instructions per sample
-            {
-                float dummy = t.tx;
-#pragma unroll
-                for (int q = 0; q < LCS_EXP_VALU; ++q) asm volatile("v_fract_f32 %0, %0" : "+v"(dummy));
-                asm volatile("" : : "v"(dummy));
-            }
-#endif
             const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;  // the subtrahends are wave-uniform (SGPRs)
             bool bad = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
             const f2 ew = window_lds<ORDER, LT_PITCH>(base_addr, pitch_bytes, rx, ry, t, e);  // e + sample of ext[t]
@@ -1640,11 +1610,6 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
                 base_addr = tile_addr + (unsigned)(lx - sox) * 16u + (unsigned)(ly - soy) * ((unsigned)LT_PITCH * 16u);
             }
         }
-        // per-level constants of the float window arithmetic (wave-uniform)
-        const f2 lo_f = {(float)lo_x, (float)lo_y};
-        const unsigned lim_bits_x = __float_as_uint((float)lim_x), lim_bits_y = __float_as_uint((float)lim_y);
-        const float base_f = (float)base_addr, pitch_f = (float)(LT_PITCH * 16);
-        (void)lo_f; (void)lim_bits_x; (void)lim_bits_y; (void)base_f; (void)pitch_f;
 #ifdef LCS_STAMPS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -1656,7 +1621,6 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 typedef __attribute__((address_space(3))) const f4 lds_f4;
-#ifndef LCS_LDS2_FLOAT_ADDR
                 const TapL t = tap_of(to_index(p[q]));
                 const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;
                 bad[q] = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
@@ -1675,31 +1639,6 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
                 unsigned row_addr;
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(base_addr));
                 lds_f4 *cell = (lds_f4 *)(size_t)(row_addr + ((unsigned)rx << 4));
-#else
-                // MEASURED AND NOT KEPT (-DLCS_LDS2_FLOAT_ADDR; bit-identical results, 7.21-7.29 ms against 7.17-7.18): on
-                // paper 8 cycles per sample cheaper, but hipcc adds two v_mov per sample to pair the fractions and
-                // 23 more hazard s_nop per level, which eat the gain.
-                // Window index and LDS address in FLOAT arithmetic: on gfx950 v_add / v_mul / v_fma_f32 issue in 2.25
-                // SIMD cycles, everything else (conversions, integer ops, compares, packed ops) in 4.13, so
-                //   floor(c) - lo = (c - lo) - fract(c)      two packed subtractions for both axes, EXACT (c, lo, fract(c)
-                //                                            are multiples of ulp(c); the result is a small integer)
-                //   address = base + ry * pitch + rx * 16    two plain fmas on small integers (exact) + ONE conversion
-                // replace 2 floor-conversions, 2 integer subtractions, a 24-bit mad and a shift-add.  The fractions are
-                // fract() of the ABSOLUTE coordinate, as in every other float kernel: same bits, wherever the tile sits.
-                // The range test is an unsigned compare on the float's bits (negative, NaN and too large all fail).
-                f2 c = to_index(p[q]);
-                asm volatile("" : "+v"(c));  // c must be the ROUNDED coordinate in both uses below: no fma(d, s, -lo)
-                f2 fr;
-                fr.x = __builtin_amdgcn_fractf(c.x);
-                fr.y = __builtin_amdgcn_fractf(c.y);
-                const f2 rf = (c - lo_f) - fr;
-                bad[q] = (unsigned)(__float_as_uint(rf.x) > lim_bits_x) | (unsigned)(__float_as_uint(rf.y) > lim_bits_y);
-                struct { float tx, ty; } t = {fr.x, fr.y};
-                const float addr_f = __builtin_fmaf(rf.y, pitch_f, __builtin_fmaf(rf.x, 16.0f, base_f));
-                unsigned cell_addr;
-                asm("v_cvt_u32_f32 %0, %1" : "=v"(cell_addr) : "v"(addr_f));  // negative / NaN -> 0, too large saturates: LDS reads cannot fault
-                lds_f4 *cell = (lds_f4 *)(size_t)cell_addr;
-#endif
                 const f4 c0 = cell[0], c1 = cell[LT_PITCH];
                 const f2 r0 = c0.xy + t.tx * c0.zw;   // n00 + tx (n01 - n00)
                 const f2 r1 = c1.xy + t.tx * c1.zw;   // n10 + tx (n11 - n10)
@@ -2813,31 +2752,9 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_
     typedef std::integral_constant<int, T64O3_EPITCH> EPitch;
     typedef std::integral_constant<int, T64O3> GRows;
     typedef std::integral_constant<int, T64O3_PITCH> GPitch;
-#ifdef LCS_O3CUB_PREFETCH
-    double dprev_x = 0.0, dprev_y = 0.0;  // previous level's Euler displacement in index space
-#endif
     for (int s = 0; s < A.nsteps; ++s) {
         // ---- 1. Euler sample out of a tile of img[t] centred on the patch's current position -------------------------
         const double c0x = (x - A.lon_min) * A.sx, c0y = (y - A.lat_min) * A.sy;
-#ifdef LCS_O3CUB_PREFETCH
-        // EXPERIMENT (EXTCUB): the iteration tile's loads of both levels issued HERE, anchored on the travel the PREVIOUS
-        // level's displacement predicts, so that they fly together with the Euler tile's (one exposed round trip per level)
-        int pox = 0, poy = 0;
-        d2 pst[T64O3 / 4], pnx[T64O3 / 4];
-        if (EXTCUB && K > 0) {
-            const double cax = c0x + dprev_x * (1.0 + kpred), cay = c0y + dprev_y * (1.0 + kpred);
-            const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);
-            const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
-            pox = min(max(rxm - (T64O3 - 4) / 2, 0), pad_cols - T64O3);
-            poy = min(max(rym - (T64O3 - 4) / 2, 0), pad_rows - T64O3);
-            const char *src = (const char *)lvl + ((size_t)poy * pad_cols + pox) * 16, *srcn = src + A.level_elems * sizeof(double);
-#pragma unroll
-            for (int r = 0; r < T64O3 / 4; ++r) {
-                __builtin_memcpy(&pst[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
-                __builtin_memcpy(&pnx[r], srcn + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
-            }
-        }
-#endif
         const int exm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(c0x, -4.0), 1.0e9)), CENTRE);
         const int eym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(c0y, -4.0), 1.0e9)), CENTRE);
         const int eox = min(max(exm - (T64O3 - 4) / 2, 0), pad_cols - T64O3), eoy = min(max(eym - (T64O3_EROWS - 4) / 2, 0), pad_rows - T64O3_EROWS);
@@ -2849,19 +2766,6 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_
         clamp_position<double>(A, x, y);                                // :89-97
         // ---- 2. tile of ext[t] anchored on the travel this level's Euler displacement predicts -----------------------
         int ox = 0, oy = 0;
-#ifdef LCS_O3CUB_PREFETCH
-        dprev_x = (x - x0p) * A.sx;
-        dprev_y = (y - y0p) * A.sy;
-        if (EXTCUB && K > 0) {
-            ox = pox;
-            oy = poy;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < T64O3 / 4; ++r)
-                gtile[(r * 4 + st_row) * T64O3_PITCH + st_col] = (d2){2.0 * pst[r].x - pnx[r].x, 2.0 * pst[r].y - pnx[r].y};
-            __builtin_amdgcn_wave_barrier();
-        } else
-#endif
         if (K > 0) {
             const double cax = c0x + (x - x0p) * A.sx * (1.0 + kpred), cay = c0y + (y - y0p) * A.sy * (1.0 + kpred);
             const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);

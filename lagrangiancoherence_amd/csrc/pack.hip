@@ -401,10 +401,7 @@ __global__ void __launch_bounds__(64) prefilter_rows_lds_kernel(T *__restrict__ 
 // 32 nodes ahead of the nodes being finished and only finished coefficients are written.  The last window of a line
 // starts from scipy's exact mirror formula at n-1 (bit-identical tail).  LCS_FIR_PREFILTER=0: the two-march kernels.
 // ======================================================================================
-#ifndef LCS_PS_C
-#define LCS_PS_C 16
-#endif
-constexpr int PS_C = LCS_PS_C, PS_H = 32, PS_W = PS_C + PS_H;  // latitude sweep: nodes finished per round, lookahead, register window
+constexpr int PS_C = 16, PS_H = 32, PS_W = PS_C + PS_H;  // latitude sweep: nodes finished per round, lookahead, register window
 
 __global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const double *__restrict__ u, const double *__restrict__ v,
                                                                     double *__restrict__ packed, int nt, int ny, int nx) {
@@ -495,10 +492,7 @@ __global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const double
 // values of chunks k and k+1; the lane starts the anticausal walk at the end of chunk k+1, walks chunk k+1 without
 // writing, finishes chunk k in place; the wave stores chunk k as whole 512-byte row segments, drops chunk k+2 (loaded
 // into registers before the walk, so its latency is behind it) into the freed half and runs the causal march over it.
-#ifndef LCS_RS_ROWS
-#define LCS_RS_ROWS 32
-#endif
-constexpr int RS_ROWS = LCS_RS_ROWS, RS_C = 32, RS_RING = 2 * RS_C;  // RS_ROWS < 32: the recursion runs on the first 2 RS_ROWS lanes, the copies on all 64
+constexpr int RS_ROWS = 32, RS_C = 32, RS_RING = 2 * RS_C;
 
 __global__ void __launch_bounds__(64) prefilter_rows_stream_kernel(double *__restrict__ packed, int ny, int nx) {
     __shared__ double ring[RS_ROWS][2 * RS_RING + 1];
@@ -508,8 +502,8 @@ __global__ void __launch_bounds__(64) prefilter_rows_stream_kernel(double *__res
     const int t = blockIdx.y;
     const int r0 = blockIdx.x * RS_ROWS;
     const int lane = threadIdx.x;
-    const int row = (lane >> 1) % RS_ROWS, comp = lane & 1;
-    const bool line_ok = lane < 2 * RS_ROWS && r0 + row < ny;
+    const int row = lane >> 1, comp = lane & 1;
+    const bool line_ok = r0 + row < ny;
     double *base = packed + (size_t)t * level + ((size_t)(r0 + LC_PAD_LO) * pitch + LC_PAD_LO) * 2;  // row r0, node 0
     const int nrows = min(RS_ROWS, ny - r0);
     double *mine = &ring[row][comp];  // node i of this lane's line: mine[2 * (i & 63)]
@@ -854,12 +848,13 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
         size_t lines = (size_t)nt * nx * 2;
         // float64: one read + one write per sweep (lines of 64 nodes or more; LCS_FIR_PREFILTER=0: the two-march kernels)
         const bool stream = sizeof(T) == 8 && ctx->fir_prefilter;
+        const bool cols_stream = stream && ny >= 64;
         if constexpr (sizeof(T) == 8) {
-            if (stream && ny >= 64)
+            if (cols_stream)
                 hipLaunchKernelGGL(prefilter_cols_stream_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, ctx->stream, u, v,
                                    packed, nt, ny, nx);
         }
-        if (!(stream && ny >= 64))
+        if (!cols_stream)
             hipLaunchKernelGGL(prefilter_cols_kernel<T>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
                                ctx->stream, u, v, packed, nt, ny, nx);
         if (stream && nx >= RS_RING) {

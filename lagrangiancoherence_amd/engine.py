@@ -227,9 +227,9 @@ class Engine:
     EXT_IMAGE_F64 = True
     # float64 at order 3 with fused levels: build the fused-level COEFFICIENT image ext = 2 cub[t] - cub[t+1] (True), or let
     # the kernels form it from cub node by node (False: the pack neither reads the coefficients back nor writes a second
-    # image, the advect kernel streams one image series instead of two).  Measured on BASELINE configs[1] at order 3
-    # (profiles/r05): see DESIGN.md section 4.
-    EXT_IMAGE_F64_O3 = False
+    # image: 4.56 -> 3.28 ms on BASELINE configs[1]; but the advect kernel then stages two levels per iteration tile and
+    # takes 8.22 ms instead of 6.31 -- the step loses 0.6 ms either way, serial and pipelined: profiles/r05/c2_o3_no_ext_image_ab.txt).
+    EXT_IMAGE_F64_O3 = True
 
     class _Concurrent:
         """Context manager for ``n`` advect calls running side by side on different streams: what fills the machine is
@@ -726,9 +726,13 @@ class Engine:
                 self._use_current_stream()
                 for t0 in starts:
                     n = min(chunk, nt - 1 - t0)         # image levels [t0, t0 + n], ext levels [t0, t0 + n)
+                    # Without the ext image the advect of chunk k itself reads level t0 + n (as the "next" level of its last
+                    # step), so chunk k+1 must NOT pack that level again behind its back (the sweeps work in place: a reader
+                    # would see half-filtered values): each level is packed once, by the chunk that first needs it.
+                    l0 = t0 + 1 if (no_ext and t0 > 0) else t0
                     _capi.check(self.lib.lc_field_pack(
-                        self.ctx, C.c_void_p(ud[t0:].data_ptr()), C.c_void_p(vd[t0:].data_ptr()), _NP2LC[dtype], n + 1, ny_f, nx_f,
-                        int(interp_order), C.c_void_p(cub[le * t0:].data_ptr()) if cub is not None else None,
+                        self.ctx, C.c_void_p(ud[l0:].data_ptr()), C.c_void_p(vd[l0:].data_ptr()), _NP2LC[dtype], t0 + n + 1 - l0, ny_f, nx_f,
+                        int(interp_order), C.c_void_p(cub[le * l0:].data_ptr()) if cub is not None else None,
                         C.c_void_p(ext[le * t0:].data_ptr()) if ext is not None else None), self.lib)
                     e = torch.cuda.Event()
                     e.record(side)

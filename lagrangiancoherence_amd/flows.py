@@ -100,17 +100,8 @@ def config2_on_device(torch, device, n=1024, nt=201):
     return u.contiguous(), v.contiguous(), lats, lons
 
 
-def era5_like(nt=97, ny=720, nx=1440, seed=20260355, dtype=np.float32,
-              dt_seconds=900.0, n_modes=12):
-    """Configs 3-5: smooth synthetic global flow on a 0.25 degree grid.
-
-    u = 25 cos^2(phi) + sum_m A_m cos(phi) sin(k_m lam + w_m t + a_m) cos(l_m phi)
-    v =                 sum_m B_m cos(phi) cos(k_m lam + w_m t + b_m) sin(l_m phi)
-
-    evaluated through the angle-sum identity so the cost is 2*n_modes rank-1
-    updates per component.  ``rng = default_rng(seed)`` draws, in this order:
-    k, l, A, B, omega, alpha, beta.
-    """
+def _era5_like_terms(nt, ny, nx, seed, dt_seconds, n_modes):
+    """The separable factors of :func:`era5_like`: u[n] = base[:, None] + Pu.T @ lu[n], v[n] = Pv.T @ lv[n]."""
     lats = -90.0 + 180.0 / ny / 2 + (180.0 / ny) * np.arange(ny)   # -89.875 ... 89.875
     lons = -180.0 + (360.0 / nx) * np.arange(nx)                    # -180 ... 179.75
     rng = np.random.default_rng(seed)
@@ -133,15 +124,50 @@ def era5_like(nt=97, ny=720, nx=1440, seed=20260355, dtype=np.float32,
     cu = np.cos(km[:, None] * lam[None, :] + al[:, None])
     sv = np.sin(km[:, None] * lam[None, :] + be[:, None])
     cv = np.cos(km[:, None] * lam[None, :] + be[:, None])
+    return lats, lons, 25.0 * cphi ** 2, Pu, Pv, ct, st, su, cu, sv, cv
+
+
+def era5_like(nt=97, ny=720, nx=1440, seed=20260355, dtype=np.float32,
+              dt_seconds=900.0, n_modes=12):
+    """Configs 3-5: smooth synthetic global flow on a 0.25 degree grid.
+
+    u = 25 cos^2(phi) + sum_m A_m cos(phi) sin(k_m lam + w_m t + a_m) cos(l_m phi)
+    v =                 sum_m B_m cos(phi) cos(k_m lam + w_m t + b_m) sin(l_m phi)
+
+    evaluated through the angle-sum identity so the cost is 2*n_modes rank-1
+    updates per component.  ``rng = default_rng(seed)`` draws, in this order:
+    k, l, A, B, omega, alpha, beta.  A shorter series is a prefix of a longer one.
+    """
+    lats, lons, base, Pu, Pv, ct, st, su, cu, sv, cv = _era5_like_terms(nt, ny, nx, seed, dt_seconds, n_modes)
     u = np.empty((nt, ny, nx), dtype=dtype)
     v = np.empty((nt, ny, nx), dtype=dtype)
-    base = 25.0 * cphi ** 2
     for n in range(nt):
         # sin(x + wt) = sin x cos wt + cos x sin wt ; cos(x + wt) = cos x cos wt - sin x sin wt
         lu = su * ct[:, n:n + 1] + cu * st[:, n:n + 1]                     # (m, nx)
         lv = cv * ct[:, n:n + 1] - sv * st[:, n:n + 1]
         u[n] = (base[:, None] + Pu.T @ lu).astype(dtype)
         v[n] = (Pv.T @ lv).astype(dtype)
+    return u, v, lats.astype(dtype), lons.astype(dtype)
+
+
+def era5_like_on_device(torch, device, nt=97, ny=720, nx=1440, seed=20260355, dtype=np.float32, dt_seconds=900.0, n_modes=12):
+    """:func:`era5_like` evaluated with torch on ``device``: the same factors (computed on the host in float64), the
+    ``nt`` rank-12 products on the device in float64, cast to ``dtype``.  The device's matrix product sums in another
+    order than the host BLAS, so a value may differ from :func:`era5_like` in the last float32 bit -- for benchmarks of
+    the long series (385 levels take 25 s of host time, milliseconds here), not for parity tests.  Returns device tensors
+    ``u, v`` of shape ``(nt, ny, nx)`` and the numpy coordinates."""
+    lats, lons, base, Pu, Pv, ct, st, su, cu, sv, cv = _era5_like_terms(nt, ny, nx, seed, dt_seconds, n_modes)
+    f64 = torch.float64
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=f64, device=device)
+    base, PuT, PvT, ct, st, su, cu, sv, cv = T(base), T(Pu.T), T(Pv.T), T(ct), T(st), T(su), T(cu), T(sv), T(cv)
+    out_dtype = getattr(torch, np.dtype(dtype).name)
+    u = torch.empty((nt, ny, nx), dtype=out_dtype, device=device)
+    v = torch.empty((nt, ny, nx), dtype=out_dtype, device=device)
+    for n in range(nt):
+        lu = su * ct[:, n:n + 1] + cu * st[:, n:n + 1]
+        lv = cv * ct[:, n:n + 1] - sv * st[:, n:n + 1]
+        u[n] = (base[:, None] + PuT @ lu).to(out_dtype)
+        v[n] = (PvT @ lv).to(out_dtype)
     return u, v, lats.astype(dtype), lons.astype(dtype)
 
 

@@ -119,7 +119,7 @@ def test_config2_order3_full_size_subset_vs_oracle(eng):
     u, v, lat, lon = flows.config2(nt=13)
     f = eng.prepare_field(u, v, lat, lon, 3)
     x, y = eng.advect(f, lat, lon, -900.0, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
-    assert eng.last_advect_kernel() == "advect_lds64_o3_kernel<4, true, cub>", eng.last_advect_kernel()   # (no ext image since round 5)
+    assert eng.last_advect_kernel() == "advect_lds64_o3_kernel<4, true>", eng.last_advect_kernel()
     rows, cols = _subset(1024, 24, 3), _subset(1024, 24, 0)
     xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=3,
                                     cyclic_xboundary=True, seed_lat=lat[rows], seed_lon=lon[cols])

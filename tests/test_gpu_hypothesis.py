@@ -181,9 +181,9 @@ def test_float64_cubic_prefilter_matches_scipy_at_any_size(ny, nx, nt, seed, sca
     v = rng.standard_normal((nt, ny, nx)) * scale
     lat = np.linspace(-80.0, 80.0, ny)
     lon = np.linspace(-180.0, 179.0, nx)
-    f = eng.prepare_field(u, v, lat, lon, 3, ext_image=True)
+    f = eng.prepare_field(u, v, lat, lon, 3)
     img = f.cub.cpu().numpy().reshape(nt, ny + 3, nx + 3, 2)
-    assert np.array_equal(eng.prepare_field(u, v, lat, lon, 3).cub.cpu().numpy().reshape(img.shape), img)   # (the default: no ext image, pads_only_kernel)
+    assert np.array_equal(eng.prepare_field(u, v, lat, lon, 3, ext_image=False).cub.cpu().numpy().reshape(img.shape), img)   # (no ext image: pads_only_kernel)
     tol = 2e-14 * scale * 6.0
     for t in range(nt):
         for c, w in ((0, u), (1, v)):

@@ -2,7 +2,8 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lagrangiancoherence_amd import flows
 from lagrangiancoherence_amd.engine import Engine
 
@@ -13,14 +14,14 @@ if which == "c3":
     u, v, lat, lon = flows.era5_like(nt=97)
     dt = np.float32
 else:
-    u, v, lat, lon = flows.config2()
+    u, v, lat, lon = flows.config2_on_device(torch, eng.device)   # (the host generator takes a minute)
     dt = np.float64
 ud, vd = eng.to_device(u, dt), eng.to_device(v, dt)
 for _ in range(3):
     f = eng.prepare_field(ud, vd, lat, lon, order)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-n = 20
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 e0.record()
 for _ in range(n):
     f = eng.prepare_field(ud, vd, lat, lon, order)
