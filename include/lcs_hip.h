@@ -38,7 +38,7 @@ extern "C" {
  * client built against 100 must be rebuilt), lc_ctx_get_level_chunk, lc_ctx_set/get_f64_fidelity, lc_advect_ex and
  * lc_sample_raw added, lc_field_pack accepts packed_dev == NULL at order 1 (fused-level image only).  lc_version() returns the value the LIBRARY
  * was built with: compare it with this macro before any other call (tests/c/abi_smoke.c, _capi.load do). */
-#define LC_VERSION 102 /* 0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify */
+#define LC_VERSION 102 /* 0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify, LC_F64_WIND_F32_LIN32 */
 
 typedef struct lc_ctx lc_ctx;
 
@@ -48,7 +48,12 @@ enum lc_dtype {
     /* lc_advect only: float64 positions and images whose wind values are float32-valued; the
      * arithmetic follows numpy's promotion for that mix in the reference (samples rounded to float,
      * latitude increments formed in float; LCS/trajectory.py:86-87,110-112 with SURVEY Q10). */
-    LC_F64_WIND_F32 = 2
+    LC_F64_WIND_F32 = 2,
+    /* lc_advect_ex only, interp_order 1, cyclic or per-point boundaries: the same arithmetic with the wind KEPT float32 --
+     * packed_lin is the order-1 image lc_field_pack builds for LC_F32 (half the bytes, no float64 copy of the wind), every
+     * other image pointer NULL; positions, seeds and outputs are float64.  Results equal LC_F64_WIND_F32's bit for bit
+     * (a node is widened as it is read: the same doubles enter the same sums); per-wave LDS tiles of levels t and t + 1. */
+    LC_F64_WIND_F32_LIN32 = 3
 };
 
 enum lc_status {

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblcs_hip.so")
 
 LC_VERSION = 102     # include/lcs_hip.h: the ABI these prototypes describe (checked against lc_version() in load())
-LC_F32, LC_F64, LC_F64_WIND_F32 = 0, 1, 2
+LC_F32, LC_F64, LC_F64_WIND_F32, LC_F64_WIND_F32_LIN32 = 0, 1, 2, 3
 LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM, LC_ERCCL = 0, -1, -2, -3, -4, -5
 LC_LAYOUT_REFERENCE, LC_LAYOUT_PHYSICAL = 0, 1
 LC_X_CLAMP_POINT, LC_X_CYCLIC, LC_X_CLAMP_REFERENCE_OUTER = 0, 1, 2

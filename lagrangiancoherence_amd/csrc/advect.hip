@@ -45,6 +45,7 @@ struct AdvectArgs {
     // the pole seed rows' order-1 / 'constant' samples (Q3), and in float64 at order 1 the Euler sample (img == lin is then
     // not read at all).  Same node values, same arithmetic, bit-identical results -- the image the pack no longer writes.
     const T *u_raw, *v_raw;
+    const float *lin32;  // LC_F64_WIND_F32_LIN32 (double instantiation, order 1): the order-1 image of the float32 wind AS float32; lin / img / raw planes unused
     size_t raw_plane;  // ny_f * nx_f
     int ext_raw;       // float64, order 1, raw planes: the fused-level value 2 F[t] - F[t+1] is formed from the planes node by node
                        // (lc_advect_args.fuse_levels_raw): no packed image at all, ext == NULL
@@ -340,6 +341,27 @@ __device__ __forceinline__ void raw_window(const T *__restrict__ up, const T *__
     b[3] = vp[r1 + x1];
 }
 
+// The order-1 sample of a window {u00, v00, u01, v01}, {u10, v10, u11, v11} in scipy's operation order (tap order: last axis
+// fastest; per tap ((value*wy)*wx), summed from 0).  ONE function for every source of the eight numbers -- packed image, raw
+// planes, the float32 image of LC_F64_WIND_F32_LIN32, an LDS tile of it -- so a seed's bits do not depend on which served it.
+template <typename T>
+__device__ __forceinline__ Pair<T> tap_sum_order1(const T (&a)[4], const T (&b)[4], const Tap<T> &t) {
+#pragma clang fp contract(off)
+    T su = T(0), sv = T(0);
+    su += (a[0] * t.wy[0]) * t.wx[0];
+    sv += (a[1] * t.wy[0]) * t.wx[0];
+    su += (a[2] * t.wy[0]) * t.wx[1];
+    sv += (a[3] * t.wy[0]) * t.wx[1];
+    su += (b[0] * t.wy[1]) * t.wx[0];
+    sv += (b[1] * t.wy[1]) * t.wx[0];
+    su += (b[2] * t.wy[1]) * t.wx[1];
+    sv += (b[3] * t.wy[1]) * t.wx[1];
+    Pair<T> r;
+    r.u = su;
+    r.v = sv;
+    return r;
+}
+
 // RAW (order 1 only): `lvl` is the level's raw u plane, the v plane lies A.v_raw - A.u_raw elements on
 template <typename T, int ORDER, bool RAW = false>
 __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const AdvectArgs<T> &A, const Tap<T> &t) {
@@ -384,19 +406,7 @@ __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const Advect
         r.v = fma(t.ty, v1 - v0, v0);
         return r;
     }
-    // scipy tap order (last axis fastest); per tap ((value*wy)*wx), summed from 0
-    T su = T(0), sv = T(0);
-    su += (a[0] * t.wy[0]) * t.wx[0];
-    sv += (a[1] * t.wy[0]) * t.wx[0];
-    su += (a[2] * t.wy[0]) * t.wx[1];
-    sv += (a[3] * t.wy[0]) * t.wx[1];
-    su += (b[0] * t.wy[1]) * t.wx[0];
-    sv += (b[1] * t.wy[1]) * t.wx[0];
-    su += (b[2] * t.wy[1]) * t.wx[1];
-    sv += (b[3] * t.wy[1]) * t.wx[1];
-    r.u = su;
-    r.v = sv;
-    return r;
+    return tap_sum_order1<T>(a, b, t);
 }
 
 template <typename T, int ORDER, bool WRAP, bool RAW = false>
@@ -551,6 +561,230 @@ __device__ __forceinline__ bool pole_block(const AdvectArgs<T> &A) {
         pole_seed<T, SRC>(A, iy, ix);
     }
     return true;
+}
+
+// ======================================================================================
+// LC_F64_WIND_F32_LIN32 -- float32 wind on float64 coordinates with the wind KEPT float32 (order 1).
+//
+// The reference's behaviour for this mix (float32 reanalysis winds on float64 lat / lon; numpy's promotion through
+// LCS/trajectory.py:86-87,110-112): scipy interpolates the float32 field in double and returns float32
+// samples, the SETTLS bracket and the latitude increments are formed in float32, the longitude increments in float64.
+// LC_F64_WIND_F32 does that on float64 IMAGES of the float32 values (twice the bytes, and a conversion pass before any
+// advection); here the image stays float32 -- lc_field_pack(LC_F32, order 1) -- and a node is widened as it is read:
+// the same eight doubles enter tap_sum_order1, so the results are those of LC_F64_WIND_F32 bit for bit.  Two samples per
+// iteration (the bracket's float32 roundings do not commute with a fused level), numpy's exact index map (locate<double>).
+// ======================================================================================
+typedef float w4 __attribute__((ext_vector_type(4)));
+typedef float w2 __attribute__((ext_vector_type(2)));
+
+// the window of cell (t.sy, t.sx) from one level of the float32 image (padded (row + 1, column + 1): pads hold the mirror)
+__device__ __forceinline__ void window_w32(const float *__restrict__ lvl, const AdvectArgs<double> &A, const Tap<double> &t,
+                                           double (&a)[4], double (&b)[4]) {
+    const float *p = lvl + ((size_t)(t.sy + LC_PAD_LO) * A.pitch + (t.sx + LC_PAD_LO)) * 2;
+    w4 r0, r1;
+    __builtin_memcpy(&r0, p, 16);                          // {u00, v00, u01, v01}
+    __builtin_memcpy(&r1, p + (size_t)A.pitch * 2, 16);    // {u10, v10, u11, v11}
+    a[0] = r0.x, a[1] = r0.y, a[2] = r0.z, a[3] = r0.w;
+    b[0] = r1.x, b[1] = r1.y, b[2] = r1.z, b[3] = r1.w;
+}
+// one sample, rounded to float32 as map_coordinates returns it (Q10)
+template <bool WRAP>
+__device__ __forceinline__ Pair<double> sample_w32(const float *__restrict__ lvl, const AdvectArgs<double> &A, const Tap<double> &t) {
+    Pair<double> r;
+    if (!WRAP && t.zero) {
+        r.u = r.v = 0.0;
+        return r;
+    }
+    double a[4], b[4];
+    window_w32(lvl, A, t, a, b);
+    r = tap_sum_order1<double>(a, b, t);
+    r.u = (double)(float)r.u;
+    r.v = (double)(float)r.v;
+    return r;
+}
+
+// trajectory.py:80-126 for one seed, every sample a global gather: the pole rows (WRAP = false: order 1 + 'constant', Q3),
+// the direct kernel, and what the LDS kernel below must equal.  advect_seed<double, 1, WRAP>'s statements with A.wind_f32.
+template <bool WRAP>
+__device__ void advect_seed_w32(const AdvectArgs<double> &A, int iy, int ix) {
+#pragma clang fp contract(off)
+    typedef double T;
+    T x = start_x<T>(A, iy, ix), y = start_y<T>(A, iy, ix);
+    const T ys = A.seed_lat[iy];
+    const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((ys * T(3.141592653589793)) / T(180))));  // Q5
+    const T dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
+    const size_t idx = (size_t)iy * A.nx + ix, plane = (size_t)A.ny * A.nx;
+    if (A.traj_x && !A.traj_skip0) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const float *lvl = A.lin32 + (size_t)A.t0 * A.level_elems;
+    for (int s = 0; s < A.nsteps; ++s) {
+        const float *nxt = lvl + A.level_elems;
+        const Pair<T> e = sample_w32<WRAP>(lvl, A, locate<T, 1, WRAP>(A, x, y));     // trajectory.py:82-84
+        y = y + lat_increment<T>(A, A.dtcy, e.v);                                     // :86
+        x = axpy<T>(dtcx, e.u, x);                                                    // :87
+        clamp_position<T>(A, x, y);
+        for (int k = 0; k < A.K; ++k) {                                               // :100
+            const Tap<T> tap = locate<T, 1, WRAP>(A, x, y);                           // one position, two time levels
+            const Pair<T> c = sample_w32<WRAP>(lvl, A, tap), n = sample_w32<WRAP>(nxt, A, tap);   // :105-108
+            y = y + lat_increment<T>(A, A.hdtcy, settls_bracket<T>(A, e.v, c.v, n.v));           // :110
+            x = axpy<T>(hdtcx, settls_bracket<T>(A, e.u, c.u, n.u), x);                          // :112
+            clamp_position<T>(A, x, y);
+        }
+        if (A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl = nxt;
+    }
+    A.x_out[idx] = x;
+    A.y_out[idx] = y;
+}
+
+__device__ __forceinline__ bool pole_block_w32(const AdvectArgs<double> &A) {   // pole_block with the float32 image as the source
+    if ((int)blockIdx.x >= A.pole_blocks) return false;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < (A.pole_lo + A.pole_hi) * A.nx) {
+        const int k = i / A.nx, ix = i - k * A.nx;
+        advect_seed_w32<false>(A, lcplan::pole_row(k, A.pole_lo, A.pole_hi, A.ny), ix);
+    }
+    return true;
+}
+
+// direct kernel: fields smaller than a tile, SETTLS_order = 0, lc_ctx_set_lds_tiles(0)
+__global__ void __launch_bounds__(BLOCK) advect_w32_kernel(const AdvectArgs<double> A0) {
+    const AdvectArgs<double> A = for_member(A0);
+    if (pole_block_w32(A)) return;
+    const int tile = xcd_tile_id(A);
+    if (tile >= A.ntiles) return;
+    const int tyi = tile / A.ntx, txi = tile - tyi * A.ntx;
+    const int ix = txi * TILE_W + (threadIdx.x % TILE_W), iy = tyi * TILE_H + (threadIdx.x / TILE_W);
+    if (ix >= A.nx || iy >= A.ny) return;
+    const int grow = A.row0 + iy;
+    if (grow < A.order || grow >= A.ny_global - A.order) {  // tools.py:24-33 (Q3)
+        if (!A.pole_blocks) advect_seed_w32<false>(A, iy, ix);
+    } else
+        advect_seed_w32<true>(A, iy, ix);
+}
+
+// Per-wave LDS tiles (advect_lds64_kernel's scheme): each wave stages a 16 x 12-node tile of levels t AND t + 1 (float32
+// nodes of 8 bytes: 1.5 KB each) around the travel the previous level's displacement predicts, and the K iterations take
+// both samples of a position out of LDS; a window that left the tile reads global memory.  Euler sample: direct gather.
+constexpr int TW_COLS = 16, TW_ROWS = 12, TW_PITCH = 17;
+template <int KFIX, bool CYCLIC>
+__global__ void __launch_bounds__(BLOCK) advect_lds64w_kernel(const AdvectArgs<double> A0) {
+#pragma clang fp contract(off)
+    typedef double T;
+    const AdvectArgs<double> A = for_member(A0);
+    const int K = KFIX >= 0 ? KFIX : A.K;
+    __shared__ __attribute__((aligned(16))) w2 s_tiles[BLOCK / 64][2][TW_ROWS * TW_PITCH];
+    if (pole_block_w32(A)) return;
+    const int tile_id = xcd_tile_id(A);
+    if (tile_id >= A.ntiles) return;  // whole block
+    const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
+    const int ix = txi * TILE_W + (threadIdx.x % TILE_W), iy = tyi * TILE_H + (threadIdx.x / TILE_W);
+    const int lane = threadIdx.x & 63;
+    w2 *tile0 = s_tiles[threadIdx.x >> 6][0], *tile1 = s_tiles[threadIdx.x >> 6][1];
+    bool live = ix < A.nx && iy < A.ny;
+    if (live) {
+        const int grow = A.row0 + iy;
+        if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path (Q3)
+            if (!A.pole_blocks) advect_seed_w32<false>(A, iy, ix);
+            live = false;
+        }
+    }
+    if (__ballot(live) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
+    const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);  // lanes without a seed shadow a neighbour; stores masked
+    T x = start_x<T>(A, sy_i, sx_i), y = start_y<T>(A, sy_i, sx_i);
+    const T ys = A.seed_lat[sy_i];
+    const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((ys * T(3.141592653589793)) / T(180))));  // Q5
+    const T dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
+    const size_t idx = live ? (size_t)iy * A.nx + ix : 0, plane = (size_t)A.ny * A.nx;
+    if (live && A.traj_x && !A.traj_skip0) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const float *lvl = A.lin32 + (size_t)A.t0 * A.level_elems;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    constexpr int CENTRE = TILE_W / 2 + TILE_W * 4;  // middle seed of the wave's 8 x 8 patch
+    const int st_row = lane >> 4, st_col = lane & 15;  // staging: one node (8 bytes) per lane and level, 4 rows per pass, 3 passes
+    const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 8u;
+    double dprev_x = 0.0, dprev_y = 0.0;  // previous level's Euler displacement in index space: predicts this level's travel
+    const double kpred = 0.5 * (double)(K > 0 ? K - 1 : 0);
+    for (int s = 0; s < A.nsteps; ++s) {
+        const float *nxt = lvl + A.level_elems;
+        // ---- 1. anchor the tiles on the centre lane's predicted travel, issue their loads ----------------------------
+        int ox = 0, oy = 0;
+        w2 st0[TW_ROWS / 4], st1[TW_ROWS / 4];
+        if (K > 0) {
+            const double cax = (x - A.lon_min) * A.sx + dprev_x * (1.0 + kpred), cay = (y - A.lat_min) * A.sy + dprev_y * (1.0 + kpred);
+            const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);
+            const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
+            ox = min(max(rxm + LC_PAD_LO - (TW_COLS - 2) / 2, 0), pad_cols - TW_COLS);
+            oy = min(max(rym + LC_PAD_LO - (TW_ROWS - 2) / 2, 0), pad_rows - TW_ROWS);
+            const char *src = (const char *)lvl + ((size_t)oy * pad_cols + ox) * 8, *srcn = src + A.level_elems * sizeof(float);
+#pragma unroll
+            for (int r = 0; r < TW_ROWS / 4; ++r) {
+                __builtin_memcpy(&st0[r], src + (size_t)(r * 4) * pad_cols * 8 + st_off, 8);
+                __builtin_memcpy(&st1[r], srcn + (size_t)(r * 4) * pad_cols * 8 + st_off, 8);
+            }
+        }
+        // ---- 2. Euler sample: direct gather from level t ------------------------------------------------------------------
+        const double x0p = x, y0p = y;
+        const Pair<T> e = sample_w32<true>(lvl, A, locate<T, 1, true>(A, x, y));   // trajectory.py:82-84
+        y = y + lat_increment<T>(A, A.dtcy, e.v);                                   // :86
+        x = axpy<T>(dtcx, e.u, x);                                                  // :87
+        clamp_position<T>(A, x, y);
+        dprev_x = (x - x0p) * A.sx;
+        dprev_y = (y - y0p) * A.sy;
+        // ---- 3. tiles into LDS ----------------------------------------------------------------------------------------------
+        if (K > 0) {
+            __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
+#pragma unroll
+            for (int r = 0; r < TW_ROWS / 4; ++r) {
+                tile0[(r * 4 + st_row) * TW_PITCH + st_col] = st0[r];
+                tile1[(r * 4 + st_row) * TW_PITCH + st_col] = st1[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- 4. K iterations, both levels' windows out of LDS -------------------------------------------------------------
+        for (int k = 0; k < K; ++k) {
+            const Tap<T> tap = locate<T, 1, true>(A, x, y);
+            const int rx = tap.sx + LC_PAD_LO - ox, ry = tap.sy + LC_PAD_LO - oy;   // window origin inside the tile (padded coordinates)
+            Pair<T> c, n;
+            if ((unsigned)rx <= (unsigned)(TW_COLS - 2) && (unsigned)ry <= (unsigned)(TW_ROWS - 2)) {
+                double a[4], b[4];
+                const w2 *w = tile0 + ry * TW_PITCH + rx;
+                w2 n00 = w[0], n01 = w[1], n10 = w[TW_PITCH], n11 = w[TW_PITCH + 1];
+                a[0] = n00.x, a[1] = n00.y, a[2] = n01.x, a[3] = n01.y;
+                b[0] = n10.x, b[1] = n10.y, b[2] = n11.x, b[3] = n11.y;
+                c = tap_sum_order1<T>(a, b, tap);
+                w = tile1 + ry * TW_PITCH + rx;
+                n00 = w[0], n01 = w[1], n10 = w[TW_PITCH], n11 = w[TW_PITCH + 1];
+                a[0] = n00.x, a[1] = n00.y, a[2] = n01.x, a[3] = n01.y;
+                b[0] = n10.x, b[1] = n10.y, b[2] = n11.x, b[3] = n11.y;
+                n = tap_sum_order1<T>(a, b, tap);
+                c.u = (double)(float)c.u, c.v = (double)(float)c.v;   // map_coordinates returns the field's dtype (Q10)
+                n.u = (double)(float)n.u, n.v = (double)(float)n.v;
+            } else {  // the window left the tile: the same nodes from global memory
+                c = sample_w32<true>(lvl, A, tap);
+                n = sample_w32<true>(nxt, A, tap);
+            }
+            y = y + lat_increment<T>(A, A.hdtcy, settls_bracket<T>(A, e.v, c.v, n.v));   // :110
+            x = axpy<T>(hdtcx, settls_bracket<T>(A, e.u, c.u, n.u), x);                  // :112
+            clamp_position<T>(A, x, y);
+        }
+        if (live && A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl = nxt;
+    }
+    if (live) {
+        A.x_out[idx] = x;
+        A.y_out[idx] = y;
+    }
 }
 
 // Member groups (PATCH_PAIR): the arguments of member q of this workgroup's group for the launch's level window
@@ -2473,7 +2707,10 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
 #ifndef LCS_LDS64_NUM_SGPR
 #define LCS_LDS64_NUM_SGPR 0
 #endif
-constexpr int T64_COLS = 16, T64_ROWS = LCS_T64_ROWS, T64_PITCH = 17;  // nodes; rows shift 4 banks of 16 bytes
+#ifndef LCS_T64_PITCH
+#define LCS_T64_PITCH 17
+#endif
+constexpr int T64_COLS = 16, T64_ROWS = LCS_T64_ROWS, T64_PITCH = LCS_T64_PITCH;  // nodes
 // RAW: the Euler sample (and the pole rows) from the raw planes of the level instead of the lin image (lc_advect_ex) -- a
 // compile-time variant: as a run-time choice the extra uniform state cost the kernel 9 vector registers and a wave per SIMD.
 // SRC = SRC_RAW_ALL: the tile of ext[t] itself is formed while it is staged -- each lane loads its nodes of levels t and
@@ -3170,7 +3407,8 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 double lat_min, double lat_max, double lon_min, double lon_max, const void *seed_lat, int ny,
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
                 int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, const void *x_start,
-                const void *y_start, int wind_f32 = 0, int n_members = 1, int t0_stride = 0, int fuse_levels_raw = 0) {
+                const void *y_start, int wind_f32 = 0, int n_members = 1, int t0_stride = 0, int fuse_levels_raw = 0,
+                const void *lin32 = nullptr) {
     AdvectArgs<T> A{};
     A.wind_f32 = wind_f32;
     A.n_members = n_members;
@@ -3188,6 +3426,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.lin = (const T *)packed_lin;
     A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
     A.ext = (order == 1 || order == 3) ? (const T *)packed_ext : nullptr;  // general orders: two-sample form
+    A.lin32 = sizeof(T) == 8 ? (const float *)lin32 : nullptr;  // LC_F64_WIND_F32_LIN32: the float32 order-1 image (then lin == img == NULL)
     A.u_raw = (const T *)u_raw;  // (lc_advect_ex validated: only where a kernel reads them)
     A.v_raw = (const T *)v_raw;
     A.raw_plane = (size_t)ny_f * nx_f;
@@ -3262,6 +3501,25 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     const bool fused64 = sizeof(T) == 8 && (A.ext != nullptr || A.ext_raw || A.ext_cub);  // single-sample iterations in float64
     const char *name = nullptr;
     auto launch = [&](const AdvectArgs<T> &A) {
+        if constexpr (sizeof(T) == 8) {
+            if (A.lin32) {  // LC_F64_WIND_F32_LIN32: per-wave LDS tiles of levels t and t + 1, or direct gathers
+                const bool tiles = use_lds && A.K > 0 && A.nx_f + LC_PAD >= TW_COLS && A.ny_f + LC_PAD >= TW_ROWS;
+#define LC_W32(KF, CY, NAME)                                                                                       \
+    {                                                                                                              \
+        hipLaunchKernelGGL((advect_lds64w_kernel<KF, CY>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);   \
+        name = NAME;                                                                                               \
+        return;                                                                                                    \
+    }
+                if (tiles && A.K == 4 && A.cyclic) LC_W32(4, true, "advect_lds64w_kernel<4, true>")
+                if (tiles && A.K == 4) LC_W32(4, false, "advect_lds64w_kernel<4, false>")
+                if (tiles && A.cyclic) LC_W32(-1, true, "advect_lds64w_kernel<-1, true>")
+                if (tiles) LC_W32(-1, false, "advect_lds64w_kernel<-1, false>")
+#undef LC_W32
+                hipLaunchKernelGGL(advect_w32_kernel, dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
+                name = "advect_w32_kernel";
+                return;
+            }
+        }
         if (order == 2 || order == 4 || order == 5) {  // generic direct kernel, any dtype
             name = order == 2 ? DirectLaunch<T, 2>::launch(A, grid, ctx->stream)
                  : order == 4 ? DirectLaunch<T, 4>::launch(A, grid, ctx->stream) : DirectLaunch<T, 5>::launch(A, grid, ctx->stream);
@@ -3636,8 +3894,16 @@ extern "C" int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args) {
                      "and cannot continue from given positions");
         return LC_EUNSUPPORTED;
     }
-    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64 || dtype == LC_F64_WIND_F32, "lc_advect: bad dtype %d", dtype);
-    LC_REQUIRE(dtype != LC_F64_WIND_F32 || !packed_ext, "lc_advect: LC_F64_WIND_F32 keeps the two-sample form (no ext)");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64 || dtype == LC_F64_WIND_F32 || dtype == LC_F64_WIND_F32_LIN32, "lc_advect: bad dtype %d", dtype);
+    LC_REQUIRE((dtype != LC_F64_WIND_F32 && dtype != LC_F64_WIND_F32_LIN32) || !packed_ext, "lc_advect: LC_F64_WIND_F32 keeps the two-sample form (no ext)");
+    if (dtype == LC_F64_WIND_F32_LIN32) {
+        LC_REQUIRE(packed_lin && !packed_cub && !u_raw && !v_raw, "lc_advect: LC_F64_WIND_F32_LIN32 takes packed_lin (the float32 order-1 image) and nothing else");
+        if (interp_order != 1 || cyclic_x == LC_X_CLAMP_REFERENCE_OUTER) {
+            lc_set_error("lc_advect: LC_F64_WIND_F32_LIN32 is the order-1 form with cyclic / per-point boundaries; interp_order %d or "
+                         "LC_X_CLAMP_REFERENCE_OUTER take LC_F64_WIND_F32 (float64 images of the float32 wind)", interp_order);
+            return LC_EUNSUPPORTED;
+        }
+    }
     if (interp_order < 1 || interp_order > 5) {
         lc_set_error("lc_advect: interp_order %d unsupported (scipy's spline orders 1..5; 0 fails in the reference too)",
                      interp_order);
@@ -3668,7 +3934,7 @@ extern "C" int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args) {
     LC_REQUIRE((traj_x == nullptr) == (traj_y == nullptr), "lc_advect: traj_x and traj_y must both be set or both NULL");
     LC_REQUIRE(lat_max > lat_min && lon_max > lon_min, "lc_advect: field coordinates must be ascending");
     // the kernels address a tap inside one time level with 32-bit offsets (24-bit row multiply)
-    if (lc_level_elems(ny_f, nx_f) * (dtype == LC_F32 ? 4 : 1) >= (size_t)1 << 32 || nx_f + LC_PAD >= (1 << 24) ||
+    if (lc_level_elems(ny_f, nx_f) * ((dtype == LC_F32 || dtype == LC_F64_WIND_F32_LIN32) ? 4 : 1) >= (size_t)1 << 32 || nx_f + LC_PAD >= (1 << 24) ||
         ny_f + LC_PAD >= (1 << 24)) {
         lc_set_error("lc_advect: a %dx%d time level is too large for 32-bit tap offsets", ny_f, nx_f);
         return LC_EUNSUPPORTED;
@@ -3679,6 +3945,11 @@ extern "C" int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args) {
                                   lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                   interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start, 0,
                                   n_members, t0_stride, 0);
+    if (dtype == LC_F64_WIND_F32_LIN32)
+        return advect_impl<double>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
+                                   lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
+                                   interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start,
+                                   1, n_members, t0_stride, 0, packed_lin);
     return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, u_raw, v_raw, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
                                lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start,

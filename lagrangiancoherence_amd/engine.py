@@ -74,6 +74,9 @@ class PackedField:
     v: "torch.Tensor | None" = None  # (lc_advect_ex: pole rows at any order, the Euler sample in float64) -- not copies: do not
     #                                  modify them in place while the field is in use (Engine._ensure_lin refuses if you did)
     planes_version: "tuple | None" = None  # (u._version, v._version) when the field was prepared
+    lin32: "torch.Tensor | None" = None    # wind_f32 at order 1: the order-1 image of the float32 wind AS float32 (LC_F64_WIND_F32_LIN32)
+    u32: "torch.Tensor | None" = None      # wind_f32: the float32 planes as given (the float64 copies u, v are made when a call needs them)
+    v32: "torch.Tensor | None" = None
 
 
 class Engine:
@@ -322,10 +325,22 @@ class Engine:
             raise ValueError("coordinate lengths do not match the field")
         if not (np.all(np.diff(lat_f) > 0) and np.all(np.diff(lon_f) > 0)):
             raise ValueError("latitude and longitude must be ascending (sort first)")
-        ud = self.to_device(u, dtype)
-        vd = self.to_device(v, dtype)
         n = self.lib.lc_packed_elems(nt, ny_f, nx_f)
         self._use_current_stream()
+        if wind_f32 and interp_order == 1 and lin_image is None:
+            # float32 wind on float64 coordinates at order 1: the wind stays float32 -- its order-1 image as lc_field_pack builds
+            # it for float32 fields, widened node by node inside the kernels (LC_F64_WIND_F32_LIN32: the bits of the float64
+            # images, half the bytes, no conversion pass; LCS/trajectory.py:86-87,110-112 with SURVEY Q10).  The float64 planes
+            # are made when a call needs them (_planes64: another order, the reference's outer-product clamp, sample()).
+            u32, v32 = self.to_device(u, f32), self.to_device(v, f32)
+            lin32 = self._empty((n,), f32)
+            _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(u32), self._ptr(v32), _capi.LC_F32, nt, ny_f, nx_f, 1,
+                                               self._ptr(lin32), None), self.lib)
+            la, lo = lat_f.astype(dtype), lon_f.astype(dtype)
+            return PackedField(None, None, None, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
+                               True, 1, False, None, None, None, lin32, u32, v32)
+        ud = self.to_device(u, dtype)
+        vd = self.to_device(v, dtype)
         if fuse_levels is None:
             fuse_levels = True
         if wind_f32 or interp_order in (2, 4, 5):   # general orders: generic direct kernel, two-sample form
@@ -483,9 +498,19 @@ class Engine:
                      n_members, t0_stride, x, y, tx, ty) -> "_capi.AdvectArgs":
         """``lc_advect_args`` of one call: the field's images, and its raw planes as the order-1 source where it has no
         lin image."""
-        dt = _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[field.dtype]
-        self._ensure_lin(field, interp_order)
         p = lambda t: t.data_ptr() if t is not None else None
+        if field.lin32 is not None and interp_order == 1 and xmode != _capi.LC_X_CLAMP_REFERENCE_OUTER:
+            # float32 wind on float64 coordinates, the wind kept float32 (prepare_field)
+            return _capi.AdvectArgs(
+                struct_size=C.sizeof(_capi.AdvectArgs), packed_lin=p(field.lin32), dtype=_capi.LC_F64_WIND_F32_LIN32, nt=field.nt,
+                ny_f=field.ny_f, nx_f=field.nx_f, lat_min=field.lat_min, lat_max=field.lat_max, lon_min=field.lon_min,
+                lon_max=field.lon_max, seed_lat_dev=p(slat), ny=int(ny), seed_lon_dev=p(slon), nx=int(nx), row0=int(row0),
+                ny_global=int(ny_global), x_start=p(sx), y_start=p(sy), timestep=float(timestep), settls_order=int(K),
+                interp_order=1, cyclic_x=int(xmode), t0=int(t0), nsteps=int(nsteps), n_members=int(n_members),
+                t0_stride=int(t0_stride), x_out=p(x), y_out=p(y), traj_x=p(tx), traj_y=p(ty), fuse_levels_raw=0)
+        dt = _capi.LC_F64_WIND_F32 if field.wind_f32 else _NP2LC[field.dtype]
+        self._planes64(field)
+        self._ensure_lin(field, interp_order)
         return _capi.AdvectArgs(
             struct_size=C.sizeof(_capi.AdvectArgs), packed_lin=p(field.lin),
             packed_cub=p(field.cub if interp_order != 1 else None),
@@ -496,6 +521,13 @@ class Engine:
             settls_order=int(K), interp_order=int(interp_order), cyclic_x=int(xmode), t0=int(t0), nsteps=int(nsteps),
             n_members=int(n_members), t0_stride=int(t0_stride), x_out=p(x), y_out=p(y), traj_x=p(tx), traj_y=p(ty),
             fuse_levels_raw=int(bool(field.fuse_raw and interp_order == field.order)))
+
+    def _planes64(self, field: PackedField):
+        """A wind_f32 field prepared at order 1 keeps its wind float32; the float64 planes (the order-1 source of every other
+        call form: lc_advect's LC_F64_WIND_F32 with the reference's outer-product clamp, :meth:`sample`) are made here, once."""
+        if field.u is None and field.u32 is not None:
+            field.u, field.v = self.to_device(field.u32, field.dtype), self.to_device(field.v32, field.dtype)
+            field.planes_version = (field.u._version, field.v._version)
 
     def _ensure_lin(self, field: PackedField, interp_order: int):
         """The order-1 source of a call on ``field``, checked and -- where it is an image that does not exist yet -- built.
@@ -520,6 +552,7 @@ class Engine:
         """tools.xr_map_coordinates for (u, v) of one time level at positions (ny, nx) in degrees."""
         if interp_order != 1 and field.order != interp_order:
             raise ValueError(f"field was prepared for interp_order={field.order}")
+        self._planes64(field)
         self._ensure_lin(field, interp_order)
         dtype = field.dtype
         px = self.to_device(pos_x, dtype)

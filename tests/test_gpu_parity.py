@@ -924,6 +924,9 @@ def test_float32_wind_on_float64_coordinates_follows_numpy_promotion(eng, O, ord
     f = eng.prepare_field(u32, v32, lat, lon, order)
     assert f.dtype == np.float64 and f.wind_f32 and f.ext is None
     x, y = eng.advect(f, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
+    # order 1 keeps the wind float32 (LC_F64_WIND_F32_LIN32, per-wave LDS tiles of both levels); order 3 the generic kernel
+    assert eng.last_advect_kernel() == ("advect_lds64w_kernel<-1, true>" if order == 1 else "advect_kernel<double, 3, false, 0>")
+    assert (f.lin32 is not None and f.u is None) == (order == 1)
     xr_, yr_ = O.parcel_propagation(u32, v32, lat, lon, timestep=-3600.0, SETTLS_order=3, interp_order=order,
                                     cyclic_xboundary=True)
     assert xr_.dtype == np.float64
@@ -933,6 +936,64 @@ def test_float32_wind_on_float64_coordinates_follows_numpy_promotion(eng, O, ord
     f64 = eng.prepare_field(u32.astype(np.float64), v32.astype(np.float64), lat, lon, order)
     x64, y64 = eng.advect(f64, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
     assert np.abs(_np(y64) - yr_).max() > 100 * POS_ATOL64
+
+
+@pytest.mark.parametrize("K,cyclic", [(4, True), (3, True), (4, False), (0, True)])
+def test_float32_wind_kept_float32_equals_the_float64_images_bit_for_bit(eng, O, K, cyclic):
+    """LC_F64_WIND_F32_LIN32 (the default for float32 winds on float64 coordinates at order 1): the order-1 image stays
+    float32 and a node is widened as it is read -- the same doubles into the same sums as LC_F64_WIND_F32 on float64 images
+    of the wind (numpy's promotion: LCS/trajectory.py:86-87,110-112), so departure points, trajectories, row
+    blocks with a continuation and pole rows are bit-identical: LDS-tile kernel, direct kernel (SETTLS_order 0 or
+    lc_ctx_set_lds_tiles(0)), sparse and dense seed grids.  The reference's outer-product clamp, another interpolation
+    order and sample() fall back to float64 planes made on demand."""
+    u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
+    u, v, lat, lon = u * np.float32(2.0), v, lat.astype(np.float64), lon.astype(np.float64)
+    f_new = eng.prepare_field(u, v, lat, lon, 1)
+    f_old = eng.prepare_field(u, v, lat, lon, 1, lin_image=False)             # float64 planes as the order-1 source (round 4)
+    assert f_new.wind_f32 and f_new.lin32 is not None and f_new.u is None and f_old.lin32 is None and f_old.u is not None
+    for sny, snx in ((150, 200), (40, 60), (300, 512), (72, 144)):
+        slat, slon = flows.seed_grid(sny, snx, lat, lon)
+        try:
+            for mode in (-1, 0):
+                eng.set_lds_tiles(mode)
+                out = []
+                for f in (f_old, f_new):
+                    r = eng.advect(f, slat, slon, -1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+                                   noncyclic_clamp="pointwise", return_traj=True)
+                    name = eng.last_advect_kernel()
+                    lo, hi = 0, sny // 2
+                    rb = eng.advect(f, slat[lo:hi], slon, -1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+                                    noncyclic_clamp="pointwise", row0=lo, ny_global=sny, t0=3, nsteps=5, start=(r[2][3][lo:hi], r[3][3][lo:hi]))
+                    out.append(([_np(t) for t in r] + [_np(t) for t in rb], name))
+                (a, na), (b, nb) = out
+                assert na == "advect_kernel<double, 1, false, 1>", na
+                assert nb == ("advect_lds64w_kernel<%s, %s>" % (4 if K == 4 else -1, "true" if cyclic else "false") if (mode == -1 and K > 0) else "advect_w32_kernel"), nb
+                for p_, q_ in zip(a, b):
+                    assert p_.dtype == np.float64 and np.array_equal(p_, q_), (sny, snx, mode, na, nb)
+        finally:
+            eng.set_lds_tiles(-1)
+    # what the float32-kept form does not serve takes float64 planes made on demand: the reference's outer-product clamp ...
+    rng = np.random.default_rng(3)
+    la, lo_ = np.linspace(-40, 40, 41), np.linspace(-60, 50, 56)
+    uu, vv = (30 + 25 * rng.standard_normal((5, 41, 56))).astype(np.float32), (8 * rng.standard_normal((5, 41, 56))).astype(np.float32)
+    g = eng.prepare_field(uu, vv, la, lo_, 1)
+    xa, ya = eng.advect(g, la, lo_, 7200.0, 2, 1, False)
+    assert eng.last_advect_kernel() == "outer_substep_kernel" and g.u is not None
+    xo, yo = O.parcel_propagation(uu, vv, la, lo_, timestep=7200.0, SETTLS_order=2, interp_order=1, cyclic_xboundary=False,
+                                  noncyclic_clamp="reference_outer")
+    assert np.abs(_np(xa) - xo).max() < POS_ATOL64 and np.abs(_np(ya) - yo).max() < POS_ATOL64
+    # ... and sample()
+    px, py = np.meshgrid(lon[::7], lat[::5])
+    sa, sb = eng.sample(f_new, px, py, level=2), eng.sample(f_old, px, py, level=2)
+    assert all(np.array_equal(_np(p_), _np(q_)) for p_, q_ in zip(sa, sb))
+    # the C ABI refuses what the dtype does not cover
+    a = eng._advect_args(f_new, 1, eng.to_device(lat, np.float64), lat.size, eng.to_device(lon, np.float64), lon.size, 0, lat.size, None, None,
+                         -1800.0, 2, 1, 0, 8, 1, 0, *(eng._empty((lat.size, lon.size), np.float64) for _ in range(2)), None, None)
+    a.interp_order = 3
+    from lagrangiancoherence_amd import _capi
+    import ctypes
+    with pytest.raises(ValueError, match="LC_F64_WIND_F32_LIN32"):
+        _capi.check(eng.lib.lc_advect_ex(eng.ctx, ctypes.byref(a)), eng.lib)
 
 
 @pytest.mark.parametrize("order", [1, 3])
