@@ -3624,7 +3624,10 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 C.traj_y = A.traj_y + (size_t)s0 * plane_elems;
             }
             if (outer) {
-                if (!saved && hipMallocAsync((void **)&saved, 2 * plane_elems * sizeof(T), ctx->stream) != hipSuccess) saved = nullptr;
+                if (!saved && hipMallocAsync((void **)&saved, 2 * plane_elems * sizeof(T), ctx->stream) != hipSuccess) {
+                    saved = nullptr;          // no room for the saved positions: the restart is from the seed grid, as before
+                    (void)hipGetLastError();  // ... and the refusal is not this call's error
+                }
                 if (saved) {
                     (void)hipMemcpyAsync(saved, A.x_out, plane_elems * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
                     (void)hipMemcpyAsync(saved + plane_elems, A.y_out, plane_elems * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);

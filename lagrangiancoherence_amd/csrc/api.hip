@@ -187,6 +187,7 @@ extern "C" int lc_ctx_set_verify(lc_ctx *ctx, int mode) {
         hipError_t e = hipMalloc((void **)&ctx->verify_dev, LC_VERIFY_WORDS * sizeof(unsigned));
         if (e != hipSuccess) {
             ctx->verify_dev = nullptr;
+            (void)hipGetLastError();
             lc_set_error("lc_ctx_set_verify: hipMalloc failed: %s", hipGetErrorString(e));
             return e == hipErrorOutOfMemory ? LC_ENOMEM : LC_EHIP;
         }
@@ -251,6 +252,7 @@ extern "C" int lc_malloc(lc_ctx *ctx, size_t bytes, void **dev_out) {
     LC_HIP_CHECK(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(dev_out, bytes ? bytes : 1);
     if (e != hipSuccess) {
+        (void)hipGetLastError();  // (consumed with the failure it belongs to: see LC_HIP_CHECK)
         lc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? LC_ENOMEM : LC_EHIP;
     }

@@ -35,12 +35,16 @@ struct lc_ctx {
 
 void lc_set_error(const char *fmt, ...);
 
+// (a failed runtime call also leaves its code in the thread's sticky "last error", which the NEXT lc_* call's
+//  hipGetLastError() after its kernel launches would report as its own: consumed here, with the failure it belongs to --
+//  found by tests/test_host_orchestration_asan.py's injected failures)
 #define LC_HIP_CHECK(expr)                                                              \
     do {                                                                                \
         hipError_t _e = (expr);                                                         \
         if (_e != hipSuccess) {                                                         \
             lc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
                          __LINE__);                                                     \
+            (void)hipGetLastError();                                                    \
             return LC_EHIP;                                                             \
         }                                                                               \
     } while (0)

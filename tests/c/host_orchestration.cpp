@@ -1,0 +1,172 @@
+// The host orchestration of liblcs_hip -- lc_lcs_host, lc_lcs_global_host (csrc/api.hip), the spectral-truncation operator
+// cache (csrc/preprocess.hip), lc_advect_ex's launcher with its level chunks and the outer-clamp bookkeeping (csrc/advect.hip),
+// the wave-state audit's counters -- run against tests/c/fake_hip.c under AddressSanitizer + UBSan (+ LeakSanitizer at exit):
+//   * the plain routes in float32 / float64, orders 1 and 3, trajectories, Gaussian smoothing, both fidelity modes;
+//   * every bad-argument refusal returns its status and leaves nothing allocated;
+//   * an allocation failure injected at EVERY allocation of a route in turn, and a copy failure at every copy: the call
+//     returns an error (never crashes, never reads a freed buffer) and the context can still be destroyed with nothing live.
+// Built and run by tests/test_host_orchestration_asan.py.  Prints "OK <n checks>" on success.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/lcs_hip.h"
+
+extern "C" {
+int fake_hip_live(void);
+int fake_hip_mallocs(void);
+int fake_hip_copies(void);
+int fake_hip_launches(void);
+int fake_hip_bad_frees(void);
+void fake_hip_fail_malloc_at(int n);
+void fake_hip_fail_memcpy_at(int n);
+void fake_hip_reset_counts(void);
+}
+
+static int g_checks = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        ++g_checks;                                                                  \
+        if (!(cond)) {                                                               \
+            fprintf(stderr, "%s:%d: CHECK failed: %s   [%s]\n", __FILE__, __LINE__, #cond, lc_last_error()); \
+            exit(1);                                                                 \
+        }                                                                            \
+    } while (0)
+
+template <typename T>
+struct Case {
+    int nt, ny_f, nx_f, ny, nx;
+    std::vector<T> u, v, lat, lon, slat, slon, sigma, x, y, tx, ty;
+    Case(int nt_, int nyf, int nxf, int ny_, int nx_) : nt(nt_), ny_f(nyf), nx_f(nxf), ny(ny_), nx(nx_) {
+        u.assign((size_t)nt * ny_f * nx_f, T(3));
+        v.assign(u.size(), T(-1));
+        for (size_t i = 0; i < u.size(); ++i) u[i] += T(0.01) * T(i % 97), v[i] += T(0.02) * T(i % 53);
+        lat.resize(ny_f), lon.resize(nx_f), slat.resize(ny), slon.resize(nx);
+        for (int i = 0; i < ny_f; ++i) lat[i] = T(-80.0 + 160.0 * i / (ny_f - 1));
+        for (int i = 0; i < nx_f; ++i) lon[i] = T(-180.0 + 360.0 * i / nx_f);
+        for (int i = 0; i < ny; ++i) slat[i] = T(-80.0 + 160.0 * i / (ny - 1));
+        for (int i = 0; i < nx; ++i) slon[i] = T(-180.0 + 359.0 * i / (nx - 1));
+        sigma.resize((size_t)ny * nx), x.resize(sigma.size()), y.resize(sigma.size());
+        tx.resize((size_t)nt * ny * nx), ty.resize(tx.size());
+    }
+    int run(lc_ctx *ctx, int dtype, int K, int order, int cyclic, double gauss, bool traj) {
+        return lc_lcs_host(ctx, u.data(), v.data(), dtype, nt, ny_f, nx_f, lat.data(), lon.data(), slat.data(), ny, slon.data(), nx,
+                           -900.0, K, order, cyclic, 0, nt - 1, gauss, 1, LC_LAYOUT_REFERENCE, sigma.data(), x.data(), y.data(),
+                           traj ? tx.data() : nullptr, traj ? ty.data() : nullptr);
+    }
+};
+
+// a route run once clean (to count its allocations and copies), then once per allocation / copy with that one failing
+template <typename F>
+static void sweep_failures(lc_ctx *ctx, const char *what, F route) {
+    fake_hip_reset_counts();
+    const int live0 = fake_hip_live();
+    CHECK(route() == LC_OK);
+    CHECK(fake_hip_live() == live0);   // (the truncation operators stay cached on the context: counted in live0 from the second run on)
+    const int live1 = fake_hip_live();
+    fake_hip_reset_counts();
+    CHECK(route() == LC_OK);
+    const int n_malloc = fake_hip_mallocs(), n_copy = fake_hip_copies();
+    CHECK(fake_hip_live() == live1 && n_malloc > 0 && n_copy > 0 && fake_hip_launches() > 0);
+    for (int k = 1; k <= n_malloc; ++k) {
+        fake_hip_fail_malloc_at(k);
+        const int rc = route();
+        fake_hip_fail_malloc_at(0);
+        if (!(rc == LC_ENOMEM || rc == LC_EHIP || rc == LC_OK)) {   // (LC_OK: an optional scratch buffer whose absence has a fallback)
+            fprintf(stderr, "%s: allocation %d of %d failing gave status %d [%s]\n", what, k, n_malloc, rc, lc_last_error());
+            exit(1);
+        }
+        if (fake_hip_live() != live1) {
+            fprintf(stderr, "%s: allocation %d of %d failing left %d buffers live (%d before) [%s]\n", what, k, n_malloc, fake_hip_live(), live1, lc_last_error());
+            exit(1);
+        }
+        ++g_checks;
+    }
+    for (int k = 1; k <= n_copy; ++k) {
+        fake_hip_fail_memcpy_at(k);
+        const int rc = route();
+        fake_hip_fail_memcpy_at(0);
+        if (rc == LC_OK || fake_hip_live() != live1) {
+            fprintf(stderr, "%s: copy %d of %d failing gave status %d, %d buffers live (%d before) [%s]\n", what, k, n_copy, rc, fake_hip_live(), live1, lc_last_error());
+            exit(1);
+        }
+        ++g_checks;
+    }
+    CHECK(route() == LC_OK && fake_hip_live() == live1);
+}
+
+int main() {
+    CHECK(lc_version() == LC_VERSION);
+    lc_ctx *ctx = nullptr;
+    CHECK(lc_ctx_create(3, &ctx) == LC_EINVAL && ctx == nullptr);   // the fake machine has one device
+    CHECK(lc_ctx_create(0, &ctx) == LC_OK && ctx != nullptr);
+    const int base = fake_hip_live();
+    {
+        Case<float> c(5, 24, 40, 33, 47);
+        Case<double> d(5, 24, 40, 33, 47);
+        for (int order = 1; order <= 3; order += 2)
+            for (int cyclic = 0; cyclic <= 2; ++cyclic) {   // LC_X_CLAMP_POINT, LC_X_CYCLIC, LC_X_CLAMP_REFERENCE_OUTER
+                CHECK(c.run(ctx, LC_F32, 4, order, cyclic, 0.0, false) == LC_OK && fake_hip_live() == base);
+                CHECK(d.run(ctx, LC_F64, 2, order, cyclic, 1.5, true) == LC_OK && fake_hip_live() == base);
+            }
+        CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_FAST) == LC_OK && d.run(ctx, LC_F64, 4, 3, 1, 0.0, false) == LC_OK);
+        CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_EXACT_ORDER) == LC_OK && d.run(ctx, LC_F64, 4, 1, 1, 0.0, true) == LC_OK);
+        CHECK(lc_ctx_set_f64_fidelity(ctx, 7) == LC_EINVAL && lc_ctx_set_f64_fidelity(ctx, LC_F64_AUTO) == LC_OK);
+        CHECK(lc_ctx_set_level_chunk(ctx, 2) == LC_OK && c.run(ctx, LC_F32, 4, 1, 1, 0.0, true) == LC_OK);   // several launches per call
+        CHECK(lc_ctx_set_level_chunk(ctx, -1) == LC_OK && fake_hip_live() == base);
+        // refusals: nothing may stay allocated
+        CHECK(c.run(ctx, 9, 4, 1, 1, 0.0, false) == LC_EINVAL);
+        CHECK(c.run(ctx, LC_F32, -1, 1, 1, 0.0, false) == LC_EINVAL);
+        CHECK(c.run(ctx, LC_F32, 4, 0, 1, 0.0, false) == LC_EUNSUPPORTED);
+        CHECK(c.run(ctx, LC_F32, 4, 6, 1, 0.0, false) == LC_EUNSUPPORTED);
+        CHECK(c.run(ctx, LC_F32, 4, 1, 5, 0.0, false) == LC_EINVAL);
+        CHECK(lc_lcs_host(ctx, nullptr, c.v.data(), LC_F32, c.nt, c.ny_f, c.nx_f, c.lat.data(), c.lon.data(), c.slat.data(), c.ny, c.slon.data(), c.nx,
+                          -900.0, 4, 1, 1, 0, 4, 0.0, 1, 0, c.sigma.data(), nullptr, nullptr, nullptr, nullptr) == LC_EINVAL);
+        CHECK(lc_lcs_host(ctx, c.u.data(), c.v.data(), LC_F32, c.nt, c.ny_f, c.nx_f, c.lat.data(), c.lon.data(), c.slat.data(), c.ny, c.slon.data(), c.nx,
+                          -900.0, 4, 1, 1, 3, 4, 0.0, 1, 0, c.sigma.data(), nullptr, nullptr, nullptr, nullptr) == LC_EINVAL);   // steps beyond the series
+        CHECK(lc_lcs_host(nullptr, c.u.data(), c.v.data(), LC_F32, c.nt, c.ny_f, c.nx_f, c.lat.data(), c.lon.data(), c.slat.data(), c.ny, c.slon.data(), c.nx,
+                          -900.0, 4, 1, 1, 0, 4, 0.0, 1, 0, c.sigma.data(), nullptr, nullptr, nullptr, nullptr) == LC_EINVAL);
+        CHECK(fake_hip_live() == base && fake_hip_bad_frees() == 0);
+        sweep_failures(ctx, "lc_lcs_host float32 order 1", [&] { return c.run(ctx, LC_F32, 4, 1, 1, 0.0, true); });
+        sweep_failures(ctx, "lc_lcs_host float32 order 3 + gauss", [&] { return c.run(ctx, LC_F32, 4, 3, 1, 2.0, false); });
+        sweep_failures(ctx, "lc_lcs_host float64 order 3", [&] { return d.run(ctx, LC_F64, 4, 3, 1, 0.0, true); });
+        sweep_failures(ctx, "lc_lcs_host float64 outer clamp", [&] { return d.run(ctx, LC_F64, 2, 1, 2, 0.0, false); });
+    }
+    {   // the reference's default global call form: regrid + T20 truncation (operator cache) + the path
+        int gy = 0, gx = 0;
+        CHECK(lc_common_grid(&gy, &gx, nullptr, nullptr) == LC_OK && gy == 360 && gx == 721);
+        const int nt = 3, ny_f = 45, nx_f = 90;   // (an odd number of equally spaced latitudes includes the poles: windspharm's rule)
+        std::vector<double> u((size_t)nt * ny_f * nx_f, 5.0), v(u.size(), 1.0), lat(ny_f), lon(nx_f);
+        for (size_t i = 0; i < u.size(); ++i) u[i] += 0.1 * std::sin(0.01 * (double)i);
+        for (int i = 0; i < ny_f; ++i) lat[i] = -90.0 + 180.0 * i / (ny_f - 1);
+        for (int i = 0; i < nx_f; ++i) lon[i] = -180.0 + 360.0 * i / nx_f;
+        std::vector<double> sg((size_t)gy * gx), x(sg.size()), y(sg.size());
+        auto global = [&](int common, int trunc) {
+            return lc_lcs_global_host(ctx, u.data(), v.data(), LC_F64, nt, ny_f, nx_f, lat.data(), lon.data(), common, trunc, -21600.0, 4, 3,
+                                      0.0, 1, LC_LAYOUT_REFERENCE, sg.data(), x.data(), y.data());
+        };
+        CHECK(global(0, 20) == LC_OK);            // the operators of (45, 90, T20) are now cached on the context
+        CHECK(global(0, 10) == LC_OK);            // another truncation: the cache is replaced, the old operators freed
+        CHECK(global(0, -1) == LC_OK);
+        CHECK(global(0, 200) != LC_OK);           // beyond the grid's resolution
+        CHECK(lc_lcs_global_host(ctx, u.data(), v.data(), 7, nt, ny_f, nx_f, lat.data(), lon.data(), 0, 20, -21600.0, 4, 3, 0.0, 1, 0, sg.data(), nullptr, nullptr) == LC_EINVAL);
+        sweep_failures(ctx, "lc_lcs_global_host own grid, T10", [&] { return global(0, 10); });
+        sweep_failures(ctx, "lc_lcs_global_host common grid, T20", [&] { return global(1, 20); });
+    }
+    {   // the wave-state audit's counters
+        unsigned out[LC_VERIFY_WORDS];
+        CHECK(lc_ctx_read_verify(ctx, out, 1) == LC_EINVAL);
+        CHECK(lc_ctx_set_verify(ctx, 3) == LC_EINVAL && lc_ctx_set_verify(ctx, 2) == LC_OK);
+        CHECK(lc_ctx_read_verify(ctx, out, 1) == LC_OK && out[15] == 0xBADu && out[0] == 0);
+        CHECK(lc_ctx_set_verify(ctx, 1) == LC_OK && lc_ctx_read_verify(ctx, out, 0) == LC_OK && out[15] == 0);
+        fake_hip_fail_malloc_at(1);
+        CHECK(lc_ctx_set_verify(ctx, 0) == LC_OK && lc_ctx_set_verify(ctx, 1) == LC_ENOMEM && lc_ctx_read_verify(ctx, out, 0) == LC_EINVAL);
+        fake_hip_fail_malloc_at(0);
+        CHECK(lc_ctx_set_verify(ctx, 1) == LC_OK);   // left on: lc_ctx_destroy frees the counters
+    }
+    CHECK(lc_ctx_destroy(ctx) == LC_OK);
+    CHECK(fake_hip_live() == 0 && fake_hip_bad_frees() == 0);
+    printf("OK %d checks\n", g_checks);
+    return 0;
+}
