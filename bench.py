@@ -99,7 +99,9 @@ def stamped_counters(kernel: str, workload: dict, csrc: str):
             continue
         for k, v in d.get("kernels", {}).items():
             kk, want = k.replace(" ", ""), kernel.replace(" ", "")
-            if kk != want and not (kk.startswith(want + "<") and "<" not in want):   # "name" matches "name<template args>"
+            # "name" matches "name<template args>"; "name<a,b>" matches the profiler's "name<a,b,defaulted...>" (the library
+            # names a kernel by its leading template arguments: trailing ones added later keep their defaults there)
+            if kk != want and not (kk.startswith(want + "<") and "<" not in want) and not (want.endswith(">") and kk.startswith(want[:-1] + ",")):
                 continue
             if "hbm_bytes_per_launch" in v:
                 out["traffic"] = v["hbm_bytes_per_launch"]
@@ -316,7 +318,8 @@ def timed_case(torch, eng, prepare, advect, sigma, steps, warmup, pack_and_advec
     return el / steps, ms
 
 
-def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dlat, dlon, steps=3, warmup=1, c2_n=1024, c2_nt=201):
+def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dlat, dlon, steps=3, warmup=1, c2_n=1024, c2_nt=201,
+                        long_nt=385, c3_long_nt=201, c4_n=8192, c5=(2048, 64, 200)):
     """The non-headline workloads, a few steps each, in the same process after the headline's timed region (so the driver's
     one run records them): the reference's default interpolation order and its trajectory output on configs[2]'s field, and
     configs[1] (float64, seeds = field nodes: the reference's own shape) at orders 1 and 3.  Each entry: whole-step rate,
@@ -363,20 +366,21 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
         u2 = v2 = None
         torch.cuda.empty_cache()
         from lagrangiancoherence_amd import sharded
-        u5, v5, lat5, lon5 = flows.era5_like_on_device(torch, eng.device, nt=385, ny=int(ud.shape[1]), nx=int(ud.shape[2]))
+        u5, v5, lat5, lon5 = flows.era5_like_on_device(torch, eng.device, nt=long_nt, ny=int(ud.shape[1]), nx=int(ud.shape[2]))
         steps, warmup = 2, 1
         # north_star: "4096^2 seeds x 200 steps"
-        case("c3 x 200 steps", ny * nx * 200, K, 1, 4, lambda: eng.prepare_field(u5[:201], v5[:201], lat5, lon5, 1),
+        case(f"c3 x {c3_long_nt - 1} steps", ny * nx * (c3_long_nt - 1), K, 1, 4, lambda: eng.prepare_field(u5[:c3_long_nt], v5[:c3_long_nt], lat5, lon5, 1),
              lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 1, True), sig32)
         # configs[3] whole on one GPU: 8192^2 seeds x 384 steps
-        s4lat, s4lon = flows.seed_grid(8192, 8192, lat5, lon5)
+        s4lat, s4lon = flows.seed_grid(c4_n, c4_n, lat5, lon5)
         s4lat_d, s4lon_d = eng.to_device(s4lat, np.float32), eng.to_device(s4lon, np.float32)
         d4 = (float(s4lat[1] - s4lat[0]), float(s4lon[1] - s4lon[0]))
-        case("c4 on one GPU", 8192 * 8192 * 384, K, 1, 4, lambda: eng.prepare_field(u5, v5, lat5, lon5, 1),
+        case("c4 on one GPU", c4_n * c4_n * (long_nt - 1), K, 1, 4, lambda: eng.prepare_field(u5, v5, lat5, lon5, 1),
              lambda f: eng.advect(f, s4lat_d, s4lon_d, -900.0, K, 1, True), lambda r: eng.sigma(r[0], r[1], s4lat_d, *d4))
         del s4lat_d, s4lon_d
         # configs[4] whole on one GPU: 64 start times x 2048^2 seeds x 200 steps on the first 264 levels
-        s5lat, s5lon = flows.seed_grid(2048, 2048, lat5, lon5)
+        c5_n, c5_m, c5_steps = c5
+        s5lat, s5lon = flows.seed_grid(c5_n, c5_n, lat5, lon5)
         s5lat_d, s5lon_d = eng.to_device(s5lat, np.float32), eng.to_device(s5lon, np.float32)
         d5 = (float(s5lat[1] - s5lat[0]), float(s5lon[1] - s5lon[0]))
 
@@ -386,8 +390,8 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
                 sg = eng.sigma(x, y, s5lat_d, *d5)
             return sg
         steps = 1
-        case("c5 on one GPU", 64 * 2048 * 2048 * 200, K, 1, 4, lambda: eng.prepare_field(u5[:264], v5[:264], lat5, lon5, 1),
-             lambda f: sharded.ensemble_advect(eng, f, s5lat_d, s5lon_d, -900.0, list(range(64)), 200, K, 1, True), c5_sigma)
+        case("c5 on one GPU", c5_m * c5_n * c5_n * c5_steps, K, 1, 4, lambda: eng.prepare_field(u5[:c5_m + c5_steps], v5[:c5_m + c5_steps], lat5, lon5, 1),
+             lambda f: sharded.ensemble_advect(eng, f, s5lat_d, s5lon_d, -900.0, list(range(c5_m)), c5_steps, K, 1, True), c5_sigma)
     except Exception as exc:
         out["c4 on one GPU"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     return out

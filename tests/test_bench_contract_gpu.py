@@ -183,12 +183,15 @@ def test_secondary_workloads_block_of_the_default_run():
     slat, slon = flows.seed_grid(160, 256, lat, lon)
     sec = bench.secondary_workloads(torch, flows, eng, eng.to_device(u, np.float32), eng.to_device(v, np.float32), lat, lon,
                                     eng.to_device(slat, np.float32), eng.to_device(slon, np.float32), float(slat[1] - slat[0]),
-                                    float(slon[1] - slon[0]), steps=2, warmup=1, c2_n=128, c2_nt=9)
-    assert list(sec) == ["c3 order 3", "c3 return_traj", "c2", "c2 order 3"]
+                                    float(slon[1] - slon[0]), steps=2, warmup=1, c2_n=128, c2_nt=9,
+                                    long_nt=25, c3_long_nt=11, c4_n=320, c5=(128, 4, 20))
+    # ... and (round 5) north_star's own target shape and the other BASELINE configurations on one GPU
+    assert list(sec) == ["c3 order 3", "c3 return_traj", "c2", "c2 order 3", "c3 x 10 steps", "c4 on one GPU", "c5 on one GPU"]
     for name, d in sec.items():
         assert "error" not in d, (name, d)
         assert d["value"] > 0 and d["ms_per_step"] > 0 and 0 < d["frac"] <= 1 and d["advect_launches"] >= 1
         assert set(d["kernel_ms"]) == {"pack", "advect", "sigma"} and abs(d["advect_kernel_ms"] * d["advect_launches"] - d["kernel_ms"]["advect"]) < 1e-3
+    assert sec["c5 on one GPU"]["advect_launches"] == 2         # 20 steps + 3 levels of stagger between the members in chunks of 16 levels
     assert "o3" in sec["c3 order 3"]["kernel"] or "<3," in sec["c3 order 3"]["kernel"]
     assert sec["c2"]["kernel"].startswith("advect_lds64_kernel") and sec["c2 order 3"]["kernel"].startswith("advect_lds64_o3_kernel")
     eng.close()

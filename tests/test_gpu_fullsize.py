@@ -157,5 +157,8 @@ def test_config3_return_traj_whole_line_stores_full_size(eng, c3):
         o[dt] = O.parcel_propagation(c(u[:nt], dt), c(v[:nt], dt), c(lat, dt), c(lon, dt), seed_lat=c(slat, dt)[rows],
                                      seed_lon=c(slon, dt)[cols], **kw)
     for lev in range(1, nt):
+        # floors grow with the level as the error does (level 1 measures 3.9e-6 / 2.4e-5 / 4.1e-5, level 24 2.3e-5 / 8.6e-4 / 2.1e-3:
+        # profiles/r05/parity_stats.txt); until round 5 every level had level 24's
+        g = 0.1 + 0.9 * (lev - 1) / 23.0
         positions_check(eng, f, slat, slon, rows, cols, xg[lev], yg[lev], (o[np.float32][0][lev], o[np.float32][1][lev]),
-                        (o[np.float64][0][lev], o[np.float64][1][lev]), f"C3 traj level {lev}", (1e-4, 5e-4, 2e-3), nsteps=lev)
+                        (o[np.float64][0][lev], o[np.float64][1][lev]), f"C3 traj level {lev}", (1e-4 * g, 5e-4 * g, 2e-3 * g), nsteps=lev)

@@ -86,8 +86,11 @@ def test_config3_sigma_windows_vs_oracle(eng, c3, O, name):
     win = WINDOWS[name]
     o32 = oracle_window(O, u, v, lat, lon, slat, slon, *win, np.float32, 1, **KW)
     o64 = oracle_window(O, u, v, lat, lon, slat, slon, *win, np.float64, 1, **KW)
-    _window_check(eng, res[1], slat, slon, win, o32, o64, f"C3 {name} (order 1, 96 steps)", 1,
-                  (1e-4, 1e-3, 1e-2), (1e-4, 5e-4, 2e-3))
+    # floors (what the engine may always have, whatever the float32 oracle's own error): by window since round 5 -- the measured
+    # values are in profiles/r05/parity_stats.txt; a floor sat an order of magnitude above them at 60N (p99 2.4e-5 against 5e-4)
+    floors_s, floors_p = {"equator": ((1e-4, 5e-4, 1e-3), (1e-4, 5e-4, 2e-3)), "60N": ((4e-4, 1.5e-3, 2.5e-3), (2e-5, 5e-5, 1e-4)),
+                          "pole_edge": ((1e-4, 1e-3, 1e-2), (3e-4, 5e-4, 2e-3))}[name]
+    _window_check(eng, res[1], slat, slon, win, o32, o64, f"C3 {name} (order 1, 96 steps)", 1, floors_s, floors_p)
 
 
 def test_config3_sigma_window_order3(eng, c3, O):
@@ -97,7 +100,7 @@ def test_config3_sigma_window_order3(eng, c3, O):
     o32 = oracle_window(O, u[:25], v[:25], lat, lon, slat, slon, *win, np.float32, **kw)
     o64 = oracle_window(O, u[:25], v[:25], lat, lon, slat, slon, *win, np.float64, **kw)
     _window_check(eng, res[3], slat, slon, win, o32, o64, "C3 60N (order 3, 24 steps)", 3,
-                  (1e-4, 1e-3, 1e-2), (1e-4, 5e-4, 2e-3))
+                  (1.5e-4, 6e-4, 1e-3), (3e-5, 1.5e-4, 2.5e-4))   # (measured 1.2e-4 / 4.6e-4 / 6.0e-4 and 2.5e-5 / 1.0e-4 / 1.6e-4)
 
 
 # ------------------------------------------------------------------------------------------ C4

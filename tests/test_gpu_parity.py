@@ -148,9 +148,21 @@ def test_raw_planes_as_the_order1_source_equal_the_lin_image_bit_for_bit(eng, dt
     sb = eng.sample(f_lin, px, py, level=2, interp_order=order)
     assert all(np.array_equal(_np(p), _np(q), equal_nan=True) for p, q in zip(sa, sb))
     if order != 1:   # "order 1 is always available" on a field prepared for another order
+        f_fresh = eng.prepare_field(u, v, lat, lon, order, fuse_levels=fuse)   # sample() FIRST: float32 builds its order-1 image on demand there too
+        sa = eng.sample(f_fresh, px, py, level=2, interp_order=1)
+        sb = eng.sample(f_lin, px, py, level=2, interp_order=1)
+        assert all(np.array_equal(_np(p), _np(q), equal_nan=True) for p, q in zip(sa, sb))
+        assert (f_fresh.lin is not None) == (dtype == np.float32)
         a = eng.advect(f_raw, slat, slon, -1800.0, K, 1, True)
         b = eng.advect(f_lin, slat, slon, -1800.0, K, 1, True)
         assert all(np.array_equal(_np(p), _np(q), equal_nan=True) for p, q in zip(a, b))
+    # the raw planes are BORROWED from the caller when they were device tensors: an in-place write afterwards is refused
+    ud, vd = eng.to_device(u, dtype), eng.to_device(v, dtype)
+    f_b = eng.prepare_field(ud, vd, lat, lon, order, fuse_levels=fuse)
+    if f_b.u is not None:
+        ud.add_(1.0)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            eng.advect(f_b, slat[:9], slon, -1800.0, K, order, True, row0=0, ny_global=slat.size)
 
 
 @pytest.mark.parametrize("K,cyclic", [(4, True), (2, True), (4, False), (1, False)])
