@@ -49,10 +49,15 @@ enum lc_dtype {
      * arithmetic follows numpy's promotion for that mix in the reference (samples rounded to float,
      * latitude increments formed in float; LCS/trajectory.py:86-87,110-112 with SURVEY Q10). */
     LC_F64_WIND_F32 = 2,
-    /* lc_advect_ex only, interp_order 1, cyclic or per-point boundaries: the same arithmetic with the wind KEPT float32 --
-     * packed_lin is the order-1 image lc_field_pack builds for LC_F32 (half the bytes, no float64 copy of the wind), every
-     * other image pointer NULL; positions, seeds and outputs are float64.  Results equal LC_F64_WIND_F32's bit for bit
-     * (a node is widened as it is read: the same doubles enter the same sums); per-wave LDS tiles of levels t and t + 1. */
+    /* lc_advect_ex only, interp_order 1 or 3, cyclic or per-point boundaries: the same arithmetic with the wind KEPT float32
+     * wherever scipy keeps it; positions, seeds and outputs are float64; results equal LC_F64_WIND_F32's bit for bit.
+     *   interp_order 1: packed_lin is the order-1 image lc_field_pack builds for LC_F32 (half the bytes, no float64 copy of
+     *                   the wind: a node is widened as it is read), every other image pointer NULL; per-wave LDS tiles of
+     *                   levels t and t + 1.
+     *   interp_order 3: packed_cub is the FLOAT64 coefficient image of the float32 planes -- lc_field_pack(LC_F64_WIND_F32,
+     *                   order 3): scipy's spline_filter(output=float64) inside map_coordinates -- and u_raw / v_raw are the
+     *                   float32 planes themselves (the order-1 source of the pole rows); packed_lin NULL.
+     * (lc_field_pack accepts LC_F64_WIND_F32 for interp_order 2..5 without ext_dev: float32 planes in, float64 image out.) */
     LC_F64_WIND_F32_LIN32 = 3
 };
 

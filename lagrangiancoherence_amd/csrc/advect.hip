@@ -46,6 +46,7 @@ struct AdvectArgs {
     // not read at all).  Same node values, same arithmetic, bit-identical results -- the image the pack no longer writes.
     const T *u_raw, *v_raw;
     const float *lin32;  // LC_F64_WIND_F32_LIN32 (double instantiation, order 1): the order-1 image of the float32 wind AS float32; lin / img / raw planes unused
+    const float *u_raw32, *v_raw32;  // LC_F64_WIND_F32_LIN32 at order 3: the float32 raw planes, the order-1 source of the pole rows (img = float64 coefficients)
     size_t raw_plane;  // ny_f * nx_f
     int ext_raw;       // float64, order 1, raw planes: the fused-level value 2 F[t] - F[t+1] is formed from the planes node by node
                        // (lc_advect_args.fuse_levels_raw): no packed image at all, ext == NULL
@@ -310,6 +311,8 @@ __device__ __forceinline__ Tap<T> locate(const AdvectArgs<T> &A, T x, T y) {
         cubic_weights<T>(t.ty, t.wy);
         cubic_weights<T>(t.tx, t.wx);
         t.off = ((unsigned)y0 * (unsigned)A.pitch + (unsigned)x0) * 2u;  // window starts at padded (y0, x0)
+        t.sy = y0;  // (an LDS tile addresses the window by its padded origin)
+        t.sx = x0;
     } else {
         t.wy[0] = T(1) - t.ty;
         t.wy[1] = T(1) - t.wy[0];  // scipy: last weight = 1 - sum(others)
@@ -362,6 +365,26 @@ __device__ __forceinline__ Pair<T> tap_sum_order1(const T (&a)[4], const T (&b)[
     return r;
 }
 
+// ... and the order-3 sample of a 4 x 4 window (rows of four interleaved nodes), scipy's tap order: per tap ((value*wy)*wx),
+// summed from 0, last axis fastest.  Shared by the global-memory window and the LDS tile of advect_lds64w_o3_kernel.
+template <typename T>
+__device__ __forceinline__ Pair<T> tap_sum_order3(const T (&q)[4][8], const Tap<T> &t) {
+#pragma clang fp contract(off)
+    T su = T(0), sv = T(0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            su += (q[a][2 * b] * t.wy[a]) * t.wx[b];
+            sv += (q[a][2 * b + 1] * t.wy[a]) * t.wx[b];
+        }
+    }
+    Pair<T> r;
+    r.u = su;
+    r.v = sv;
+    return r;
+}
+
 // RAW (order 1 only): `lvl` is the level's raw u plane, the v plane lies A.v_raw - A.u_raw elements on
 template <typename T, int ORDER, bool RAW = false>
 __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const AdvectArgs<T> &A, const Tap<T> &t) {
@@ -376,20 +399,10 @@ __device__ __forceinline__ Pair<T> fetch(const T *__restrict__ lvl, const Advect
     if (ORDER != 1 && ORDER != 3) return fetch_general<T, ORDER>(lvl, A, t);
     const T *p = RAW ? lvl : lvl + t.off;
     if (ORDER == 3) {
-        T su = T(0), sv = T(0);
+        T q[4][8];  // the 4 x 4 window, rows of {u0, v0, u1, v1, u2, v2, u3, v3}
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            T row[8];
-            __builtin_memcpy(row, p + (unsigned)a * (unsigned)A.pitch * 2u, sizeof(row));
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {  // scipy tap order; per tap ((value*wy)*wx), summed from 0
-                su += (row[2 * b] * t.wy[a]) * t.wx[b];
-                sv += (row[2 * b + 1] * t.wy[a]) * t.wx[b];
-            }
-        }
-        r.u = su;
-        r.v = sv;
-        return r;
+        for (int a = 0; a < 4; ++a) __builtin_memcpy(q[a], p + (unsigned)a * (unsigned)A.pitch * 2u, sizeof(q[a]));
+        return tap_sum_order3<T>(q, t);
     }
     T a[4], b[4];
     if (RAW) {
@@ -543,8 +556,16 @@ constexpr int POLE_LIN = 0, POLE_EITHER = 1, POLE_RAW = 2;
 // float64 at order 1, where the samples come from: packed images (lin + ext) / raw planes for the Euler sample + ext image /
 // raw planes for both (the fused-level value formed node by node)
 constexpr int SRC_IMAGES = 0, SRC_RAW_EULER = 1, SRC_RAW_ALL = 2;
+template <bool WRAP>
+__device__ void advect_seed_w32(const AdvectArgs<double> &A, int iy, int ix);  // (below: the float32 wind's own order-1 path)
 template <typename T, int SRC>
 __device__ __forceinline__ void pole_seed(const AdvectArgs<T> &A, int iy, int ix) {
+    if constexpr (sizeof(T) == 8 && SRC == POLE_EITHER) {
+        if (A.u_raw32) {  // LC_F64_WIND_F32_LIN32 at order 3: the pole rows sample the float32 planes
+            advect_seed_w32<false>(A, iy, ix);
+            return;
+        }
+    }
     if (SRC == POLE_RAW || (SRC == POLE_EITHER && A.u_raw))
         advect_seed<T, 1, false, false, true>(A, A.u_raw, iy, ix);
     else
@@ -576,10 +597,21 @@ __device__ __forceinline__ bool pole_block(const AdvectArgs<T> &A) {
 // ======================================================================================
 typedef float w4 __attribute__((ext_vector_type(4)));
 typedef float w2 __attribute__((ext_vector_type(2)));
+typedef double d2w __attribute__((ext_vector_type(2)));
 
 // the window of cell (t.sy, t.sx) from one level of the float32 image (padded (row + 1, column + 1): pads hold the mirror)
+// (no image -- order 3, where only the pole rows sample at order 1 --: `lvl` is the level's raw float32 u plane, the v plane
+//  lies A.v_raw32 - A.u_raw32 on; the neighbour behind the last node is its mirror image, node n - 2, as in the image's pads)
 __device__ __forceinline__ void window_w32(const float *__restrict__ lvl, const AdvectArgs<double> &A, const Tap<double> &t,
                                            double (&a)[4], double (&b)[4]) {
+    if (!A.lin32) {
+        const float *up = lvl, *vp = lvl + (A.v_raw32 - A.u_raw32);
+        const int x1 = t.sx + 1 < A.nx_f ? t.sx + 1 : A.nx_f - 2, y1 = t.sy + 1 < A.ny_f ? t.sy + 1 : A.ny_f - 2;
+        const size_t r0 = (size_t)t.sy * A.nx_f, r1 = (size_t)y1 * A.nx_f;
+        a[0] = up[r0 + t.sx], a[1] = vp[r0 + t.sx], a[2] = up[r0 + x1], a[3] = vp[r0 + x1];
+        b[0] = up[r1 + t.sx], b[1] = vp[r1 + t.sx], b[2] = up[r1 + x1], b[3] = vp[r1 + x1];
+        return;
+    }
     const float *p = lvl + ((size_t)(t.sy + LC_PAD_LO) * A.pitch + (t.sx + LC_PAD_LO)) * 2;
     w4 r0, r1;
     __builtin_memcpy(&r0, p, 16);                          // {u00, v00, u01, v01}
@@ -618,9 +650,10 @@ __device__ void advect_seed_w32(const AdvectArgs<double> &A, int iy, int ix) {
         A.traj_x[idx] = x;
         A.traj_y[idx] = y;
     }
-    const float *lvl = A.lin32 + (size_t)A.t0 * A.level_elems;
+    const size_t lstride = A.lin32 ? A.level_elems : A.raw_plane;   // image levels, or raw planes
+    const float *lvl = (A.lin32 ? A.lin32 : A.u_raw32) + (size_t)A.t0 * lstride;
     for (int s = 0; s < A.nsteps; ++s) {
-        const float *nxt = lvl + A.level_elems;
+        const float *nxt = lvl + lstride;
         const Pair<T> e = sample_w32<WRAP>(lvl, A, locate<T, 1, WRAP>(A, x, y));     // trajectory.py:82-84
         y = y + lat_increment<T>(A, A.dtcy, e.v);                                     // :86
         x = axpy<T>(dtcx, e.u, x);                                                    // :87
@@ -773,6 +806,132 @@ __global__ void __launch_bounds__(BLOCK) advect_lds64w_kernel(const AdvectArgs<d
             }
             y = y + lat_increment<T>(A, A.hdtcy, settls_bracket<T>(A, e.v, c.v, n.v));   // :110
             x = axpy<T>(hdtcx, settls_bracket<T>(A, e.u, c.u, n.u), x);                  // :112
+            clamp_position<T>(A, x, y);
+        }
+        if (live && A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl = nxt;
+    }
+    if (live) {
+        A.x_out[idx] = x;
+        A.y_out[idx] = y;
+    }
+}
+
+// ORDER 3 with such a wind (the reference's default interpolation on float32 reanalysis winds): scipy forms the spline
+// coefficients in double (spline_filter(output=float64) inside map_coordinates), samples them in double and returns float32.
+// img = the float64 coefficient image of the float32 planes (lc_field_pack(LC_F64_WIND_F32, order 3)); per wave two 16 x 16-node
+// tiles (levels t and t + 1, one anchor on the middle of the level's travel) serve the Euler sample and both samples of every
+// iteration; scipy's weights (cubic_weights), tap order (tap_sum_order3) and numpy's index map (locate<double, 3>), so the
+// result is advect_seed<double, 3, true> with A.wind_f32 bit for bit.  A window outside the tiles reads global memory.
+#ifndef LCS_LDS64W_O3_MINWAVES
+#define LCS_LDS64W_O3_MINWAVES 2   // 200 vector registers, no spills (a 4 x 4 window of float64 nodes is 64 of them): config 2's shape 15.8 ms;
+                                   // 3 waves (168 registers, 34 spilled) 17.4; 4 waves (128, 138 spilled) not run
+#endif
+constexpr int TW3 = 16, TW3_PITCH = 20;
+template <int KFIX, bool CYCLIC>
+__global__ void __launch_bounds__(BLOCK, LCS_LDS64W_O3_MINWAVES) advect_lds64w_o3_kernel(const AdvectArgs<double> A0) {
+#pragma clang fp contract(off)
+    typedef double T;
+    const AdvectArgs<double> A = for_member(A0);
+    const int K = KFIX >= 0 ? KFIX : A.K;
+    __shared__ __attribute__((aligned(16))) d2w s_tiles[BLOCK / 64][2][TW3 * TW3_PITCH];
+    if (pole_block<double, POLE_EITHER>(A)) return;
+    const int tile_id = xcd_tile_id(A);
+    if (tile_id >= A.ntiles) return;  // whole block
+    const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
+    const int ix = txi * TILE_W + (threadIdx.x % TILE_W), iy = tyi * TILE_H + (threadIdx.x / TILE_W);
+    const int lane = threadIdx.x & 63;
+    d2w *tile0 = s_tiles[threadIdx.x >> 6][0], *tile1 = s_tiles[threadIdx.x >> 6][1];
+    bool live = ix < A.nx && iy < A.ny;
+    if (live) {
+        const int grow = A.row0 + iy;
+        if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path (Q3)
+            if (!A.pole_blocks) pole_seed<double, POLE_EITHER>(A, iy, ix);
+            live = false;
+        }
+    }
+    if (__ballot(live) == 0ull) return;  // whole wave (no workgroup barrier anywhere below)
+    const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);  // lanes without a seed shadow a neighbour; stores masked
+    T x = start_x<T>(A, sy_i, sx_i), y = start_y<T>(A, sy_i, sx_i);
+    const T ys = A.seed_lat[sy_i];
+    const T cx_conv = T(180) / (T(3.141592653589793 * 6371000.0) * fabs(cos((ys * T(3.141592653589793)) / T(180))));  // Q5
+    const T dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
+    const size_t idx = live ? (size_t)iy * A.nx + ix : 0, plane = (size_t)A.ny * A.nx;
+    if (live && A.traj_x && !A.traj_skip0) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const double *lvl = A.img + (size_t)A.t0 * A.level_elems;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    constexpr int CENTRE = TILE_W / 2 + TILE_W * 4;  // middle seed of the wave's 8 x 8 patch
+    const int st_row = lane >> 4, st_col = lane & 15;  // staging: one node (16 bytes) per lane and level, 4 rows per pass, 4 passes
+    const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 16u;
+    double dprev_x = 0.0, dprev_y = 0.0;  // previous level's Euler displacement in index space: predicts this level's travel
+    // one sample at a located window: out of the tile when the window (padded origin (sy, sx), 4 x 4) lies inside it
+    auto sample = [&](const double *level, const d2w *tile, const Tap<T> &tap, int ox, int oy) {
+        const int rx = tap.sx - ox, ry = tap.sy - oy;
+        Pair<T> r;
+        if ((unsigned)rx <= (unsigned)(TW3 - 4) && (unsigned)ry <= (unsigned)(TW3 - 4)) {
+            T q[4][8];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const d2w n = tile[(ry + a) * TW3_PITCH + rx + b];
+                    q[a][2 * b] = n.x;
+                    q[a][2 * b + 1] = n.y;
+                }
+            r = tap_sum_order3<T>(q, tap);
+        } else {
+            r = fetch<T, 3>(level, A, tap);
+        }
+        r.u = (double)(float)r.u;   // map_coordinates returns the field's dtype (Q10)
+        r.v = (double)(float)r.v;
+        return r;
+    };
+    for (int s = 0; s < A.nsteps; ++s) {
+        const double *nxt = lvl + A.level_elems;
+        // ---- 1. both tiles, anchored on the middle of the travel [0, K] Euler displacements the previous level predicts ------
+        const double cax = (x - A.lon_min) * A.sx + dprev_x * (0.5 * K), cay = (y - A.lat_min) * A.sy + dprev_y * (0.5 * K);
+        const int rxm = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cax, -4.0), 1.0e9)), CENTRE);
+        const int rym = __builtin_amdgcn_readlane((int)floor(fmin(fmax(cay, -4.0), 1.0e9)), CENTRE);
+        const int ox = min(max(rxm - (TW3 - 4) / 2, 0), pad_cols - TW3), oy = min(max(rym - (TW3 - 4) / 2, 0), pad_rows - TW3);
+        {
+            d2w st0[TW3 / 4], st1[TW3 / 4];
+            const char *src = (const char *)lvl + ((size_t)oy * pad_cols + ox) * 16, *srcn = src + A.level_elems * sizeof(double);
+#pragma unroll
+            for (int r = 0; r < TW3 / 4; ++r) {
+                __builtin_memcpy(&st0[r], src + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+                if (K > 0) __builtin_memcpy(&st1[r], srcn + (size_t)(r * 4) * pad_cols * 16 + st_off, 16);
+            }
+            __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
+#pragma unroll
+            for (int r = 0; r < TW3 / 4; ++r) {
+                tile0[(r * 4 + st_row) * TW3_PITCH + st_col] = st0[r];
+                if (K > 0) tile1[(r * 4 + st_row) * TW3_PITCH + st_col] = st1[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- 2. Euler sample ------------------------------------------------------------------------------------------------
+        const double x0p = x, y0p = y;
+        const Pair<T> e = sample(lvl, tile0, locate<T, 3, true>(A, x, y), ox, oy);   // trajectory.py:82-84
+        y = y + lat_increment<T>(A, A.dtcy, e.v);                                     // :86
+        x = axpy<T>(dtcx, e.u, x);                                                    // :87
+        clamp_position<T>(A, x, y);
+        dprev_x = (x - x0p) * A.sx;
+        dprev_y = (y - y0p) * A.sy;
+        // ---- 3. K iterations, one located window, both levels ------------------------------------------------------------------
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            const Tap<T> tap = locate<T, 3, true>(A, x, y);
+            const Pair<T> c = sample(lvl, tile0, tap, ox, oy);   // :105,107
+            __builtin_amdgcn_sched_barrier(0);                  // (one 64-register window at a time)
+            const Pair<T> n = sample(nxt, tile1, tap, ox, oy);   // :106,108
+            y = y + lat_increment<T>(A, A.hdtcy, settls_bracket<T>(A, e.v, c.v, n.v));               // :110
+            x = axpy<T>(hdtcx, settls_bracket<T>(A, e.u, c.u, n.u), x);                              // :112
             clamp_position<T>(A, x, y);
         }
         if (live && A.traj_x) {
@@ -3408,7 +3567,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 const void *seed_lon, int nx, int row0, int ny_global, double timestep, int K, int order, int cyclic,
                 int t0, int nsteps, void *x_out, void *y_out, void *traj_x, void *traj_y, const void *x_start,
                 const void *y_start, int wind_f32 = 0, int n_members = 1, int t0_stride = 0, int fuse_levels_raw = 0,
-                const void *lin32 = nullptr) {
+                const void *lin32 = nullptr, const void *lin32_v = nullptr) {
     AdvectArgs<T> A{};
     A.wind_f32 = wind_f32;
     A.n_members = n_members;
@@ -3426,7 +3585,9 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.lin = (const T *)packed_lin;
     A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
     A.ext = (order == 1 || order == 3) ? (const T *)packed_ext : nullptr;  // general orders: two-sample form
-    A.lin32 = sizeof(T) == 8 ? (const float *)lin32 : nullptr;  // LC_F64_WIND_F32_LIN32: the float32 order-1 image (then lin == img == NULL)
+    A.lin32 = (sizeof(T) == 8 && order == 1) ? (const float *)lin32 : nullptr;  // LC_F64_WIND_F32_LIN32: the float32 order-1 image (then lin == img == NULL)
+    A.u_raw32 = (sizeof(T) == 8 && order == 3) ? (const float *)lin32 : nullptr;  // ... at order 3: the float32 raw planes (u, then v given as u_raw / v_raw)
+    A.v_raw32 = (sizeof(T) == 8 && order == 3) ? (const float *)lin32_v : nullptr;
     A.u_raw = (const T *)u_raw;  // (lc_advect_ex validated: only where a kernel reads them)
     A.v_raw = (const T *)v_raw;
     A.raw_plane = (size_t)ny_f * nx_f;
@@ -3518,6 +3679,21 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
                 hipLaunchKernelGGL(advect_w32_kernel, dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);
                 name = "advect_w32_kernel";
                 return;
+            }
+            if (A.u_raw32 && order == 3 && use_lds && A.nx_f + LC_PAD >= TW3 && A.ny_f + LC_PAD >= TW3) {
+                // LC_F64_WIND_F32_LIN32 at order 3: tiles of the float64 coefficients of levels t and t + 1 (else: the generic kernel below,
+                // whose pole rows read the float32 planes)
+#define LC_W32O3(KF, CY, NAME)                                                                                        \
+    {                                                                                                                 \
+        hipLaunchKernelGGL((advect_lds64w_o3_kernel<KF, CY>), dim3(grid, nmem(A)), dim3(BLOCK), 0, ctx->stream, A);   \
+        name = NAME;                                                                                                  \
+        return;                                                                                                       \
+    }
+                if (A.K == 4 && A.cyclic) LC_W32O3(4, true, "advect_lds64w_o3_kernel<4, true>")
+                if (A.K == 4) LC_W32O3(4, false, "advect_lds64w_o3_kernel<4, false>")
+                if (A.cyclic) LC_W32O3(-1, true, "advect_lds64w_o3_kernel<-1, true>")
+                LC_W32O3(-1, false, "advect_lds64w_o3_kernel<-1, false>")
+#undef LC_W32O3
             }
         }
         if (order == 2 || order == 4 || order == 5) {  // generic direct kernel, any dtype
@@ -3900,12 +4076,16 @@ extern "C" int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args) {
     LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64 || dtype == LC_F64_WIND_F32 || dtype == LC_F64_WIND_F32_LIN32, "lc_advect: bad dtype %d", dtype);
     LC_REQUIRE((dtype != LC_F64_WIND_F32 && dtype != LC_F64_WIND_F32_LIN32) || !packed_ext, "lc_advect: LC_F64_WIND_F32 keeps the two-sample form (no ext)");
     if (dtype == LC_F64_WIND_F32_LIN32) {
-        LC_REQUIRE(packed_lin && !packed_cub && !u_raw && !v_raw, "lc_advect: LC_F64_WIND_F32_LIN32 takes packed_lin (the float32 order-1 image) and nothing else");
-        if (interp_order != 1 || cyclic_x == LC_X_CLAMP_REFERENCE_OUTER) {
-            lc_set_error("lc_advect: LC_F64_WIND_F32_LIN32 is the order-1 form with cyclic / per-point boundaries; interp_order %d or "
+        if ((interp_order != 1 && interp_order != 3) || cyclic_x == LC_X_CLAMP_REFERENCE_OUTER) {
+            lc_set_error("lc_advect: LC_F64_WIND_F32_LIN32 serves interp_order 1 and 3 with cyclic / per-point boundaries; interp_order %d or "
                          "LC_X_CLAMP_REFERENCE_OUTER take LC_F64_WIND_F32 (float64 images of the float32 wind)", interp_order);
             return LC_EUNSUPPORTED;
         }
+        if (interp_order == 1)
+            LC_REQUIRE(packed_lin && !packed_cub && !u_raw && !v_raw, "lc_advect: LC_F64_WIND_F32_LIN32 at order 1 takes packed_lin (the float32 order-1 image) and nothing else");
+        else
+            LC_REQUIRE(packed_cub && u_raw && v_raw && !packed_lin, "lc_advect: LC_F64_WIND_F32_LIN32 at order 3 takes packed_cub (float64 coefficients: "
+                       "lc_field_pack with LC_F64_WIND_F32) and the float32 planes as u_raw / v_raw");
     }
     if (interp_order < 1 || interp_order > 5) {
         lc_set_error("lc_advect: interp_order %d unsupported (scipy's spline orders 1..5; 0 fails in the reference too)",
@@ -3913,7 +4093,7 @@ extern "C" int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args) {
         return LC_EUNSUPPORTED;
     }
     LC_REQUIRE((u_raw == nullptr) == (v_raw == nullptr), "lc_advect_ex: u_raw and v_raw must both be set or both NULL");
-    const bool raw_ok = raw_replaces_lin(u_raw, v_raw, dtype, interp_order);
+    const bool raw_ok = raw_replaces_lin(u_raw, v_raw, dtype, interp_order) || dtype == LC_F64_WIND_F32_LIN32;
     LC_REQUIRE(packed_lin || raw_ok, "lc_advect: packed_lin is required (the order-1 image: pole rows use order 1) unless lc_advect_ex is "
                "given the raw planes u_raw / v_raw -- and in LC_F32 at interp_order 1 always");
     if (!raw_ok) u_raw = v_raw = nullptr;  // (float32 at order 1 reads the lin image's 16-byte node pairs)
@@ -3948,11 +4128,11 @@ extern "C" int lc_advect_ex(lc_ctx *ctx, const lc_advect_args *args) {
                                   lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                   interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start, 0,
                                   n_members, t0_stride, 0);
-    if (dtype == LC_F64_WIND_F32_LIN32)
-        return advect_impl<double>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
+    if (dtype == LC_F64_WIND_F32_LIN32)   // (order 1: the float32 image; order 3: the float64 coefficients + the float32 planes)
+        return advect_impl<double>(ctx, nullptr, interp_order == 3 ? packed_cub : nullptr, nullptr, nullptr, nullptr, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
                                    lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                    interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start,
-                                   1, n_members, t0_stride, 0, packed_lin);
+                                   1, n_members, t0_stride, 0, interp_order == 1 ? packed_lin : u_raw, interp_order == 3 ? v_raw : nullptr);
     return advect_impl<double>(ctx, packed_lin, packed_cub, packed_ext, u_raw, v_raw, nt, ny_f, nx_f, lat_min, lat_max, lon_min,
                                lon_max, seed_lat_dev, ny, seed_lon_dev, nx, row0, ny_global, timestep, settls_order,
                                interp_order, cyclic_x, t0, nsteps, x_out, y_out, traj_x, traj_y, x_start, y_start,

@@ -292,7 +292,10 @@ extern "C" size_t lc_packed_elems(int nt, int ny_f, int nx_f) {
 extern "C" int lc_field_pack(lc_ctx *ctx, const void *u_dev, const void *v_dev, int dtype, int nt, int ny_f, int nx_f,
                              int interp_order, void *packed_dev, void *ext_dev) {
     LC_REQUIRE(ctx, "lc_field_pack: null context");
-    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, "lc_field_pack: bad dtype %d", dtype);
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64 || dtype == LC_F64_WIND_F32, "lc_field_pack: bad dtype %d", dtype);
+    LC_REQUIRE(dtype != LC_F64_WIND_F32 || (interp_order >= 2 && packed_dev && !ext_dev),
+               "lc_field_pack: LC_F64_WIND_F32 (float32 planes in, float64 spline coefficients out) is for interp_order 2..5 without ext_dev; "
+               "at order 1 pack the float32 wind as LC_F32");
     LC_REQUIRE(u_dev && v_dev, "lc_field_pack: null pointer");
     LC_REQUIRE(packed_dev || (interp_order == 1 && ext_dev && nt >= 2),
                "lc_field_pack: packed_dev may only be NULL at interp_order 1 with ext_dev set (fused-level image alone)");

@@ -9,6 +9,8 @@
 // Node (y, x) of the field sits at padded position (y+1, x+1).  Pad nodes hold
 // the mirrored interior value (i -> |i| reflected about 0 and n-1), which is
 // the tap rule scipy applies to out-of-range spline taps.
+#include <type_traits>
+
 #include "lcs_common.h"
 
 namespace {
@@ -21,8 +23,10 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
 }
 
 // interior nodes: packed[t][y+1][x+1] = {u[t][y][x], v[t][y][x]}
-template <typename T>
-__global__ void pack_interior_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ packed,
+// TIN: the element type of the raw planes (float for LC_F64_WIND_F32: a float32 wind whose spline coefficients scipy forms
+// in double -- spline_filter(output=float64) inside map_coordinates, LCS/tools.py:26-30)
+template <typename T, typename TIN = T>
+__global__ void pack_interior_kernel(const TIN *__restrict__ u, const TIN *__restrict__ v, T *__restrict__ packed,
                                      int ny, int nx, size_t n_nodes_total) {
     const size_t plane = (size_t)ny * nx;
     const int pitch = nx + LC_PAD;
@@ -34,8 +38,8 @@ __global__ void pack_interior_kernel(const T *__restrict__ u, const T *__restric
         const int y = (int)(r / nx);
         const int x = (int)(r - (size_t)y * nx);
         const size_t o = (t * level + (size_t)(y + LC_PAD_LO) * pitch + (x + LC_PAD_LO)) * 2;
-        packed[o] = u[i];
-        packed[o + 1] = v[i];
+        packed[o] = (T)u[i];
+        packed[o + 1] = (T)v[i];
     }
 }
 
@@ -104,19 +108,14 @@ __device__ void prefilter_line(T *c, size_t stride, int n) {
 
 // Same recursion, marching in blocks of 8 elements whose loads are issued together: the march
 // is a dependent chain per line, so memory latency (not bandwidth) is what must be overlapped.
-// ``src`` / ``sstride``: where the causal pass READS the line (the raw field, so that the interleave and the
-// latitude sweep are one pass over the data); NULL = in place.
-template <typename T>
-__device__ void prefilter_line_blocked(T *c, size_t stride, int n, const T *src = nullptr, size_t sstride = 0) {
+// ``src`` / ``sstride``: where the causal pass READS the line (the raw field -- of element type TIN --, so that the
+// interleave and the latitude sweep are one pass over the data).
+template <typename T, typename TIN = T>
+__device__ void prefilter_line_blocked(T *c, size_t stride, int n, const TIN *src, size_t sstride) {
     constexpr int B = 8;
     const double z = -0.26794919243112270647, gain = 6.0;
-    if (!src) {
-        src = c;
-        sstride = stride;
-    }
     if (n < 2 * B) {
-        if (src != c)
-            for (int i = 0; i < n; ++i) c[(size_t)i * stride] = src[(size_t)i * sstride];
+        for (int i = 0; i < n; ++i) c[(size_t)i * stride] = (T)src[(size_t)i * sstride];
         prefilter_line<T>(c, stride, n);
         return;
     }
@@ -259,8 +258,8 @@ __global__ void prefilter_general_kernel(T *__restrict__ packed, int nt, int ny,
 // threads touch consecutive elements, so every step of the march is coalesced.
 // The causal pass reads the RAW field (u / v planes) and writes the interleaved image: the separate interleave
 // pass (pack_interior_kernel, one write + one read of the whole image) is folded into the sweep.
-template <typename T>
-__global__ void prefilter_cols_kernel(const T *__restrict__ u, const T *__restrict__ v, T *__restrict__ packed, int nt, int ny,
+template <typename T, typename TIN = T>
+__global__ void prefilter_cols_kernel(const TIN *__restrict__ u, const TIN *__restrict__ v, T *__restrict__ packed, int nt, int ny,
                                       int nx) {
     const int pitch = nx + LC_PAD;
     const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
@@ -270,8 +269,8 @@ __global__ void prefilter_cols_kernel(const T *__restrict__ u, const T *__restri
     const size_t t = i / ((size_t)nx * 2);
     const size_t xc = i - t * (size_t)nx * 2;  // x*2 + component
     T *c = packed + t * level + ((size_t)LC_PAD_LO * pitch + LC_PAD_LO) * 2 + xc;
-    const T *src = ((xc & 1) ? v : u) + t * (size_t)ny * nx + (xc >> 1);
-    prefilter_line_blocked<T>(c, (size_t)pitch * 2, ny, src, (size_t)nx);
+    const TIN *src = ((xc & 1) ? v : u) + t * (size_t)ny * nx + (xc >> 1);
+    prefilter_line_blocked<T, TIN>(c, (size_t)pitch * 2, ny, src, (size_t)nx);
 }
 
 // axis 1 (longitude): one thread per (level, row, component).
@@ -403,7 +402,8 @@ __global__ void __launch_bounds__(64) prefilter_rows_lds_kernel(T *__restrict__ 
 // ======================================================================================
 constexpr int PS_C = 16, PS_H = 32, PS_W = PS_C + PS_H;  // latitude sweep: nodes finished per round, lookahead, register window
 
-__global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const double *__restrict__ u, const double *__restrict__ v,
+template <typename TIN>
+__global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const TIN *__restrict__ u, const TIN *__restrict__ v,
                                                                     double *__restrict__ packed, int nt, int ny, int nx) {
     const double z = -0.26794919243112270647, gain = 6.0, zend = z / (z * z - 1.0);
     const int pitch = nx + LC_PAD;
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const double
     const size_t xc = i - t * (size_t)nx * 2;  // x*2 + component
     double *c = packed + t * level + ((size_t)LC_PAD_LO * pitch + LC_PAD_LO) * 2 + xc;
     const size_t cs = (size_t)pitch * 2, ss = (size_t)nx;
-    const double *src = ((xc & 1) ? v : u) + t * (size_t)ny * nx + (xc >> 1);
+    const TIN *src = ((xc & 1) ? v : u) + t * (size_t)ny * nx + (xc >> 1);
     const int n = ny;  // >= 64 (the launcher checks)
     // causal start value: the first 64 terms (prefilter_line_blocked's horizon), loads 8 deep
     double c0 = gain * src[0], zi = z;
@@ -813,11 +813,11 @@ static FirTaps cubic_fir_taps() {
     return T;
 }
 
-template <typename T>
-int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int order, T *packed, T *ext) {
+template <typename T, typename TIN = T>
+int pack_impl(lc_ctx *ctx, const TIN *u, const TIN *v, int nt, int ny, int nx, int order, T *packed, T *ext) {
     const size_t nodes = (size_t)nt * ny * nx;
     const int threads = 256;
-    if (order == 1) {
+    if constexpr (std::is_same<T, TIN>::value) if (order == 1) {
         // (grid.y and grid.z are capped at 65535 blocks: the kernel loops over what is beyond)
         const int nchunk = (nt + PACK_LV - 1) / PACK_LV;
         hipLaunchKernelGGL(pack_fused_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nchunk < 65535 ? nchunk : 65535),
@@ -826,7 +826,7 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
         return LC_OK;
     }
     const int blocks = (int)((nodes + threads - 1) / threads < 8192 ? (nodes + threads - 1) / threads : 8192);
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 && std::is_same<T, TIN>::value) {
         // float32, order 3: truncated-convolution prefilter, pads and the fused-level image in one pass over the raw
         // field (each reflection of the 14-node halo must stay inside the grid: n >= 16)
         if (order == 3 && ny >= FHALO + 2 && nx >= FHALO + 2 && ctx->fir_prefilter) {
@@ -851,11 +851,11 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
         const bool cols_stream = stream && ny >= 64;
         if constexpr (sizeof(T) == 8) {
             if (cols_stream)
-                hipLaunchKernelGGL(prefilter_cols_stream_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, ctx->stream, u, v,
+                hipLaunchKernelGGL(prefilter_cols_stream_kernel<TIN>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, ctx->stream, u, v,
                                    packed, nt, ny, nx);
         }
         if (!cols_stream)
-            hipLaunchKernelGGL(prefilter_cols_kernel<T>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
+            hipLaunchKernelGGL((prefilter_cols_kernel<T, TIN>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
                                ctx->stream, u, v, packed, nt, ny, nx);
         if (stream && nx >= RS_RING) {
             if constexpr (sizeof(T) == 8)
@@ -870,7 +870,7 @@ int pack_impl(lc_ctx *ctx, const T *u, const T *v, int nt, int ny, int nx, int o
                                ctx->stream, packed, nt, ny, nx);
         }
     } else {  // orders 2, 4, 5: generic pole lists, thread per line
-        hipLaunchKernelGGL(pack_interior_kernel<T>, dim3(blocks), dim3(threads), 0, ctx->stream, u, v, packed, ny, nx,
+        hipLaunchKernelGGL((pack_interior_kernel<T, TIN>), dim3(blocks), dim3(threads), 0, ctx->stream, u, v, packed, ny, nx,
                            nodes);
         const PoleList P = spline_poles(order);
         const size_t l0 = (size_t)nt * nx * 2, l1 = (size_t)nt * ny * 2;
@@ -907,6 +907,8 @@ int lc_launch_pack(lc_ctx *ctx, const void *u, const void *v, int dtype, int nt,
     if (dtype == LC_F32)
         return pack_impl<float>(ctx, (const float *)u, (const float *)v, nt, ny_f, nx_f, order, (float *)packed,
                                 (float *)ext);
+    if (dtype == LC_F64_WIND_F32)   // float32 planes in, float64 spline coefficients out (orders 2..5: lc_field_pack checked)
+        return pack_impl<double, float>(ctx, (const float *)u, (const float *)v, nt, ny_f, nx_f, order, (double *)packed, (double *)ext);
     return pack_impl<double>(ctx, (const double *)u, (const double *)v, nt, ny_f, nx_f, order, (double *)packed,
                              (double *)ext);
 }

@@ -339,6 +339,18 @@ class Engine:
             la, lo = lat_f.astype(dtype), lon_f.astype(dtype)
             return PackedField(None, None, None, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
                                True, 1, False, None, None, None, lin32, u32, v32)
+        if wind_f32 and interp_order == 3 and lin_image is None:
+            # ... and at order 3 (the reference's default): scipy's spline coefficients of a float32 field are float64
+            # (spline_filter(output=float64) inside map_coordinates), so the coefficient image is packed in float64 STRAIGHT from
+            # the float32 planes (lc_field_pack(LC_F64_WIND_F32): no float64 copy of the wind), and the planes themselves are the
+            # order-1 source of the pole rows.
+            u32, v32 = self.to_device(u, f32), self.to_device(v, f32)
+            cub = self._empty((n,), dtype)
+            _capi.check(self.lib.lc_field_pack(self.ctx, self._ptr(u32), self._ptr(v32), _capi.LC_F64_WIND_F32, nt, ny_f, nx_f, 3,
+                                               self._ptr(cub), None), self.lib)
+            la, lo = lat_f.astype(dtype), lon_f.astype(dtype)
+            return PackedField(None, cub, None, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
+                               True, 3, False, None, None, None, None, u32, v32)
         ud = self.to_device(u, dtype)
         vd = self.to_device(v, dtype)
         if fuse_levels is None:
@@ -499,6 +511,15 @@ class Engine:
         """``lc_advect_args`` of one call: the field's images, and its raw planes as the order-1 source where it has no
         lin image."""
         p = lambda t: t.data_ptr() if t is not None else None
+        if field.u32 is not None and field.lin32 is None and interp_order == 3 == field.order and xmode != _capi.LC_X_CLAMP_REFERENCE_OUTER:
+            # float32 wind on float64 coordinates at order 3: float64 coefficients, the float32 planes for the pole rows
+            return _capi.AdvectArgs(
+                struct_size=C.sizeof(_capi.AdvectArgs), packed_cub=p(field.cub), u_raw=p(field.u32), v_raw=p(field.v32),
+                dtype=_capi.LC_F64_WIND_F32_LIN32, nt=field.nt, ny_f=field.ny_f, nx_f=field.nx_f, lat_min=field.lat_min,
+                lat_max=field.lat_max, lon_min=field.lon_min, lon_max=field.lon_max, seed_lat_dev=p(slat), ny=int(ny),
+                seed_lon_dev=p(slon), nx=int(nx), row0=int(row0), ny_global=int(ny_global), x_start=p(sx), y_start=p(sy),
+                timestep=float(timestep), settls_order=int(K), interp_order=3, cyclic_x=int(xmode), t0=int(t0), nsteps=int(nsteps),
+                n_members=int(n_members), t0_stride=int(t0_stride), x_out=p(x), y_out=p(y), traj_x=p(tx), traj_y=p(ty), fuse_levels_raw=0)
         if field.lin32 is not None and interp_order == 1 and xmode != _capi.LC_X_CLAMP_REFERENCE_OUTER:
             # float32 wind on float64 coordinates, the wind kept float32 (prepare_field)
             return _capi.AdvectArgs(

@@ -936,9 +936,10 @@ def test_float32_wind_on_float64_coordinates_follows_numpy_promotion(eng, O, ord
     f = eng.prepare_field(u32, v32, lat, lon, order)
     assert f.dtype == np.float64 and f.wind_f32 and f.ext is None
     x, y = eng.advect(f, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
-    # order 1 keeps the wind float32 (LC_F64_WIND_F32_LIN32, per-wave LDS tiles of both levels); order 3 the generic kernel
-    assert eng.last_advect_kernel() == ("advect_lds64w_kernel<-1, true>" if order == 1 else "advect_kernel<double, 3, false, 0>")
-    assert (f.lin32 is not None and f.u is None) == (order == 1)
+    # the wind stays float32 (LC_F64_WIND_F32_LIN32): per-wave LDS tiles of both levels -- of the float32 image at order 1, of the
+    # float64 coefficients packed straight from the float32 planes at order 3
+    assert eng.last_advect_kernel() == ("advect_lds64w_kernel<-1, true>" if order == 1 else "advect_lds64w_o3_kernel<-1, true>")
+    assert f.u is None and f.u32 is not None and (f.lin32 is not None) == (order == 1) and (f.cub is not None) == (order == 3)
     xr_, yr_ = O.parcel_propagation(u32, v32, lat, lon, timestep=-3600.0, SETTLS_order=3, interp_order=order,
                                     cyclic_xboundary=True)
     assert xr_.dtype == np.float64
@@ -1006,6 +1007,47 @@ def test_float32_wind_kept_float32_equals_the_float64_images_bit_for_bit(eng, O,
     import ctypes
     with pytest.raises(ValueError, match="LC_F64_WIND_F32_LIN32"):
         _capi.check(eng.lib.lc_advect_ex(eng.ctx, ctypes.byref(a)), eng.lib)
+
+
+@pytest.mark.parametrize("K,cyclic", [(4, True), (2, True), (4, False), (0, True)])
+def test_float32_wind_kept_float32_at_order3_equals_the_float64_planes_form_bit_for_bit(eng, K, cyclic):
+    """LC_F64_WIND_F32_LIN32 at interp_order 3 (the reference's default order on float32 reanalysis winds): the float64 spline
+    coefficients packed straight from the float32 planes (lc_field_pack(LC_F64_WIND_F32)) equal those of a float64 copy of
+    the wind, and the per-wave-tile kernel -- scipy's weights and tap order, numpy's index map, two samples per iteration
+    rounded to float32 -- equals the generic kernel on float64 planes bit for bit: departure points, trajectories, a row
+    block with a continuation, pole rows (order 1 from the float32 planes), LDS and direct kernels, sparse and dense seeds."""
+    u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
+    u, v, lat, lon = u * np.float32(2.0), v, lat.astype(np.float64), lon.astype(np.float64)
+    f_new = eng.prepare_field(u, v, lat, lon, 3)
+    f_old = eng.prepare_field(u, v, lat, lon, 3, lin_image=False)            # float64 planes (round 4)
+    assert f_new.u32 is not None and f_new.u is None and f_old.u is not None and f_old.u32 is None
+    assert np.array_equal(_np(f_new.cub), _np(f_old.cub))
+    for sny, snx in ((150, 200), (40, 60), (300, 512), (72, 144)):
+        slat, slon = flows.seed_grid(sny, snx, lat, lon)
+        try:
+            for mode in (-1, 0):
+                eng.set_lds_tiles(mode)
+                out = []
+                for f in (f_old, f_new):
+                    r = eng.advect(f, slat, slon, -1800.0, SETTLS_order=K, interp_order=3, cyclic_xboundary=cyclic,
+                                   noncyclic_clamp="pointwise", return_traj=True)
+                    name = eng.last_advect_kernel()
+                    lo, hi = 0, sny // 2
+                    rb = eng.advect(f, slat[lo:hi], slon, -1800.0, SETTLS_order=K, interp_order=3, cyclic_xboundary=cyclic,
+                                    noncyclic_clamp="pointwise", row0=lo, ny_global=sny, t0=3, nsteps=5, start=(r[2][3][lo:hi], r[3][3][lo:hi]))
+                    out.append(([_np(t) for t in r] + [_np(t) for t in rb], name))
+                (a, na), (b, nb) = out
+                assert na == "advect_kernel<double, 3, false, 0>", na
+                assert nb == ("advect_lds64w_o3_kernel<%s, %s>" % (4 if K == 4 else -1, "true" if cyclic else "false") if mode == -1 else "advect_kernel<double, 3, false, 0>"), nb
+                for p_, q_ in zip(a, b):
+                    assert p_.dtype == np.float64 and np.array_equal(p_, q_), (sny, snx, mode, na, nb)
+        finally:
+            eng.set_lds_tiles(-1)
+    # order 1 on such a field ("order 1 is always available") takes float64 planes made on demand
+    slat, slon = flows.seed_grid(60, 90, lat, lon)
+    a = eng.advect(f_new, slat, slon, -1800.0, K, 1, cyclic, noncyclic_clamp="pointwise")
+    b = eng.advect(f_old, slat, slon, -1800.0, K, 1, cyclic, noncyclic_clamp="pointwise")
+    assert f_new.u is not None and all(np.array_equal(_np(p_), _np(q_)) for p_, q_ in zip(a, b))
 
 
 @pytest.mark.parametrize("order", [1, 3])
