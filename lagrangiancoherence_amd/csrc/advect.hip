@@ -79,6 +79,7 @@ struct AdvectArgs {
     int traj_line_ok;            // two-seed kernel, PATCH_LINES: nx % 4 == 0 and traj bases 16-byte aligned (whole-line stores)
     int patch_mode;              // two-seed kernel: -1 by call (PATCH_LINES with trajectories, else PATCH_TALL), or a Patch value
     int xcd_rows;                // tile rows per XCD chunk (xcd_chunk = xcd_rows * ntx, recomputed when a launcher changes ntx)
+    int xcd_split;               // > 0: a chunk is 1 / xcd_split of that (lcplan::xcd_chunk_tiles)
     int ntx, ntiles;
     int xcd_chunk;  // tiles per chunk of the XCD-cyclic tile order; 0: one contiguous band of tiles per XCD
     int tile_order;  // 0 as stored, 1 last tile row first, 2 from the poles inwards (xcd_tile_id)
@@ -1242,17 +1243,25 @@ __device__ __forceinline__ unsigned lds_address(const void *shared_ptr) {
 // LDS busy 81 % -> 52 % of the cycles).  The load/store optimiser pairs plain loads; volatile ones are left alone.
 typedef volatile lds_f2 lds_node;
 
-template <int LT_PITCH>
+// NOPS: two wait states in front of the multiply-add.  Its SGPR operand is loop-invariant, but under register pressure hipcc
+// parks it in a VGPR lane and reloads it (v_readlane_b32) right before the use -- a VALU-written SGPR read by a VALU
+// instruction needs 2 wait states on gfx950, and hipcc does not insert them in front of asm (tools/asm_hazards.py found
+// exactly that in the order-3 verify instance, the one kernel with the pressure; the product instances carry no such
+// reload, which tests/test_asm_hazards.py checks on every build).
+template <int LT_PITCH, bool NOPS = false>
 __device__ __forceinline__ lds_node *window_origin(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry) {
     unsigned row_addr;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(tile_addr));
+    if (NOPS)
+        asm("s_nop 1\n\tv_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(tile_addr));
+    else
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row_addr) : "v"(ry), "s"(pitch_bytes), "v"(tile_addr));
     return (lds_node *)(size_t)(row_addr + ((unsigned)rx << 3));
 }
 
 // order 1: the 2x2 window and its two lerps
-template <int LT_PITCH>
+template <int LT_PITCH, bool NOPS = false>
 __device__ __forceinline__ f2 window_lds1(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry, const TapL &t) {
-    lds_node *p = window_origin<LT_PITCH>(tile_addr, pitch_bytes, rx, ry);
+    lds_node *p = window_origin<LT_PITCH, NOPS>(tile_addr, pitch_bytes, rx, ry);
     const f2 n00 = p[0], n01 = p[1], n10 = p[LT_PITCH], n11 = p[LT_PITCH + 1];
     const f2 r0 = n00 + t.tx * (n01 - n00);
     const f2 r1 = n10 + t.tx * (n11 - n10);
@@ -1299,9 +1308,9 @@ __device__ __forceinline__ f2 cubic_apply(const f2 (&q)[4][4], const TapL &t, f2
     }
     return acc;
 }
-template <int LT_PITCH>
+template <int LT_PITCH, bool NOPS = false>
 __device__ __forceinline__ f2 window_lds3(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry, const TapL &t, f2 start) {
-    lds_node *p = window_origin<LT_PITCH>(tile_addr, pitch_bytes, rx, ry);
+    lds_node *p = window_origin<LT_PITCH, NOPS>(tile_addr, pitch_bytes, rx, ry);
     f2 q[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -1312,10 +1321,10 @@ __device__ __forceinline__ f2 window_lds3(unsigned tile_addr, unsigned pitch_byt
 }
 
 // returns start + interpolated (u, v)
-template <int ORDER, int LT_PITCH>
+template <int ORDER, int LT_PITCH, bool NOPS = false>
 __device__ __forceinline__ f2 window_lds(unsigned tile_addr, unsigned pitch_bytes, int rx, int ry, const TapL &t, f2 start) {
-    if (ORDER == 3) return window_lds3<LT_PITCH>(tile_addr, pitch_bytes, rx, ry, t, start);
-    return start + window_lds1<LT_PITCH>(tile_addr, pitch_bytes, rx, ry, t);
+    if (ORDER == 3) return window_lds3<LT_PITCH, NOPS>(tile_addr, pitch_bytes, rx, ry, t, start);
+    return start + window_lds1<LT_PITCH, NOPS>(tile_addr, pitch_bytes, rx, ry, t);
 }
 
 template <int ORDER>
@@ -1563,7 +1572,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
                 const int rx = t.x0 - lx, ry = t.y0 - ly;
                 bad |= ((unsigned)rx > (unsigned)(hx - lx)) | ((unsigned)ry > (unsigned)(hy - ly)) | (hx < lx) | (hy < ly);
                 const unsigned ebase = etile_addr + (unsigned)(lx - sox) * 8u + (unsigned)(ly - soy) * ((unsigned)E::PITCH * 8u);
-                e = window_lds<ORDER, E::PITCH>(ebase, epitch_bytes, rx, ry, t, zero);
+                e = window_lds<ORDER, E::PITCH, VERIFY>(ebase, epitch_bytes, rx, ry, t, zero);
             } else {
                 e = window_global<ORDER>(lvl, A, t, zero);
             }
@@ -1617,7 +1626,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
             TapL t = tap_of(to_index(p));
             const int rx = t.x0 - lo_x, ry = t.y0 - lo_y;  // the subtrahends are wave-uniform (SGPRs)
             bool bad = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
-            const f2 ew = window_lds<ORDER, LT_PITCH>(base_addr, pitch_bytes, rx, ry, t, e);  // e + sample of ext[t]
+            const f2 ew = window_lds<ORDER, LT_PITCH, VERIFY>(base_addr, pitch_bytes, rx, ry, t, e);  // e + sample of ext[t]
             f2 pn = hd * ew + p;
             bad |= x_needs_care(pn.x);
             if (bad) {  // exact sequence, global gather
@@ -2452,7 +2461,7 @@ struct LdsLaunch<float, ORDER> {
                 A.ntx = (A.nx + TILE_W * 4 - 1) / (TILE_W * 4);
                 nty = (A.ny + 8 * SPL - 1) / (8 * SPL);
             }
-            A.xcd_chunk = A.xcd_rows * A.ntx;
+            A.xcd_chunk = lcplan::xcd_chunk_tiles(A.ntx, nty, A.xcd_rows, A.xcd_split);
             A.ntiles = A.ntx * nty;
             A.tile_order = A.tile_order_two_seed;
             const int g2 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
@@ -2491,7 +2500,7 @@ struct LdsLaunch<float, ORDER> {
                 A.ntx = (A.nx + TILE_W * 4 - 1) / (TILE_W * 4);
                 nty = (A.ny + 8 * SPL - 1) / (8 * SPL);
             }
-            A.xcd_chunk = A.xcd_rows * A.ntx;
+            A.xcd_chunk = lcplan::xcd_chunk_tiles(A.ntx, nty, A.xcd_rows, A.xcd_split);
             A.ntiles = A.ntx * nty;
             const int g2 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
 #define LC_LDS2O3(KF, CY, MD, NAME)                                                                       \
@@ -2529,8 +2538,9 @@ struct LdsLaunch<float, ORDER> {
         int g1 = grid;
         if (lines) {
             A.ntx = (A.nx + TILE_W * 4 - 1) / (TILE_W * 4);
-            A.ntiles = A.ntx * ((A.ny + 7) / 8);
-            A.xcd_chunk = A.xcd_rows * A.ntx;
+            const int nty = (A.ny + 7) / 8;
+            A.ntiles = A.ntx * nty;
+            A.xcd_chunk = lcplan::xcd_chunk_tiles(A.ntx, nty, A.xcd_rows, A.xcd_split);
             g1 = xcd_grid(A.ntiles, A.xcd_chunk) + A.pole_blocks;
         }
 #define LC_LDS1(KF, CY, LN, NAME)                                                                                       \
@@ -2578,6 +2588,24 @@ struct LdsLaunch<float, ORDER> {
 // ======================================================================================
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// trajectory.py:89-97 for the fast float64 family (direct and LDS-tile kernels alike: one function, so a seed's bits do not
+// depend on which served it): the values of clamp_position<double> -- fmax(NaN, y_min) = y_min is Q8's rule, and a finite y
+// comes out as the two selects give it -- in v_max_f64 + v_min_f64 instead of two compares and four 32-bit selects, and the
+// cyclic wrap's two rare cases behind ONE test of |x| (round 5: the float64 order-1 kernel issues VALU in 0.67 of its
+// cycles, 65 instructions per sample; these were 8 of them).
+__device__ __forceinline__ void clamp_position_fast64(const AdvectArgs<double> &A, double &x, double &y) {
+    y = fmin(fmax(y, A.y_min), A.y_max);
+    if (A.cyclic) {
+        if (!(fabs(x) < 180.0)) {  // rare: the exact reference sequence, trajectory.py:93-94 (Q7)
+            if (!(x > -180.0)) x = pymod180<double>(x);
+            if (!(x < 180.0)) x = -180.0 + pymod180<double>(x);
+        }
+    } else if (x < A.x_min || x > A.x_max) {
+        if (A.clamp_flag) *A.clamp_flag = 1u;
+        x = x < A.x_min ? A.x_min : A.x_max;
+    }
+}
 
 // The two halves of a fast float64 sample, shared by the direct-gather kernel and the LDS-tile kernel below so that a
 // seed's result never depends on which of the two served it: explicit operations, no contraction left to the compiler.
@@ -2786,12 +2814,12 @@ __device__ void advect_seed_fast64_o3(const AdvectArgs<double> &A, int iy, int i
         const d2 e = sample_fast64_o3(lvl, A, x, y, zero);   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                             // :86
         x = fma(dtcx, e.x, x);                               // :87
-        clamp_position<double>(A, x, y);                     // :89-97
+        clamp_position_fast64(A, x, y);                     // :89-97
         for (int k = 0; k < A.K; ++k) {                      // :100
             const d2 d = A.ext_cub ? sample_fast64_o3_fused(lvl, A, x, y, e) : sample_fast64_o3(elv, A, x, y, e);  // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
             y = fma(A.hdtcy, d.y, y);
             x = fma(hdtcx, d.x, x);
-            clamp_position<double>(A, x, y);
+            clamp_position_fast64(A, x, y);
         }
         if (A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = x;
@@ -2827,12 +2855,12 @@ __device__ void advect_seed_fast64(const AdvectArgs<double> &A, int iy, int ix) 
         const d2 e = RAW ? sample_fast64_raw(lvl, A, x, y) : sample_fast64(lvl, A, x, y);   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                        // :86
         x = fma(dtcx, e.x, x);                          // :87
-        clamp_position<double>(A, x, y);                // :89-97
+        clamp_position_fast64(A, x, y);                // :89-97
         for (int k = 0; k < A.K; ++k) {                 // :100
             const d2 d = e + (EXTRAW ? sample_ext_fast64_raw(lvl, A, x, y) : sample_fast64(elv, A, x, y));   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
             y = fma(A.hdtcy, d.y, y);
             x = fma(hdtcx, d.x, x);
-            clamp_position<double>(A, x, y);
+            clamp_position_fast64(A, x, y);
         }
         if (A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = x;
@@ -2963,31 +2991,35 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
         const d2 e = RAW ? sample_fast64_raw(lvl, A, x, y) : sample_fast64(lvl, A, x, y);   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                        // :86
         x = fma(dtcx, e.x, x);                          // :87
-        clamp_position<double>(A, x, y);                // :89-97
+        clamp_position_fast64(A, x, y);                // :89-97
         dprev_x = (x - x0p) * A.sx;
         dprev_y = (y - y0p) * A.sy;
         // ---- 3. tile into LDS ------------------------------------------------------------------------------------
-        int lo_x = 0x40000000, lo_y = 0x40000000, lim_x = 0, lim_y = 0;  // no tile: nothing is "inside"
+        // window origins (x0, y0) the tile serves: [acc_x, acc_x + acc_w] x [acc_y, acc_y + acc_h] (one unsigned compare per axis);
+        // tile-relative index = x0 - lo_x.  No tile: nothing is "inside" (x0 - 2^30 wraps to a huge unsigned number)
+        int lo_x = 0, lo_y = 0, acc_x = 0x40000000, acc_y = 0x40000000, acc_w = 0, acc_h = 0;
         if (K > 0) {
             __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
 #pragma unroll
             for (int r = 0; r < T64_ROWS / 4; ++r) tile[(r * 4 + st_row) * T64_PITCH + st_col] = stage[r];
             __builtin_amdgcn_wave_barrier();
-            // window origins (x0, y0) the tile serves: inside it (padded origin = (y0 + 1, x0 + 1)) and in [0, n - 2]
+            // inside the tile (padded origin = (y0 + 1, x0 + 1)) and in [0, n - 2]
             const int sox = ox - LC_PAD_LO, soy = oy - LC_PAD_LO;
             const int hx = min(sox + T64_COLS - 2, A.nx_f - 2), hy = min(soy + T64_ROWS - 2, A.ny_f - 2);
             const int lx = max(sox, 0), ly = max(soy, 0);
             if (hx >= lx && hy >= ly) {
-                lo_x = sox;      // tile-relative index = x0 - sox; accepted range [lx - sox, hx - sox]
+                lo_x = sox;
                 lo_y = soy;
-                lim_x = hx;
-                lim_y = hy;
+                acc_x = lx;
+                acc_y = ly;
+                acc_w = hx - lx;
+                acc_h = hy - ly;
             }
         }
         // ---- 4. K iterations out of LDS ---------------------------------------------------------------------------
         for (int k = 0; k < K; ++k) {
             const Loc64 t = locate_fast64(A, x, y);
-            const bool in_tile = t.x0 >= max(lo_x, 0) && t.x0 <= lim_x && t.y0 >= max(lo_y, 0) && t.y0 <= lim_y && lo_x != 0x40000000;
+            const bool in_tile = ((unsigned)(t.x0 - acc_x) <= (unsigned)acc_w) & ((unsigned)(t.y0 - acc_y) <= (unsigned)acc_h);
             d4 a, b;
             if (in_tile) {
                 const d2 *w = tile + (t.y0 - lo_y) * T64_PITCH + (t.x0 - lo_x);
@@ -3022,7 +3054,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
             const d2 d = e + lerp_fast64(a, b, t.tx, t.ty);   // e + (2 F[t] - F[t+1])(x, y)
             y = fma(A.hdtcy, d.y, y);
             x = fma(hdtcx, d.x, x);
-            clamp_position<double>(A, x, y);
+            clamp_position_fast64(A, x, y);
         }
         if (live && A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = x;
@@ -3159,7 +3191,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_
         const d2 e = sample(lvl, etile, eox, eoy, true, x, y, zero, ERows(), EPitch(), OneLevel());   // trajectory.py:82-84
         y = fma(A.dtcy, e.y, y);                                        // :86
         x = fma(dtcx, e.x, x);                                          // :87
-        clamp_position<double>(A, x, y);                                // :89-97
+        clamp_position_fast64(A, x, y);                                // :89-97
         // ---- 2. tile of ext[t] anchored on the travel this level's Euler displacement predicts -----------------------
         int ox = 0, oy = 0;
         if (K > 0) {
@@ -3175,7 +3207,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_O3_MINWAVES) advect_lds64_o3_
             const d2 d = sample(elv, gtile, ox, oy, true, x, y, e, GRows(), GPitch(), IterLevels());   // e + (2 F[t] - F[t+1])(x, y): :105-112 in one sample
             y = fma(A.hdtcy, d.y, y);
             x = fma(hdtcx, d.x, x);
-            clamp_position<double>(A, x, y);
+            clamp_position_fast64(A, x, y);
         }
         if (live && A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = x;
@@ -3582,6 +3614,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.traj_line_ok = (nx % 4 == 0) && ((size_t)traj_x % 16 == 0) && ((size_t)traj_y % 16 == 0) && sizeof(T) == 4;
     A.patch_mode = ctx->patch_mode;
     A.xcd_rows = ctx->xcd_chunk_rows;
+    A.xcd_split = ctx->xcd_split;
     A.lin = (const T *)packed_lin;
     A.img = (order != 1) ? (const T *)packed_cub : (const T *)packed_lin;
     A.ext = (order == 1 || order == 3) ? (const T *)packed_ext : nullptr;  // general orders: two-sample form
@@ -3640,7 +3673,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     A.ntx = (nx + TILE_W - 1) / TILE_W;
     const int nty = (ny + TILE_H - 1) / TILE_H;
     A.ntiles = A.ntx * nty;
-    A.xcd_chunk = ctx->xcd_chunk_rows * A.ntx;
+    A.xcd_chunk = lcplan::xcd_chunk_tiles(A.ntx, nty, ctx->xcd_chunk_rows, ctx->xcd_split);
     A.tile_order = ctx->tile_order >= 0 ? ctx->tile_order : 1;
     A.tile_order_two_seed = ctx->tile_order >= 0 ? ctx->tile_order : 2;
     {   // leading workgroups for the global pole rows present in this block of seed rows

@@ -48,6 +48,8 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     if (const char *ev = getenv("LCS_LDS_TILES")) c->lds_tiles = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : (ev[0] == '1' ? 1 : 3));  // read once, here
     c->xcd_chunk_rows = 1;  // tile rows dealt to the XCDs cyclically (measured: C3 -1.7 %, C4 -2.8 %, C5 -5 % against contiguous bands)
     if (const char *ev = getenv("LCS_XCD_CHUNK_ROWS")) c->xcd_chunk_rows = atoi(ev) > 0 ? atoi(ev) : 0;  // read once, here
+    c->xcd_split = -1;  // by the launch's shape (lcplan::xcd_chunk_tiles)
+    if (const char *ev = getenv("LCS_XCD_SPLIT")) c->xcd_split = atoi(ev) >= 0 ? atoi(ev) : -1;  // read once, here (0: whole tile rows always)
     c->tile_order = -1;
     if (const char *ev = getenv("LCS_TILE_ORDER")) c->tile_order = (ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : -1;  // read once, here
     c->pole_blocks = 1;

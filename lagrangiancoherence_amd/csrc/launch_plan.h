@@ -37,6 +37,22 @@ LCP_HD int tile_of_block(int b, int ntiles, int ntx, int xcd_chunk, int tile_ord
     }
     return d;
 }
+// Tiles per XCD chunk.  xcd_rows whole tile rows (0: contiguous bands) go to the XCDs cyclically -- which leaves one XCD with
+// an extra chunk whenever the number of chunks is not a multiple of 8: 17 tile rows are 3 + 7 x 2, the launch ends when the
+// XCD with 3 does (1084 x 8192 seeds: 7.19 ms against 5.06).  xcd_split > 0: a chunk is a 1 / xcd_split part of that (split
+// 8: every tile row is dealt to all eight XCDs in ntx / 8-tile segments: equal shares whatever the row count, at ~4 % on
+// launches that divide evenly anyway -- neighbouring tiles of a row share wind nodes, and eight times as many of them
+// then sit on different L2s).  xcd_split < 0 (the default): split 8 exactly when whole chunks would leave the XCDs more
+// than 15 % apart (profiles/r05/xcd_split_ab.txt).
+LCP_HD int xcd_chunk_tiles(int ntx, int nty, int xcd_rows, int xcd_split) {
+    if (xcd_rows <= 0) return 0;
+    const int whole = xcd_rows * ntx;
+    if (xcd_split < 0) {
+        const int nch = (nty + xcd_rows - 1) / xcd_rows, full = (nch + XCDS - 1) / XCDS * XCDS;
+        xcd_split = (full - nch) * 100 > 15 * nch ? XCDS : 0;
+    }
+    return xcd_split > 0 ? imax((whole + xcd_split - 1) / xcd_split, 1) : whole;
+}
 // Blocks to launch so that every tile has one (excluding the pole blocks).
 LCP_HD int xcd_grid(int ntiles, int xcd_chunk) {
     if (xcd_chunk <= 0) return ((ntiles + XCDS - 1) / XCDS) * XCDS;
@@ -142,12 +158,12 @@ LCP_HD int outer_restart(int s0, bool have_saved) { return (s0 > 0 && !have_save
 struct TileGrid {
     int ntx, nty, ntiles, xcd_chunk, grid;  // grid: blocks incl. the pole blocks
 };
-LCP_HD TileGrid tile_grid(int ny, int nx, int w, int h, int xcd_rows, int pole_blocks) {
+LCP_HD TileGrid tile_grid(int ny, int nx, int w, int h, int xcd_rows, int pole_blocks, int xcd_split = 0) {
     TileGrid t;
     t.ntx = (nx + w - 1) / w;
     t.nty = (ny + h - 1) / h;
     t.ntiles = t.ntx * t.nty;
-    t.xcd_chunk = xcd_rows * t.ntx;
+    t.xcd_chunk = xcd_chunk_tiles(t.ntx, t.nty, xcd_rows, xcd_split);
     t.grid = xcd_grid(t.ntiles, t.xcd_chunk) + pole_blocks;
     return t;
 }

@@ -17,6 +17,7 @@ struct lc_ctx {
     int lds_tiles;       // lc_advect float32 kernel choice: 3 LDS tiles, seeds per lane by size (default); 1 two seeds, 2 one seed per lane; 0 direct gathers (LCS_LDS_TILES at creation)
     int lds_tiles_init, sigma_march_init;  // what lc_ctx_create set (environment or built-in default): what -1 restores
     int sigma_march;     // lc_sigma float32 kernel choice: 2 by size (default: marching kernel from 2^23 cells), 1 marching kernel with wavefront shuffles, 0 LDS tiles (LCS_SIGMA_MARCH at creation)
+    int xcd_split;       // lc_advect tile order: > 0 = a chunk is 1 / xcd_split of xcd_chunk_rows tile rows; -1 (default) = 8 when whole chunks would leave the XCDs > 15 % apart, else 0 (LCS_XCD_SPLIT at creation)
     int xcd_chunk_rows;  // lc_advect tile order: tile rows per chunk dealt to the XCDs cyclically; default 1; 0 = one contiguous band per XCD (LCS_XCD_CHUNK_ROWS at creation)
     int fir_prefilter;   // float32 order-3 pack: 1 one-pass truncated-convolution prefilter (default), 0 the recursive sweeps (LCS_FIR_PREFILTER at creation)
     int tile_order;      // lc_advect tile-row order: -1 per kernel (default), 0 as stored, 1 last row first, 2 poles inwards (LCS_TILE_ORDER at creation)

@@ -56,6 +56,37 @@ static void test_tile_order() {
                         CHECK(tile_of_block(0, ntiles, ntx, chunk, 1) / ntx == nty - 1, "order 1 starts at the last row");
                     ++cases;
                 }
+    // chunks that are PARTS of a tile row (xcd_chunk_tiles with a split): still one block per tile, and the XCDs' shares of
+    // the tiles differ by at most one chunk -- whatever the number of tile rows (whole rows: 17 rows are 3 + 7 x 2)
+    for (int ntx = 1; ntx <= 1100; ntx = ntx * 3 + 1)
+        for (int nty = 1; nty <= 70; nty += (nty < 20 ? 1 : 7))
+            for (int split : {-1, 0, 4, 8})
+                for (int order = 0; order <= 2; ++order) {
+                    const int ntiles = ntx * nty, chunk = xcd_chunk_tiles(ntx, nty, 1, split);
+                    CHECK(chunk >= 1 && chunk <= ntx, "chunk %d of a row of %d tiles", chunk, ntx);
+                    if (split == 0) CHECK(chunk == ntx, "no split: whole rows");
+                    if (split < 0) {   // the automatic rule: split exactly when whole rows would leave the XCDs > 15 % apart
+                        const int full = (nty + XCDS - 1) / XCDS * XCDS;
+                        CHECK((chunk < ntx || ntx < XCDS) == ((full - nty) * 100 > 15 * nty) || ntx < XCDS, "auto split: nty %d ntx %d chunk %d", nty, ntx, chunk);
+                    }
+                    const int grid = xcd_grid(ntiles, chunk);
+                    CHECK(grid % XCDS == 0 && grid >= ntiles, "grid %d ntiles %d", grid, ntiles);
+                    std::vector<int> seen(ntiles, 0);
+                    long per_xcd[XCDS] = {0};
+                    for (int b = 0; b < grid; ++b) {
+                        const int t = tile_of_block(b, ntiles, ntx, chunk, order);
+                        CHECK(t >= 0, "negative tile %d", t);
+                        if (t < ntiles) {
+                            ++seen[t];
+                            ++per_xcd[b % XCDS];
+                        }
+                    }
+                    for (int t = 0; t < ntiles; ++t) CHECK(seen[t] == 1, "tile %d visited %d times (ntx %d nty %d split %d)", t, seen[t], ntx, nty, split);
+                    long lo = per_xcd[0], hi = per_xcd[0];
+                    for (int x = 1; x < XCDS; ++x) lo = per_xcd[x] < lo ? per_xcd[x] : lo, hi = per_xcd[x] > hi ? per_xcd[x] : hi;
+                    CHECK(hi - lo <= chunk, "XCD shares %ld .. %ld with chunks of %d (ntx %d nty %d split %d)", lo, hi, chunk, ntx, nty, split);
+                    ++cases;
+                }
     std::printf("tile order: %ld launch shapes\n", cases);
 }
 

@@ -21,6 +21,73 @@ eng = Engine(0)
 K, dt = 4, -900.0
 REPS = 3
 
+# ---- a cost-weighted row partition: measured in round 5 and NOT adopted (profiles/r05/shard_costs_balanced.txt) ------------
+# Cutting the rows by measured per-band cost equalises the ranks' times -- and raises every one of them: a rank's cost is
+# not proportional to its rows at this granularity (1024 rows of C4 are 16 tile rows = 2 per XCD and 2^23 seeds, the two-seed
+# kernel's threshold; 1078 rows are 17 tile rows, 959 rows fall to the one-seed kernel).  C4 on 8 ranks: 0.70 uniform, 0.67 cut by cost.
+
+
+def balanced_bounds(weights, world: int):
+    """``world`` contiguous row blocks [(lo, hi), ...] of a grid with per-row costs ``weights`` whose total costs are as
+    equal as whole rows allow: the k-th cut is the row at which the running cost passes k / world of the total.  Every
+    block keeps at least HALO rows (what the neighbour exchange needs).  A row's advection cost is not uniform over
+    latitude -- jets and the polar convergence of the meridians stretch a wave's patch beyond its LDS tile there -- and
+    the step time of a row-sharded run is its slowest rank's (C4 on 8 ranks 11.3 ... 14.8 ms)."""
+    import numpy as np
+    w = np.asarray(weights, dtype=np.float64)
+    ny = int(w.size)
+    if ny < world * sharded.HALO or not np.all(np.isfinite(w)) or not np.all(w > 0):
+        raise ValueError("weights: one positive finite cost per row, at least HALO rows per rank")
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for k in range(1, world):
+        r = int(np.searchsorted(c, c[-1] * k / world, side="left"))
+        r = min(max(r, cuts[-1] + sharded.HALO), ny - (world - k) * sharded.HALO)    # room for this block and for every block still to come
+        cuts.append(r)
+    cuts.append(ny)
+    return [(cuts[k], cuts[k + 1]) for k in range(world)]
+
+
+def band_costs(engine, field, seed_lat_global, seed_lon, timestep, SETTLS_order=0, interp_order=1, cyclic_xboundary=True,
+               n_bands: int = 64, levels: int = 32, t0: int = 0, rank: int = 0, world: int = 1, group=None):
+    """Per-row advection cost of a seed grid, measured: the grid is cut into ``n_bands`` equal bands of rows, each band is
+    advected through the first ``levels`` time levels on its own (HIP events; the kernels the real call would take, by
+    ``Engine.concurrent_calls``), and a band's time is spread evenly over its rows.  With ``world`` > 1 the ranks share
+    the bands (band b is timed by rank b % world) and all-gather the times, so every rank returns the SAME array -- what a
+    cost-weighted partition needs.  A pilot outside any timed region: n_bands launches of a few levels each."""
+    import numpy as np
+    torch = engine.torch
+    seed_lat_global = np.asarray(seed_lat_global, dtype=field.dtype)
+    seed_lon = np.asarray(seed_lon, dtype=field.dtype)
+    nyg = seed_lat_global.size
+    n_bands = max(1, min(int(n_bands), nyg // max(sharded.HALO, 1)))
+    edges = [round(b * nyg / n_bands) for b in range(n_bands + 1)]
+    levels = max(1, min(int(levels), field.nt - 1 - t0))
+    slat_d, slon_d = engine.to_device(seed_lat_global, field.dtype), engine.to_device(seed_lon, field.dtype)
+    mine = {}
+    with engine.concurrent_calls(nyg * seed_lon.size // max(world, 1), 1):
+        for b in range(rank, n_bands, max(world, 1)):
+            lo, hi = edges[b], edges[b + 1]
+            call = lambda: engine.advect(field, slat_d[lo:hi], slon_d, timestep, SETTLS_order, interp_order, cyclic_xboundary,
+                                         t0, levels, row0=lo, ny_global=nyg)
+            call()                                      # (first touch of the band's tiles, allocator warm)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call()
+            e1.record()
+            e1.synchronize()
+            mine[b] = e0.elapsed_time(e1)
+    if world > 1:
+        import torch.distributed as dist
+        parts = [None] * world
+        dist.all_gather_object(parts, mine, group=group)
+        mine = {k: v for d in parts for k, v in d.items()}
+    w = np.empty(nyg, dtype=np.float64)
+    for b in range(n_bands):
+        w[edges[b]:edges[b + 1]] = max(mine[b], 1e-6) / (edges[b + 1] - edges[b])
+    return w
+
+
 
 def timed(fn, reps=REPS):
     fn()
@@ -34,7 +101,8 @@ def timed(fn, reps=REPS):
     return e0.elapsed_time(e1) / reps
 
 
-def row_sharded(name, ny_global, nx, nt, weak):
+def row_sharded(name, ny_global, nx, nt, weak, balance_levels=0):
+    """balance_levels > 0: the rows are cut by measured cost (sharded.band_costs over that many levels, 64 bands)."""
     u, v, lat, lon = flows.era5_like_on_device(torch, eng.device, nt=nt)
     out = {"workload": name, "nt": nt, "nx": nx, "K": K, "order": 1, "per_N": {}}
     out["pack_ms"] = timed(lambda: eng.prepare_field(u, v, lat, lon, 1))
@@ -44,9 +112,17 @@ def row_sharded(name, ny_global, nx, nt, weak):
         slat, slon = flows.seed_grid(nyg, nx, lat, lon)
         slat_d, slon_d = eng.to_device(slat, np.float32), eng.to_device(slon, np.float32)
         dlat, dlon = float(slat[1] - slat[0]), float(slon[1] - slon[0])
+        weights = None
+        if balance_levels and N > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            weights = band_costs(eng, field, slat, slon, dt, K, 1, True, n_bands=64, levels=balance_levels)
+            e1.record()
+            torch.cuda.synchronize()
+            out.setdefault("pilot_ms_all_bands_on_one_gpu", {})[N] = round(e0.elapsed_time(e1), 3)
         ranks = []
         for r in range(N):
-            lo, hi = sharded.row_partition(nyg, N, r)
+            lo, hi = balanced_bounds(weights, N)[r] if weights is not None else sharded.row_partition(nyg, N, r)
             n_lo, n_hi = sharded.halo_rows(nyg, lo, hi) if N > 1 else (0, 0)
             box = {}
 
@@ -107,6 +183,12 @@ for w in which:
         r = row_sharded("c3 strong (4096^2 in all)", 4096, 4096, 97, False)
     elif w == "c4":
         r = row_sharded("c4 strong (8192^2 x 384)", 8192, 8192, 385, False)
+    elif w.startswith("c4b"):       # c4b32: rows cut by the cost measured over the first 32 levels
+        r = row_sharded(f"c4 strong, rows cut by measured cost ({w[3:]} pilot levels)", 8192, 8192, 385, False, int(w[3:]))
+    elif w.startswith("c3sb"):
+        r = row_sharded(f"c3 strong, rows cut by measured cost ({w[4:]} pilot levels)", 4096, 4096, 97, False, int(w[4:]))
+    elif w.startswith("c3wb"):
+        r = row_sharded(f"c3 weak, rows cut by measured cost ({w[4:]} pilot levels)", 4096, 4096, 97, True, int(w[4:]))
     else:
         r = ensemble("c5 strong (64 x 2048^2 x 200)", 64, 2048, 264, 200)
     print(json.dumps(r), flush=True)
