@@ -66,8 +66,8 @@ def halo_exchange_into(x_ext, y_ext, n_lo: int, n_hi: int, rank: int, world: int
 
     ``x_ext``, ``y_ext``: ``(n_lo + n + n_hi, nx)`` buffers whose middle ``n``
     rows hold this rank's departure points; the first ``n_lo`` / last ``n_hi`` rows are filled with the
-    neighbours' boundary rows.  One message per neighbour per direction carries both arrays
-    (2 rows x nx x 2 arrays: 64 KiB at nx=4096 fp32 -- latency-bound on xGMI; no collective)."""
+    neighbours' boundary rows.  Per neighbour and direction one message per array, straight from / into the buffers
+    (2 rows x nx: 32 KiB at nx=4096 fp32 -- latency-bound on xGMI; no collective)."""
     import torch
     import torch.distributed as dist
     if world == 1:
@@ -81,18 +81,36 @@ def halo_exchange_into(x_ext, y_ext, n_lo: int, n_hi: int, rank: int, world: int
     # gloo cannot move device tensors: stage the (tiny) messages through the host.  Only used when
     # rehearsing the N>1 path without RCCL (several ranks on one GPU); nccl sends device memory.
     via_host = x_ext.is_cuda and dist.get_backend(group) == "gloo"
+    if not via_host:
+        # Row slices of a contiguous (rows, nx) buffer are contiguous: the boundary rows are sent from, and the halo rows
+        # received into, the buffers themselves -- one send and one receive per array and neighbour inside ONE batch (a
+        # single ncclGroupStart / End with the nccl backend), no staging copies, no kernel launch at all.  (Until round 5
+        # both arrays travelled in one stacked message: two gather kernels before and four copy kernels after the exchange,
+        # each a launch latency on a path that is nothing but latency.)  Both sides list x before y: point-to-point
+        # operations between a pair of ranks match in order.
+        ops = []
+        if rank > 0:           # previous rank owns the rows just below ours
+            assert n_lo == HALO
+            ops += [dist.P2POp(dist.isend, t[n_lo:n_lo + HALO], rank - 1, group) for t in (x_ext, y_ext)]
+            ops += [dist.P2POp(dist.irecv, t[:n_lo], rank - 1, group) for t in (x_ext, y_ext)]
+        if rank < world - 1:   # next rank owns the rows above ours
+            assert n_hi == HALO
+            ops += [dist.P2POp(dist.isend, t[n_lo + n - HALO:n_lo + n], rank + 1, group) for t in (x_ext, y_ext)]
+            ops += [dist.P2POp(dist.irecv, t[n_lo + n:], rank + 1, group) for t in (x_ext, y_ext)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return
 
     def msg(rows):
-        m = torch.stack([x_ext[rows], y_ext[rows]]).contiguous()
-        return m.cpu() if via_host else m
+        return torch.stack([x_ext[rows], y_ext[rows]]).contiguous().cpu()
 
     ops, recv_lo, recv_hi = [], None, None
-    if rank > 0:           # previous rank owns the rows just below ours
+    if rank > 0:
         assert n_lo == HALO
         send = msg(slice(n_lo, n_lo + HALO))
         recv_lo = torch.empty_like(send)
         ops += [dist.P2POp(dist.isend, send, rank - 1, group), dist.P2POp(dist.irecv, recv_lo, rank - 1, group)]
-    if rank < world - 1:   # next rank owns the rows above ours
+    if rank < world - 1:
         assert n_hi == HALO
         send2 = msg(slice(n_lo + n - HALO, n_lo + n))
         recv_hi = torch.empty_like(send2)
