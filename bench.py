@@ -24,8 +24,10 @@ Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the f
   algorithmic_GBps   SURVEY 8d's byte figure B_adv(K, order) x particle-timesteps / that duration (it charges every
             cache-served tap to memory, so it may exceed the HBM peak; kept for cross-round comparison only).
   hbm       compulsory bytes (every image level + seeds + outputs once), their rate as a fraction of the 8 TB/s peak,
-            and -- when a committed rocprofv3 --pmc summary was collected on exactly this csrc/ (hash-stamped) for
-            this workload -- the measured traffic per launch and its fraction; otherwise null.
+            and the measured traffic per launch and its fraction: in the default one-GPU run MEASURED BY THIS RUN (two
+            counter-only child passes of this command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE after the timed
+            region, live_traffic()); otherwise replayed from a committed rocprofv3 --pmc summary collected on exactly
+            this csrc/ (hash-stamped) for this workload, or null.
 """
 from __future__ import annotations
 
@@ -84,6 +86,133 @@ def measured_copy_peak(torch, nbytes: int = 1 << 30, reps: int = 10) -> float:
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
 
 
+def kernel_name_matches(k: str, kernel: str) -> bool:
+    """Does the profiler's (or a summary's) kernel name `k` name the kernel the library reports as `kernel`?  "name" matches
+    "name<template args>"; "name<a,b>" matches the profiler's "name<a,b,defaulted...>" (the library names a kernel by its
+    leading template arguments: trailing ones added later keep their defaults there)."""
+    kk, want = k.replace(" ", ""), kernel.replace(" ", "")
+    return kk == want or (kk.startswith(want + "<") and "<" not in want) or (want.endswith(">") and kk.startswith(want[:-1] + ","))
+
+
+# The counter sets of the live passes: one rocprofv3 --pmc pass each (what fits the SQ / TCP counter registers of one pass;
+# the same sets as tools/pmc_sets.txt, minus the one no derived figure uses).
+TRAFFIC_SETS = (("FETCH_SIZE",), ("WRITE_SIZE",))
+UNIT_SETS = (
+    ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES"),
+    ("SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC",
+     "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"),
+    ("SQ_INST_LEVEL_VMEM", "SQ_INST_LEVEL_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_UNALIGNED_STALL",
+     "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_CYCLES"),
+    ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TA_BUSY_avr"),
+)
+
+
+def derived_unit_figures(c: dict, steps_per_launch: float, cus: int = 256):
+    """The per-unit figures DESIGN.md quotes, from one kernel's per-launch counter averages `c` (W = waves, S = time steps per
+    launch): instructions per wave-timestep = SQ_INSTS_* / (W S); valu_issue_frac = SQ_ACTIVE_INST_VALU / (cycles x CUs)
+    (each SIMD issues one VALU op per 4 cycles); scalar_issue_frac = (SALU + BRANCH) / (cycles x CUs) (one scalar pipe per
+    CU); lds_active_frac = SQ_LDS_IDX_ACTIVE / (cycles x CUs); lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT /
+    SQ_LDS_IDX_ACTIVE; tcp_lookups_per_cu_cycle; l2_hit_frac = TCC_HIT / (HIT + MISS).  cycles = GRBM_GUI_ACTIVE / 8 (the
+    counter is summed over the 8 XCDs).  {} when the two counters everything is divided by are missing."""
+    if "GRBM_GUI_ACTIVE" not in c or "SQ_WAVES" not in c:
+        return {}
+    cu_cycles = c["GRBM_GUI_ACTIVE"] / 8 * cus
+    ws = c["SQ_WAVES"] * steps_per_launch
+    sal = c.get("SQ_INSTS_SALU", 0) + c.get("SQ_INSTS_BRANCH", 0)
+    return {
+        "valu_instr_per_wave_timestep": c.get("SQ_INSTS_VALU", 0) / ws,
+        "salu_instr_per_wave_timestep": sal / ws,
+        "lds_instr_per_wave_timestep": c.get("SQ_INSTS_LDS", 0) / ws,
+        "vmem_rd_instr_per_wave_timestep": c.get("SQ_INSTS_VMEM_RD", 0) / ws,
+        "valu_issue_frac": c.get("SQ_ACTIVE_INST_VALU", 0) / cu_cycles,
+        "scalar_issue_frac": sal / cu_cycles,
+        "lds_active_frac": c.get("SQ_LDS_IDX_ACTIVE", 0) / cu_cycles,
+        "lds_bank_conflict_frac": (c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else 0.0,
+        "tcp_lookups_per_cu_cycle": c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / cu_cycles,
+        "l2_hit_frac": (c.get("TCC_HIT_sum", 0) / (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))) if c.get("TCC_HIT_sum") else None,
+    }
+
+
+def pmc_passes(counter_sets, kernels, bench_args, timeout_s: float = 150.0):
+    """One counter-only child pass of this same command (2 steps, no warmup, nothing but the headline) per counter set under
+    `rocprofv3 --pmc <set>` -- counters only, no tracing, separate passes, as MI355X_MICROARCH.md's rocprofv3 section
+    prescribes.  Returns ({kernel: {counter: [one value per launch]}}, None), or (what the passes so far gave, why the next
+    one failed)."""
+    import csv
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {}, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="lcs_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for i, counters in enumerate(counter_sets):
+            out_dir = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", out_dir, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-secondary",
+                   "--no-live-counters"] + list(bench_args)
+            # a child process in its own group (this process has the GPU open: never exec over it), stopped by that group id
+            p = subprocess.Popen(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return vals, f"rocprofv3 --pmc {counters[0]} ... pass exceeded {timeout_s:.0f} s"
+            if rc != 0:
+                return vals, f"rocprofv3 --pmc {counters[0]} ... pass exited {rc}"
+            for f in glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] not in counters:
+                        continue
+                    name = r["Kernel_Name"].replace("void ", "")           # "void (anonymous namespace)::kernel<...>((anonymous namespace)::Args<T>)"
+                    name = (name.split("(anonymous namespace)::", 1)[1] if "(anonymous namespace)::" in name else name).split("(")[0]
+                    for k in kernels:
+                        if kernel_name_matches(name, k):
+                            vals.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return vals, None
+
+
+def live_traffic(kernels, bench_args, timeout_s: float = 150.0):
+    """HBM-side bytes per launch of `kernels`, MEASURED by this run: pmc_passes() over FETCH_SIZE and WRITE_SIZE, after the
+    timed region.  bytes = (2 FETCH_SIZE + WRITE_SIZE) x 1024 (both in KiB; gfx950's FETCH_SIZE counts half of the bytes
+    fetched: profiles/summarize.py checks that on the pack kernel's known reads).  Returns {kernel: {"traffic", "launches"}}
+    plus "source", or {"error": why} -- the caller then falls back to the hash-stamped summaries under profiles/."""
+    sums, err = pmc_passes(TRAFFIC_SETS, kernels, bench_args, timeout_s)
+    if err:
+        return {"error": err}
+    out = {}
+    for k, d in sums.items():
+        if d.get("FETCH_SIZE") and d.get("WRITE_SIZE"):
+            f, w = d["FETCH_SIZE"], d["WRITE_SIZE"]
+            out[k] = {"traffic": (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0, "launches": len(f)}
+    if not out:
+        return {"error": "no launch of " + ", ".join(kernels) + " in the counter passes"}
+    out["source"] = ("live: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` child passes of this command (2 steps each), "
+                     "(2 FETCH_SIZE + WRITE_SIZE) x 1024 averaged over the launches")
+    return out
+
+
+def live_limiting_unit(kernel, steps_per_launch, bench_args, timeout_s: float = 150.0):
+    """derived_unit_figures() of `kernel` from four more pmc_passes() (UNIT_SETS) of this run; {"error": why} otherwise."""
+    vals, err = pmc_passes(UNIT_SETS, [kernel], bench_args, timeout_s)
+    if err:
+        return {"error": err}
+    c = {n: sum(v) / len(v) for n, v in vals.get(kernel, {}).items()}
+    der = derived_unit_figures(c, steps_per_launch)
+    if not der:
+        return {"error": "no launch of " + kernel + " in the counter passes"}
+    return {"limiting_unit": {k: round(v, 4) for k, v in der.items() if v is not None},
+            "source": "live: four `rocprofv3 --pmc` child passes of this command (2 steps each; counter sets: UNIT_SETS in bench.py), "
+                      "per-launch averages"}
+
+
 def stamped_counters(kernel: str, workload: dict, csrc: str):
     """Counters of `kernel` from the committed rocprofv3 --pmc summaries (profiles/*/*_pmc_*.json, written by
     profiles/summarize*.py from separate passes of this same command).  Counters cannot be read from inside the
@@ -98,10 +227,7 @@ def stamped_counters(kernel: str, workload: dict, csrc: str):
         if d.get("workload") != workload or d.get("csrc_hash") != csrc:
             continue
         for k, v in d.get("kernels", {}).items():
-            kk, want = k.replace(" ", ""), kernel.replace(" ", "")
-            # "name" matches "name<template args>"; "name<a,b>" matches the profiler's "name<a,b,defaulted...>" (the library
-            # names a kernel by its leading template arguments: trailing ones added later keep their defaults there)
-            if kk != want and not (kk.startswith(want + "<") and "<" not in want) and not (want.endswith(">") and kk.startswith(want[:-1] + ",")):
+            if not kernel_name_matches(k, kernel):
                 continue
             if "hbm_bytes_per_launch" in v:
                 out["traffic"] = v["hbm_bytes_per_launch"]
@@ -546,6 +672,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="c2 only: pack the whole series, then advect (default at order 3: the two pipelined on two streams)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in the default "
+                         "one-GPU c3 run (the hash-stamped summaries under profiles/ are replayed instead; also skipped with "
+                         "--no-secondary / --no-cpu-baseline and when the run is itself under rocprofv3)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the non-headline workloads the default one-GPU c3 run appends under \"secondary\"")
     ap.add_argument("--traj", action="store_true",
@@ -963,6 +1093,39 @@ def main():
         del sig, x_ext, y_ext, field          # the headline's outputs: the secondary cases reuse the memory
         torch.cuda.empty_cache()
         out["secondary"] = secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dlat, dlon)
+    # ---- roofline.traffic measured by this run (default one-GPU run only): two counter-only child passes of this command ----
+    profiled = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)      # this run is itself under rocprofv3
+    if plain and not (args.no_live_counters or args.no_secondary or args.no_cpu_baseline or profiled):
+        sk = out["roofline_sigma"]["kernel"]        # (the headline's: the secondary cases have launched others since)
+        torch.cuda.empty_cache()
+        t_live = time.time()
+        live = live_traffic([advect_kernel, sk], [])
+        rf, rs = out["roofline"], out["roofline_sigma"]
+        if advect_kernel in live:
+            tr = live[advect_kernel]["traffic"]
+            rf["traffic_replayed"], rf["hbm"]["traffic_replayed_source"] = rf["traffic"], rf["hbm"]["traffic_source"]
+            rf["traffic"] = rf["hbm"]["traffic_bytes"] = tr
+            rf["hbm"]["hbm_traffic_frac"] = tr / (rf["kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBPS
+            rf["hbm"]["traffic_source"] = live["source"]
+            rf["hbm"]["traffic_launches"] = live[advect_kernel]["launches"]
+            rf["note"] = rf["note"].replace("traffic / limiting_unit are replayed from hash-stamped rocprofv3 summaries or null",
+                                            "traffic is measured by this run (hbm.traffic_source), limiting_unit is replayed from the "
+                                            "hash-stamped rocprofv3 summaries or null")
+            if sk in live:
+                rs["traffic_replayed"], rs["traffic"] = rs["traffic"], live[sk]["traffic"]
+                rs["traffic_source"] = live["source"]
+                rs["hbm_traffic_frac"] = live[sk]["traffic"] / sig_s / 1e9 / HBM_PEAK_GBPS
+            lu = live_limiting_unit(advect_kernel, nsteps / rf["kernel_launches_per_advect"], [])
+            if "limiting_unit" in lu:
+                rf["limiting_unit_replayed"], rf["limiting_unit_replayed_source"] = rf["limiting_unit"], rf["limiting_unit_source"]
+                rf["limiting_unit"], rf["limiting_unit_source"] = lu["limiting_unit"], lu["source"]
+                rf["note"] = rf["note"].replace("limiting_unit is replayed from the hash-stamped rocprofv3 summaries or null",
+                                                "so is limiting_unit; the *_replayed fields are the committed profiles/ summaries' values")
+            else:
+                rf["limiting_unit_live_error"] = lu["error"]
+            rf["hbm"]["counter_passes_s"] = round(time.time() - t_live, 1)
+        else:
+            rf["hbm"]["traffic_live_error"] = live.get("error", "advect kernel not in the counter passes")
     # ---- CPU baseline: the oracle (numpy+scipy port) on a bounded sample, rank 0, N=1 only ----
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(flows, u, v, lat, lon, dt, K, order, nsteps)

@@ -23,6 +23,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lagrangiancoherence_amd.build import csrc_hash  # noqa: E402
+from bench import derived_unit_figures  # noqa: E402  (the same formulas bench.py applies to its own live passes)
 
 
 def stamp(run):
@@ -55,23 +56,7 @@ def main():
     kernels = {}
     for k, d in agg.items():
         c = {n: sum(v) / len(v) for n, v in d.items()}
-        der = {}
-        if "GRBM_GUI_ACTIVE" in c and "SQ_WAVES" in c:
-            cu_cycles = c["GRBM_GUI_ACTIVE"] / 8 * CUS
-            ws = c["SQ_WAVES"] * nsteps
-            sal = c.get("SQ_INSTS_SALU", 0) + c.get("SQ_INSTS_BRANCH", 0)
-            der = {
-                "valu_instr_per_wave_timestep": c.get("SQ_INSTS_VALU", 0) / ws,
-                "salu_instr_per_wave_timestep": sal / ws,
-                "lds_instr_per_wave_timestep": c.get("SQ_INSTS_LDS", 0) / ws,
-                "vmem_rd_instr_per_wave_timestep": c.get("SQ_INSTS_VMEM_RD", 0) / ws,
-                "valu_issue_frac": c.get("SQ_ACTIVE_INST_VALU", 0) / cu_cycles,
-                "scalar_issue_frac": sal / cu_cycles,
-                "lds_active_frac": c.get("SQ_LDS_IDX_ACTIVE", 0) / cu_cycles,
-                "lds_bank_conflict_frac": (c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else 0.0,
-                "tcp_lookups_per_cu_cycle": c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / cu_cycles,
-                "l2_hit_frac": (c.get("TCC_HIT_sum", 0) / (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))) if c.get("TCC_HIT_sum") else None,
-            }
+        der = derived_unit_figures(c, nsteps, CUS)
         kernels[k] = {**c, "derived": der}
     json.dump({"workload": workload, "csrc_hash": stamp(run), "kernels": kernels,
                "note": "rocprofv3 --pmc passes (counter sets in profiles/README.md) over bench.py --steps 1 --warmup 0; "

@@ -195,3 +195,23 @@ def test_secondary_workloads_block_of_the_default_run():
     assert "o3" in sec["c3 order 3"]["kernel"] or "<3," in sec["c3 order 3"]["kernel"]
     assert sec["c2"]["kernel"].startswith("advect_lds64_kernel") and sec["c2 order 3"]["kernel"].startswith("advect_lds64_o3_kernel")
     eng.close()
+
+
+def test_live_counter_passes_of_the_default_run():
+    """What the default one-GPU run adds to `roofline` from its own `rocprofv3 --pmc` child passes (here on a miniature
+    workload): the dispatched kernel's HBM-side bytes per launch and its per-unit figures, counters only, no tracing."""
+    import shutil
+    if not shutil.which("rocprofv3"):
+        pytest.skip("no rocprofv3 on this box")
+    sys.path.insert(0, ROOT)
+    import bench
+    small = ["--seeds", "256", "--nt", "5"]
+    k = "advect_lds_kernel<1, 4, true>"
+    t = bench.live_traffic([k], small)
+    assert "error" not in t, t
+    # 2 steps of one launch each; at least the seeds' outputs (256^2 x 2 planes x 4 bytes) leave the chip, and not a whole GB
+    assert t[k]["launches"] == 2 and 256 * 256 * 8 <= t[k]["traffic"] < 1e9
+    u = bench.live_limiting_unit(k, 4, small)
+    assert "error" not in u, u
+    lu = u["limiting_unit"]
+    assert 100 < lu["valu_instr_per_wave_timestep"] < 1000 and 0 < lu["valu_issue_frac"] <= 1 and 0 <= lu["lds_bank_conflict_frac"] <= 1
