@@ -44,6 +44,12 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
         return LC_EHIP;
     }
     c->stream = c->own_stream;
+    c->n_cus = 256;
+    {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->n_cus = n;
+        else (void)hipGetLastError();
+    }
     c->lds_tiles = 3;  // by size
     if (const char *ev = getenv("LCS_LDS_TILES")) c->lds_tiles = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : (ev[0] == '1' ? 1 : 3));  // read once, here
     c->xcd_chunk_rows = 1;  // tile rows dealt to the XCDs cyclically (measured: C3 -1.7 %, C4 -2.8 %, C5 -5 % against contiguous bands)
@@ -56,6 +62,8 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     if (const char *ev = getenv("LCS_POLE_BLOCKS")) c->pole_blocks = ev[0] != '0';  // read once, here
     c->fir_prefilter = 1;
     if (const char *ev = getenv("LCS_FIR_PREFILTER")) c->fir_prefilter = ev[0] == '0' ? 0 : (ev[0] == '2' ? 2 : 1);  // read once, here
+    c->fused_prefilter = 1;
+    if (const char *ev = getenv("LCS_FUSED_PREFILTER")) c->fused_prefilter = ev[0] != '0';
     c->sigma_march = 2;  // by size
     if (const char *ev = getenv("LCS_SIGMA_MARCH")) c->sigma_march = ev[0] == '0' ? 0 : (ev[0] == '1' ? 1 : 2);  // read once, here
     c->level_chunk = -1;  // by size (advect.hip: 32 levels per launch from 2^22 seeds per call)

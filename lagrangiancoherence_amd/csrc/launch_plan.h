@@ -44,6 +44,35 @@ LCP_HD int tile_of_block(int b, int ntiles, int ntx, int xcd_chunk, int tile_ord
 // launches that divide evenly anyway -- neighbouring tiles of a row share wind nodes, and eight times as many of them
 // then sit on different L2s).  xcd_split < 0 (the default): split 8 exactly when whole chunks would leave the XCDs more
 // than 15 % apart (profiles/r05/xcd_split_ab.txt).
+// prefilter_fused_stream_kernel: waves per workgroup.  A workgroup of nw waves keeps 32 (nw - 2) columns (its first and last
+// wave are halo); a line of nx columns takes ceil(nx / kept) workgroups.  The choice marches the fewest columns in all
+// (ties: the larger workgroup -- fewer halo waves per kept column at the same cost).
+LCP_HD int fused_prefilter_waves(int nx, int max_waves) {
+    int best = 4, best_cost = 1 << 30;
+    for (int nw = 4; nw <= max_waves; ++nw) {
+        const int kept = 32 * (nw - 2), cost = (nx + kept - 1) / kept * nw;
+        if (cost <= best_cost) best = nw, best_cost = cost;
+    }
+    return best;
+}
+
+// prefilter_fused_stream_kernel: row pieces of the workgroups that do not fill a round.  One workgroup per CU at a time, all
+// the same length: `items` (level, x block) columns-of-workgroups on `cus` CUs run in ceil(items / cus) rounds, the last one
+// with (items % cus) workgroups on an otherwise idle chip.  Those last ones are cut into row pieces so that the last round has
+// up to `cus` shorter workgroups: a piece restarts the latitude march 64 rows above its first row and runs 32 rows past its
+// last (FS_RESTART), so pieces are kept at 128 rows or more.  Returns the pieces per leftover item (1: no split).
+struct FusedSplit { int n_whole, pieces, piece_rows; };   // items run whole; pieces of each of the others; rows per piece (a multiple of 8)
+LCP_HD FusedSplit fused_prefilter_split(int items, int cus, int ny) {
+    FusedSplit f;
+    const int left = cus > 0 ? items % cus : 0;
+    f.n_whole = items - left;
+    f.pieces = 1;
+    if (left > 0) f.pieces = imax(1, imin(cus / left, ny / 128));
+    f.piece_rows = ((ny + f.pieces - 1) / f.pieces + 7) / 8 * 8;
+    while (f.pieces > 1 && f.piece_rows * (f.pieces - 1) >= ny) --f.pieces;   // (rounding up to 8 rows may leave the last piece empty)
+    return f;
+}
+
 LCP_HD int xcd_chunk_tiles(int ntx, int nty, int xcd_rows, int xcd_split) {
     if (xcd_rows <= 0) return 0;
     const int whole = xcd_rows * ntx;

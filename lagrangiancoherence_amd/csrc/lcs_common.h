@@ -12,6 +12,7 @@ void lc_trunc_cache_free(lc_trunc_cache *c);
 
 struct lc_ctx {
     int device;
+    int n_cus;           // compute units of the device (the fused prefilter sizes its last round by it)
     hipStream_t own_stream;
     hipStream_t stream;  // the one work is enqueued on (own or borrowed)
     int lds_tiles;       // lc_advect float32 kernel choice: 3 LDS tiles, seeds per lane by size (default); 1 two seeds, 2 one seed per lane; 0 direct gathers (LCS_LDS_TILES at creation)
@@ -20,6 +21,7 @@ struct lc_ctx {
     int xcd_split;       // lc_advect tile order: > 0 = a chunk is 1 / xcd_split of xcd_chunk_rows tile rows; -1 (default) = 8 when whole chunks would leave the XCDs > 15 % apart, else 0 (LCS_XCD_SPLIT at creation)
     int xcd_chunk_rows;  // lc_advect tile order: tile rows per chunk dealt to the XCDs cyclically; default 1; 0 = one contiguous band per XCD (LCS_XCD_CHUNK_ROWS at creation)
     int fir_prefilter;   // float32 order-3 pack: 1 one-pass truncated-convolution prefilter (default), 0 the recursive sweeps (LCS_FIR_PREFILTER at creation)
+    int fused_prefilter; // float64 order-3 pack: 1 both sweeps in one pass (prefilter_fused_stream_kernel, default), 0 the two streaming sweeps (LCS_FUSED_PREFILTER at creation)
     int tile_order;      // lc_advect tile-row order: -1 per kernel (default), 0 as stored, 1 last row first, 2 poles inwards (LCS_TILE_ORDER at creation)
     int pole_blocks;     // lc_advect: 1 leading workgroups take the global pole rows (default), 0 the tiles do (LCS_POLE_BLOCKS at creation)
     int level_chunk;     // lc_advect: time levels per launch (-1 by size, the default: 32 from 2^18 seeds per call; 0 = the whole series in one launch); LCS_LEVEL_CHUNK at creation / lc_ctx_set_level_chunk

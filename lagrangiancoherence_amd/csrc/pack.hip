@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "lcs_common.h"
+#include "launch_plan.h"
 
 namespace {
 
@@ -487,6 +488,231 @@ __global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const TIN *_
     }
 }
 
+// Both sweeps in ONE pass over the raw planes (round 5; float64 order 3 moved 13.6 GB in the two sweeps above, this one
+// 7.7): the latitude march of prefilter_cols_stream_kernel, a lane per (column, component) walking down its column, and --
+// instead of storing the finished latitude values for a second kernel to transpose through LDS -- the longitude recursion
+// ACROSS THE LANES of the workgroup, on the FS_C rows a round finishes.  A first-order recursion s[i] = a[i] + z s[i-1] is a
+// scan.  Within a DPP row (16 lanes = 8 nodes x 2 components) three doubling steps s[i] += z^(2^k) s[i - 2^k] by row_shr
+// (lanes without a source read 0: no select); the rows then publish their last value E in LDS and every lane adds
+// z^(l+1) (E[R-1] + z^8 E[R-2] + z^16 E[R-3] + z^24 E[R-4]) of the four rows before its own (l: its node within the row):
+// at least 32 predecessors in every sum, the same |z|^32 = 5e-19 horizon the anticausal walks above start from.  The
+// anticausal pass is the same mirrored (row_shl, the rows' first values, the four rows after).  No ds_bpermute: the first
+// form of this kernel did all five doubling steps of a 64-lane scan with it and was bound by the LDS crossbar (3.1 ms).
+// The first and the last wave of a workgroup are halo (their columns are marched and their row ends feed the neighbours,
+// nothing of theirs is kept); at the ends of a line the halo columns are the mirrored ones (x -> -x, x -> 2 (nx - 1) - x),
+// which IS scipy's mirror boundary: its causal start value and its closed form at n - 1 are the infinite mirrored sums
+// these truncate at |z|^32.  Results differ from the two-sweep kernels in the last bits only (summation order).  A
+// workgroup is 4..12 waves (the launcher picks what marches the fewest halo columns for this nx:
+// lcplan::fused_prefilter_waves); blocks are dealt so that the workgroups of one level run on the same XCD (their halo
+// columns are each other's interior: L2 hits).  FS_C = 8 rows per round: 168 registers, three waves per SIMD (16 rows: 228).
+constexpr int FS_MAXW = 12;
+constexpr int FS_C = 8, FS_H = 32, FS_W = FS_C + FS_H;
+constexpr int FS_ROWS = FS_MAXW * 4 + 8;  // DPP rows of a workgroup + 4 rows of zeros on either side
+
+template <int CTRL>
+__device__ __forceinline__ double row_shift64(double v) {  // DPP row_shr:n (0x110 + n) / row_shl:n (0x100 + n); no source lane: 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void workgroup_barrier_lds() {  // LDS traffic only: the global loads in flight stay in flight
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// The longitude filter of rows 0 .. FS_C - 1 of the register window, in place.  Every thread of the workgroup calls it
+// (two workgroup barriers).  ends[0] / ends[1]: the rows' last causal / first anticausal values, [4 + DPP row][q][component].
+template <int P>
+__device__ __forceinline__ void lanes_prefilter(double (&r)[FS_W], double (&ends)[2][FS_ROWS][FS_C][2], const double (&zp)[2][8], int tid) {
+    constexpr int B = FS_C * P;  // the window's first row sits at r[B] in phase P (fused_round)
+    const double z = -0.26794919243112270647, gain = 6.0;
+    const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const int R = 4 + (tid >> 4), l = (tid & 15) >> 1, comp = tid & 1;  // zp[0][l] = z^(l + 1), zp[1][l] = z^(8 - l): read when used (registers)
+    // causal: s[i] = gain a[i] + z s[i-1]
+#pragma unroll
+    for (int q = 0; q < FS_C; ++q) {
+        double s = gain * r[B + q];
+        s = fma(z, row_shift64<0x112>(s), s);
+        s = fma(z2, row_shift64<0x114>(s), s);
+        s = fma(z4, row_shift64<0x118>(s), s);
+        r[B + q] = s;
+    }
+    if (l == 7) {
+#pragma unroll
+        for (int q = 0; q < FS_C; ++q) ends[0][R][q][comp] = r[B + q];
+    }
+    workgroup_barrier_lds();
+    // ... the four rows before, then the anticausal input b[i] = -z c+[i]: c[i] = b[i] + z c[i+1]
+    const double zp_in = zp[0][l];
+#pragma unroll
+    for (int q = 0; q < FS_C; ++q) {
+        const double t = fma(z8, fma(z8, fma(z8, ends[0][R - 4][q][comp], ends[0][R - 3][q][comp]), ends[0][R - 2][q][comp]), ends[0][R - 1][q][comp]);
+        double s = -z * fma(zp_in, t, r[B + q]);
+        s = fma(z, row_shift64<0x102>(s), s);
+        s = fma(z2, row_shift64<0x104>(s), s);
+        s = fma(z4, row_shift64<0x108>(s), s);
+        r[B + q] = s;
+        if (q % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // four rows' LDS reads in flight, not all FS_C (registers: 6 spilled otherwise)
+    }
+    if (l == 0) {
+#pragma unroll
+        for (int q = 0; q < FS_C; ++q) ends[1][R][q][comp] = r[B + q];
+    }
+    workgroup_barrier_lds();
+    const double zp_out = zp[1][l];
+#pragma unroll
+    for (int q = 0; q < FS_C; ++q) {
+        const double t = fma(z8, fma(z8, fma(z8, ends[1][R + 4][q][comp], ends[1][R + 3][q][comp]), ends[1][R + 2][q][comp]), ends[1][R + 1][q][comp]);
+        r[B + q] = fma(zp_out, t, r[B + q]);
+        if (q % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// One round of the fused kernel in phase P: the window (FS_W rows, first row s) sits at r[(j + FS_C P) % FS_W] -- the
+// round loop is unrolled over the FS_W / FS_C phases, so the window never moves (a shift by FS_C rows per round is 2 FS_H
+// register moves and, worse, doubles the window's live range at the point where the finished rows are still needed).
+template <int P, typename TIN>
+__device__ __forceinline__ void fused_round(double (&r)[FS_W], double (&ends)[2][FS_ROWS][FS_C][2], const double (&zp)[2][8], const TIN *__restrict__ src,
+                                            double *__restrict__ c, int s, int y1, int n, size_t ss, size_t cs, int tid) {
+    constexpr double z = -0.26794919243112270647, gain = 6.0, zend = z / (z * z - 1.0);
+    constexpr int B = FS_C * P;
+    auto W = [&](int j) -> double & { return r[(B + j) % FS_W]; };
+    // (the row index reaches the address arithmetic through an opaque scalar: left to itself, loop strength reduction keeps one
+    // 64-bit per-lane pointer for every row of the window and of the store list across the rounds -- 80 registers, spilled)
+    asm volatile("" : "+s"(s));
+    double a[FS_C];  // the next FS_C inputs, in flight during the anticausal walk and the lane scans
+#pragma unroll
+    for (int q = 0; q < FS_C; ++q) {
+        const int i = s + FS_W + q;
+        a[q] = src[(size_t)(i > n - 1 ? 2 * (n - 1) - i : i) * ss];
+    }
+    double prev = W(FS_W - 1);
+    // (the lookahead stretch in closed form -- four Horner chains in z^4, 8 dependent operations instead of 62 -- was tried:
+    // the register allocator answers with 90 spilled registers, whatever the scheduling barriers)
+    double next = (z * W(FS_W - 2) + W(FS_W - 1)) * zend;
+#pragma unroll
+    for (int j = FS_W - 2; j >= FS_C; --j) next = z * (next - W(j));
+#pragma unroll
+    for (int j = FS_C - 1; j >= 0; --j) {
+        next = z * (next - W(j));
+        W(j) = next;
+    }
+    lanes_prefilter<P>(r, ends, zp, tid);
+#pragma unroll
+    for (int j = 0; j < FS_C; ++j)
+        if (s + j < y1) c[(size_t)(s + j) * cs] = W(j);
+#pragma unroll
+    for (int q = 0; q < FS_C; ++q) {  // rows s + FS_W + q take the places of the rows just stored
+        prev = gain * a[q] + z * prev;
+        W(q) = prev;
+    }
+}
+
+template <typename TIN>
+__global__ void __launch_bounds__(FS_MAXW * 64) prefilter_fused_stream_kernel(const TIN *__restrict__ u, const TIN *__restrict__ v,
+                                                                              double *__restrict__ packed, int nt, int ny, int nx, int nxb,
+                                                                              const lcplan::FusedSplit split) {
+    __shared__ double ends[2][FS_ROWS][FS_C][2];
+    __shared__ double zp[2][8];
+    for (int i = threadIdx.x; i < 2 * FS_ROWS * FS_C * 2; i += blockDim.x) (&ends[0][0][0][0])[i] = 0.0;  // (the rows beside the workgroup's stay 0)
+    const double z = -0.26794919243112270647, gain = 6.0, zend = z / (z * z - 1.0);
+    const int nw = blockDim.x >> 6, xout = 32 * (nw - 2);
+    // the 8 XCDs take consecutive runs of (level, x block) items: blocks i, i + 8, ... (one XCD) are neighbours in x
+    // (the items past split.n_whole come in split.pieces row pieces each: lcplan::fused_prefilter_split; every XCD takes an
+    // eighth of the whole items and an eighth of the pieces)
+    const unsigned items = (unsigned)nxb * nt, n_pieces = (items - split.n_whole) * split.pieces;
+    const unsigned whole_per = (split.n_whole + 7) / 8, piece_per = (n_pieces + 7) / 8;
+    const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    unsigned item;
+    int piece = 0;
+    if (j < whole_per) {
+        item = xcd * whole_per + j;
+        if (item >= (unsigned)split.n_whole) return;
+    } else {
+        const unsigned q = xcd * piece_per + (j - whole_per);
+        if (q >= n_pieces) return;
+        item = split.n_whole + q / split.pieces;
+        piece = q % split.pieces;
+    }
+    const int y0 = piece * split.piece_rows;                                                         // this workgroup's rows [y0, y1)
+    const int y1 = item < (unsigned)split.n_whole ? ny : min(ny, y0 + split.piece_rows);
+    const int t = item / nxb, xb = item - t * nxb;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, comp = lane & 1;
+    const int x = xb * xout - 32 + (tid >> 1);  // this lane's column; outside [0, nx): the mirrored one (beyond that: unused)
+    int xm = x < 0 ? -x : x;
+    xm = xm > nx - 1 ? 2 * (nx - 1) - xm : xm;
+    xm = min(max(xm, 0), nx - 1);
+    const bool keep = w >= 1 && w <= nw - 2 && x < nx;
+    if (threadIdx.x < 8) {  // z^(l + 1), z^(8 - l) for the node l of a DPP row
+        double p = z;
+        for (int i = 0; i < (int)threadIdx.x; ++i) p *= z;
+        zp[0][threadIdx.x] = p;
+        zp[1][7 - threadIdx.x] = p;
+    }
+
+    const int pitch = nx + LC_PAD;
+    const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
+    // a lane that keeps nothing (halo waves, columns past nx) stores like the others, into the pad column of the same rows: the
+    // pads are written after this kernel (pads_ext_kernel / pads_only_kernel)
+    double *c = packed + (size_t)t * level + ((size_t)LC_PAD_LO * pitch + (keep ? LC_PAD_LO + x : 0)) * 2 + comp;
+    const size_t cs = (size_t)pitch * 2, ss = (size_t)nx;
+    const TIN *src = (comp ? v : u) + (size_t)t * ny * nx + xm;
+    const int n = ny;  // >= 64 (the launcher checks)
+    // the latitude march: prefilter_cols_stream_kernel's, with the finished values kept in the window instead of stored.  The
+    // causal value at the first row y0 is the sum of the 64 rows above it, c+[y0] = sum_k z^k gain a[|y0 - k|]: scipy's mirror
+    // start value at y0 = 0 (prefilter_line_blocked's horizon), and the restart of a row piece anywhere else (|z|^64 = 2.5e-37)
+    auto row = [&](int i) { return (size_t)(i > n - 1 ? 2 * (n - 1) - i : i) * ss; };   // rows past the end: mirrored
+    double c0 = gain * src[row(y0)], zi = z;
+    for (int i0 = 1; i0 < 64; i0 += 8) {
+        double a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = src[(size_t)abs(y0 - min(i0 + q, 63)) * ss];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (i0 + q < 64) {
+                c0 += zi * (gain * a[q]);
+                zi *= z;
+            }
+        }
+    }
+    double r[FS_W];
+    r[0] = c0;
+    {
+        double prev = c0;
+#pragma unroll
+        for (int j0 = 1; j0 < FS_W; j0 += 16) {
+            double a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = src[row(y0 + min(j0 + q, FS_W - 1))];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (j0 + q < FS_W) {
+                    prev = gain * a[q] + z * prev;
+                    r[j0 + q] = prev;
+                }
+            }
+        }
+    }
+    // Past the end of the column the march goes on over the mirrored rows (i -> 2 (n - 1) - i): the anticausal walk of the
+    // last rounds then starts 32 rows beyond n - 1 on scipy's mirror extension, which its closed form at n - 1 sums exactly
+    // (the same |z|^32 horizon as everywhere else), and every round is the same code.
+    static_assert(FS_W % FS_C == 0 && FS_W / FS_C == 5, "the round loop is unrolled over five phases");
+    for (int s = y0; s < y1;) {   // (y0, y1 are the same for every thread: the barriers inside are reached by all or none)
+        fused_round<0>(r, ends, zp, src, c, s, y1, n, ss, cs, tid);
+        if ((s += FS_C) >= y1) break;
+        fused_round<1>(r, ends, zp, src, c, s, y1, n, ss, cs, tid);
+        if ((s += FS_C) >= y1) break;
+        fused_round<2>(r, ends, zp, src, c, s, y1, n, ss, cs, tid);
+        if ((s += FS_C) >= y1) break;
+        fused_round<3>(r, ends, zp, src, c, s, y1, n, ss, cs, tid);
+        if ((s += FS_C) >= y1) break;
+        fused_round<4>(r, ends, zp, src, c, s, y1, n, ss, cs, tid);
+        s += FS_C;
+    }
+}
+
 // Longitude sweep, same scheme on the wave-per-32-rows LDS tile of prefilter_rows_lds_kernel: the tile is a ring of
 // 64 nodes (two chunks of 32); a lane walks its line (row, component) through it.  Round k: the ring holds the causal
 // values of chunks k and k+1; the lane starts the anticausal walk at the end of chunk k+1, walks chunk k+1 without
@@ -849,15 +1075,25 @@ int pack_impl(lc_ctx *ctx, const TIN *u, const TIN *v, int nt, int ny, int nx, i
         // float64: one read + one write per sweep (lines of 64 nodes or more; LCS_FIR_PREFILTER=0: the two-march kernels)
         const bool stream = sizeof(T) == 8 && ctx->fir_prefilter;
         const bool cols_stream = stream && ny >= 64;
+        bool fused = false;
         if constexpr (sizeof(T) == 8) {
-            if (cols_stream)
+            if (cols_stream && nx >= 64 && ctx->fused_prefilter) {   // both sweeps in one pass over the raw planes
+                const int nw = lcplan::fused_prefilter_waves(nx, FS_MAXW), nxb = (nx + 32 * (nw - 2) - 1) / (32 * (nw - 2));
+                const lcplan::FusedSplit split = lcplan::fused_prefilter_split(nxb * nt, ctx->n_cus, ny);
+                const unsigned per = ((unsigned)split.n_whole + 7) / 8 + (((unsigned)nxb * nt - split.n_whole) * split.pieces + 7) / 8;
+                hipLaunchKernelGGL(prefilter_fused_stream_kernel<TIN>, dim3(per * 8), dim3(nw * 64), 0, ctx->stream, u, v, packed, nt, ny, nx, nxb,
+                                   split);
+                fused = true;
+            }
+            if (cols_stream && !fused)
                 hipLaunchKernelGGL(prefilter_cols_stream_kernel<TIN>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, ctx->stream, u, v,
                                    packed, nt, ny, nx);
         }
         if (!cols_stream)
             hipLaunchKernelGGL((prefilter_cols_kernel<T, TIN>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
                                ctx->stream, u, v, packed, nt, ny, nx);
-        if (stream && nx >= RS_RING) {
+        if (fused) {
+        } else if (stream && nx >= RS_RING) {
             if constexpr (sizeof(T) == 8)
                 hipLaunchKernelGGL(prefilter_rows_stream_kernel, dim3((ny + RS_ROWS - 1) / RS_ROWS, nt), dim3(64), 0, ctx->stream, packed,
                                    ny, nx);

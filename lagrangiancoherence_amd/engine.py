@@ -714,12 +714,14 @@ class Engine:
     PIPELINE_CHUNK = 24      # time levels per pack / advect stage of the pipelined form (measured: profiles/r04/pipelined_pack_ab.txt)
 
     def pipeline_pays(self, dtype, interp_order, fuse_levels, nsteps, n_seeds, cyclic_xboundary, return_traj=False) -> bool:
-        """Where packing chunk k+1 on a side stream while chunk k is advected is the default: float64 at order 3 in the
-        fused-level form (the pack's prefilter sweeps run at half the HBM rate and the float64 order-3 advect kernel is
-        latency-bound: 11.0 -> 9.9 ms per step on BASELINE configs[1] at order 3); not float32 (its advect kernels saturate
-        the VALU: nothing to hide behind, measured) and not float64 at order 1 (measured equal)."""
-        return (np.dtype(dtype) == np.dtype(np.float64) and interp_order == 3 and bool(fuse_levels) and cyclic_xboundary
-                and not return_traj and nsteps > self.PIPELINE_CHUNK and n_seeds > _capi.LC_EXACT_ORDER_MAX_SEEDS)
+        """Where packing chunk k+1 on a side stream while chunk k is advected is the default: nowhere since round 5.  Until
+        then float64 at order 3 in the fused-level form took it (the pack's two prefilter sweeps ran at half the HBM rate
+        next to a latency-bound advect kernel: 10.9 -> 9.75 ms per step on BASELINE configs[1]); with both sweeps in one
+        pass (``prefilter_fused_stream_kernel``: pack 4.6 -> 2.95 ms) the serial form takes 9.0 ms and the pipelined one
+        9.1-9.5 at any chunk length (``profiles/r05/c2_o3_fused_prefilter_ab.txt``): the two kernels now want the same
+        CUs.  float32 (its advect kernels saturate the VALU) and float64 at order 1 never gained from it.  The pipelined
+        form stays available (``pack_and_advect(pipeline=True)``, bit-identical)."""
+        return False
 
     def pack_and_advect(self, u, v, lat_f, lon_f, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
                         cyclic_xboundary=True, fuse_levels=None, pipeline=None, chunk=None, return_traj=False,

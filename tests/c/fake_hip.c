@@ -62,6 +62,7 @@ static hipError_t do_copy(void *dst, const void *src, size_t n) {
 }
 
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int d) { (void)a; (void)d; *v = 256; return hipSuccess; }
 hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : (g_last = hipErrorInvalidDevice); }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags) { (void)flags; *s = (hipStream_t)malloc(1); return *s ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }

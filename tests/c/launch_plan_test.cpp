@@ -88,6 +88,32 @@ static void test_tile_order() {
                     ++cases;
                 }
     std::printf("tile order: %ld launch shapes\n", cases);
+    // the fused float64 prefilter (pack.hip): waves per workgroup and the row pieces of the last round
+    cases = 0;
+    for (int nx = 64; nx <= 6000; nx += (nx < 200 ? 1 : 37)) {
+        const int nw = fused_prefilter_waves(nx, 12), kept = 32 * (nw - 2), wgs = (nx + kept - 1) / kept;
+        CHECK(nw >= 4 && nw <= 12 && wgs * kept >= nx && (wgs - 1) * kept < nx, "nx %d: %d waves", nx, nw);
+        for (int other = 4; other <= 12; ++other)   // no other workgroup size marches fewer columns
+            CHECK(wgs * nw <= (nx + 32 * (other - 2) - 1) / (32 * (other - 2)) * other, "nx %d: %d waves march more than %d", nx, nw, other);
+        ++cases;
+    }
+    CHECK(fused_prefilter_waves(1024, 12) == 10 && fused_prefilter_waves(1440, 12) == 11, "BASELINE widths");
+    for (int items = 1; items <= 3000; items += (items < 600 ? 1 : 13))
+        for (int cus : {1, 8, 104, 256, 304})
+            for (int ny : {64, 100, 128, 255, 256, 720, 1024, 4097}) {
+                const FusedSplit f = fused_prefilter_split(items, cus, ny);
+                CHECK(f.n_whole % cus == 0 && f.n_whole <= items && items - f.n_whole < cus, "items %d cus %d: %d whole", items, cus, f.n_whole);
+                CHECK(f.pieces >= 1 && f.piece_rows % 8 == 0, "pieces %d of %d rows", f.pieces, f.piece_rows);
+                CHECK((long)f.pieces * f.piece_rows >= ny && (long)(f.pieces - 1) * f.piece_rows < ny, "pieces %d x %d rows cover %d", f.pieces, f.piece_rows, ny);
+                CHECK(f.pieces == 1 || f.piece_rows >= 128, "piece of %d rows", f.piece_rows);     // (a piece restarts 64 rows above its own)
+                CHECK((long)(items - f.n_whole) * f.pieces <= (cus > items - f.n_whole ? cus : items - f.n_whole), "last round: %d x %d on %d CUs", items - f.n_whole, f.pieces, cus);
+                ++cases;
+            }
+    {
+        const FusedSplit f = fused_prefilter_split(804, 256, 1024);   // BASELINE configs[1] at order 3: 201 levels x 4 workgroups
+        CHECK(f.n_whole == 768 && f.pieces == 7 && f.piece_rows == 152, "configs[1]: %d whole, %d pieces of %d rows", f.n_whole, f.pieces, f.piece_rows);
+    }
+    std::printf("fused prefilter: %ld shapes\n", cases);
 }
 
 // Over any partition of the global grid into row blocks, the pole rows the blocks take are the global first / last

@@ -256,8 +256,8 @@ def test_pipelined_pack_and_advect_equals_the_serial_form_bit_for_bit(eng, O, dt
     """Engine.pack_and_advect(pipeline=True): the images of level chunk k+1 packed on a side stream while chunk k is advected,
     each advect continuing in place (lc_advect_from) -- the images and the departure points of prepare_field + advect, bit
     for bit, for chunk sizes that divide the series, do not, and leave a last chunk of one level; the field it returns is
-    complete (a second advect from it gives the same answer).  The default (pipeline=None) takes the pipelined form only
-    where it was measured to pay (float64, order 3, more than 2^18 seeds); what cannot be pipelined falls back."""
+    complete (a second advect from it gives the same answer).  The default (pipeline=None) is the serial form everywhere since
+    round 5 (with the one-pass float64 prefilter the pipelined form no longer pays); what cannot be pipelined falls back."""
     u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
     u, v, lat, lon = (a.astype(dtype) for a in (u, v, lat, lon))
     slat, slon = (a.astype(dtype) for a in flows.seed_grid(150, 200, lat, lon))
@@ -281,7 +281,7 @@ def test_pipelined_pack_and_advect_equals_the_serial_form_bit_for_bit(eng, O, dt
         assert np.minimum(d, np.abs(d - 360)).max() < POS_ATOL64 and np.abs(_np(y1) - yo).max() < POS_ATOL64
     if chunk == 3:
         # the default form on this small grid is the serial one; trajectories, the non-cyclic clamp and the exact order fall back
-        assert not eng.pipeline_pays(dtype, order, True, 8, 150 * 200, True) and eng.pipeline_pays(np.float64, 3, True, 200, 1 << 20, True)
+        assert not eng.pipeline_pays(dtype, order, True, 8, 150 * 200, True) and not eng.pipeline_pays(np.float64, 3, True, 200, 1 << 20, True)
         assert not eng.pipeline_pays(np.float64, 1, True, 200, 1 << 20, True) and not eng.pipeline_pays(np.float32, 3, True, 200, 1 << 24, True)
         r = eng.pack_and_advect(u, v, lat, lon, slat, slon, -1800.0, 4, order, True, pipeline=True, chunk=chunk, return_traj=True)
         assert len(r) == 5 and np.array_equal(_np(r[1]), _np(x0)) and np.array_equal(_np(r[3][-1]), _np(x0))
@@ -793,12 +793,16 @@ def test_one_pass_prefilter_matches_the_recursive_sweeps(eng, O, monkeypatch):
     assert np.array_equal(_np(eng.prepare_field(u2, v2, lat2, lon2, 3).cub), _np(eng0.prepare_field(u2, v2, lat2, lon2, 3).cub))
 
 
-@pytest.mark.parametrize("ny,nx", [(97, 150), (64, 64), (130, 65), (65, 97), (37, 150), (97, 40), (81, 96), (200, 257)])
+@pytest.mark.parametrize("ny,nx", [(97, 150), (64, 64), (130, 65), (65, 97), (37, 150), (97, 40), (81, 96), (200, 257),
+                                   (300, 150), (513, 70), (260, 700), (1030, 333)])
 def test_float64_streaming_prefilter_matches_the_two_march_sweeps_and_scipy(eng, O, monkeypatch, ny, nx):
-    """float64, order 3: the one-read-one-write sweeps (default; lines of 64 nodes or more, anticausal walk started 32
-    nodes ahead) against the two-march kernels (LCS_FIR_PREFILTER=0) and against scipy's recursion: line lengths at
-    the limit (64), one node over a chunk, a ragged last chunk, a ragged row block, one axis too short for the
-    streaming form; pads and the fused-level image follow."""
+    """float64, order 3: the streaming prefilter (default; lines of 64 nodes or more, anticausal walks started 32 nodes
+    ahead; both axes of 64 nodes or more: ONE pass, the longitude recursion across the lanes of the workgroup --
+    prefilter_fused_stream_kernel; otherwise one streaming sweep per axis that is long enough) against the two-march
+    kernels (LCS_FIR_PREFILTER=0) and against scipy's recursion: line lengths at the limit (64), one node over a chunk, a
+    ragged last chunk, a ragged row block, one axis too short for the streaming form, columns cut into row pieces (300
+    rows and more on an idle chip: lcplan::fused_prefilter_split), lines of several workgroups (700 columns), a partly
+    filled last wave; pads and the fused-level image follow."""
     from lagrangiancoherence_amd.engine import Engine
     u, v, lat, lon = _rand_field(1000 + ny + nx, nt=3, ny=ny, nx=nx, dtype=np.float64, scale=20.0)
     monkeypatch.setenv("LCS_FIR_PREFILTER", "0")
@@ -816,6 +820,20 @@ def test_float64_streaming_prefilter_matches_the_two_march_sweeps_and_scipy(eng,
         np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 0], O.spline_prefilter_mirror(u[t]), rtol=0, atol=2e-14 * scale)
         np.testing.assert_allclose(img[t, 1:ny + 1, 1:nx + 1, 1], O.spline_prefilter_mirror(v[t]), rtol=0, atol=2e-14 * scale)
     assert np.array_equal(img[:, 0, 1:nx + 1], img[:, 2, 1:nx + 1]) and np.array_equal(img[:, :, nx + 2], img[:, :, nx - 2])
+    if ny >= 64 and nx >= 64:
+        # the one-pass kernel against the two streaming sweeps it replaces (LCS_FUSED_PREFILTER=0): other summation order, last bits
+        monkeypatch.setenv("LCS_FUSED_PREFILTER", "0")
+        eng2 = Engine(0)
+        monkeypatch.delenv("LCS_FUSED_PREFILTER")
+        c2 = _np(eng2.prepare_field(u, v, lat, lon, 3).cub)
+        c1 = _np(a.cub)
+        assert not np.array_equal(c1, c2) and np.abs(c1 - c2).max() <= 3e-15 * scale
+        # ... and its float32-wind instance (LC_F64_WIND_F32: float32 planes in, float64 coefficients out) = the float64 one on the same values
+        u32, v32 = u.astype(np.float32), v.astype(np.float32)
+        fw = eng.prepare_field(u32, v32, lat, lon, 3)
+        fd = eng.prepare_field(u32.astype(np.float64), v32.astype(np.float64), lat, lon, 3)
+        assert np.array_equal(_np(fw.cub), _np(fd.cub))
+        eng2.close()
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
