@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) prefilter_cols_stream_kernel(const TIN *_
 }
 
 // Both sweeps in ONE pass over the raw planes (round 5; float64 order 3 moved 13.6 GB in the two sweeps above, this one
-// 7.7): the latitude march of prefilter_cols_stream_kernel, a lane per (column, component) walking down its column, and --
+// 7.7; BASELINE configs[1]: 3.23 -> 1.70 ms, profiles/r05/c2_o3_fused_prefilter_ab.txt): the latitude march of prefilter_cols_stream_kernel, a lane per (column, component) walking down its column, and --
 // instead of storing the finished latitude values for a second kernel to transpose through LDS -- the longitude recursion
 // ACROSS THE LANES of the workgroup, on the FS_C rows a round finishes.  A first-order recursion s[i] = a[i] + z s[i-1] is a
 // scan.  Within a DPP row (16 lanes = 8 nodes x 2 components) three doubling steps s[i] += z^(2^k) s[i - 2^k] by row_shr

@@ -11,7 +11,8 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in sorted(glob.glob(f"{root}/p*/**/*_counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("void ", "")      # "void (anonymous namespace)::kernel<...>((anonymous namespace)::Args)"
+        k = (k.split("(anonymous namespace)::", 1)[1] if "(anonymous namespace)::" in k else k).split("(")[0]
         if pats and not any(p in k for p in pats):
             continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel trace + three counter passes of lc_field_pack alone:  tools/prof_pack.sh <outdir under gpurun_out> [c2|c3] [order]
+# Kernel trace + counter passes (only sets that tools/pmc_sets.txt has run with: an unknown counter name aborts rocprofv3 and hangs) of lc_field_pack alone:  tools/prof_pack.sh <outdir under gpurun_out> [c2|c3] [order]
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$1; W=${2:-c2}; O=${3:-3}
 mkdir -p $OUT
@@ -14,8 +14,9 @@ while read -r c; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/p$i -- python3 $R/tools/pack_bench.py $W $O 2 > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
 done <<'SETS'
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
-TCC_HIT_sum TCC_MISS_sum
-TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TCP_TCR_TCP_STALL_CYCLES_sum
+TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TA_BUSY_avr
+FETCH_SIZE
+WRITE_SIZE
 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 SETS
 python3 $R/tools/pmc_by_kernel.py $OUT prefilter pads_ext 2>/dev/null | head -120
