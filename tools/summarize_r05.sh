@@ -20,6 +20,10 @@ W='{"workload":"c2","order":3,"K":4,"dtype":"f64","fuse_levels":true}'
 python profiles/summarize.py gpurun_out/r05_c2_o3 profiles/r05/c2_o3 "$W" > /dev/null
 python profiles/summarize_sq.py gpurun_out/r05_c2_o3 profiles/r05/c2_o3 "$W" 28.5714 > /dev/null
 cp gpurun_out/r05_c2_o3/bench_stdout.json profiles/r05/c2_o3_bench_stdout.json
+W='{"workload":"c2","order":1,"K":4,"dtype":"f64","fuse_levels":true,"wind":"f32"}'
+python profiles/summarize.py gpurun_out/r05_c2_wind_f32 profiles/r05/c2_wind_f32 "$W" > /dev/null
+python profiles/summarize_sq.py gpurun_out/r05_c2_wind_f32 profiles/r05/c2_wind_f32 "$W" 28.5714 > /dev/null
+cp gpurun_out/r05_c2_wind_f32/bench_stdout.json profiles/r05/c2_wind_f32_bench_stdout.json
 tools/regs.sh > /dev/null
 python tools/isa_hist.py build/isa/regs_tmp.s advect_lds2_kernelILi4ELb1ELi0E --json profiles/r05/isa_hist_advect_lds2_k4_cyclic.json > /dev/null
 python tools/isa_hist.py build/isa/regs_tmp.s advect_lds2_o3_kernelILi4ELb1ELi0E --json profiles/r05/isa_hist_advect_lds2_o3_k4_cyclic.json > /dev/null
