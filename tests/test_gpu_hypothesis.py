@@ -194,3 +194,35 @@ def test_float64_cubic_prefilter_matches_scipy_at_any_size(ny, nx, nt, seed, sca
     if nt >= 2:
         ext = f.ext.cpu().numpy().reshape(nt - 1, ny + 3, nx + 3, 2)
         assert np.array_equal(ext, 2.0 * img[:-1] - img[1:])
+
+
+@settings(max_examples=40 * _SCALE, deadline=None, derandomize=_DERAND, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(ny=st.integers(64, 420), nx=st.integers(64, 900), nt=st.integers(2, 4), seed=st.integers(0, 2 ** 31 - 1),
+       scale=st.sampled_from([1e-3, 1.0, 40.0]), wind_f32=st.booleans())
+def test_float64_one_pass_prefilter_matches_scipy_on_any_shape(ny, nx, nt, seed, scale, wind_f32):
+    """float64 order 3, both axes of 64 nodes or more: the one-pass prefilter (pack.hip: prefilter_fused_stream_kernel -- the
+    longitude recursion as a scan across the lanes of a workgroup, 4..12 waves by the line length, halo waves, mirrored halo
+    columns, row pieces on an idle chip) against scipy's recursion on every node, pads and the fused-level image included;
+    float32 planes in (numpy's promotion of a float32 wind on float64 coordinates) take the same kernel."""
+    from oracle import lcs_oracle as O
+    eng = _engine()
+    rng = np.random.default_rng(seed)
+    lat = np.linspace(-80.0, 80.0, ny)
+    lon = -180 + 360.0 / nx * np.arange(nx)
+    u = scale * rng.standard_normal((nt, ny, nx))
+    v = scale * (0.3 + rng.standard_normal((nt, ny, nx)))
+    if wind_f32:
+        u, v = u.astype(np.float32), v.astype(np.float32)
+    f = eng.prepare_field(u, v, lat, lon, 3)
+    img = f.cub.cpu().numpy().reshape(nt, ny + 3, nx + 3, 2)
+    tol = 2e-14 * float(np.abs(u).max())
+    for t in range(nt):
+        for k, w in enumerate((u, v)):
+            want = O.spline_prefilter_mirror(w[t].astype(np.float64))
+            got = img[t, 1:ny + 1, 1:nx + 1, k]
+            assert np.abs(got - want).max() <= tol, (t, k, float(np.abs(got - want).max()), tol)
+    assert np.array_equal(img[:, 0, 1:nx + 1], img[:, 2, 1:nx + 1]) and np.array_equal(img[:, ny + 2, 1:nx + 1], img[:, ny - 2, 1:nx + 1])
+    assert np.array_equal(img[:, :, 0], img[:, :, 2]) and np.array_equal(img[:, :, nx + 2], img[:, :, nx - 2])
+    if f.ext is not None:
+        ext = f.ext.cpu().numpy().reshape(nt - 1, ny + 3, nx + 3, 2)
+        assert np.array_equal(ext, 2.0 * img[:-1] - img[1:])
