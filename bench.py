@@ -537,8 +537,8 @@ def run_c2(args, torch, flows, Engine, local_rank, csrc):
     dlat, dlon = float(lat[1] - lat[0]), float(lon[1] - lon[0])
 
     ext_image = None if "LCS_EXT_IMAGE" not in os.environ else os.environ["LCS_EXT_IMAGE"] != "0"
-    # the pipelined form (chunk k+1 packed on a side stream while chunk k is advected) where the engine makes it the default:
-    # float64 at order 3; --no-pipeline: pack, then advect
+    # the pipelined form (chunk k+1 packed on a side stream while chunk k is advected) where the engine makes it the default
+    # (nowhere since round 5: Engine.pipeline_pays); LCS_PIPELINE=1 forces it for an A/B
     piped = (not args.no_pipeline and eng.pipeline_pays(np.float64, order, args.fuse_levels, nt - 1, ny * nx, True))
     if os.environ.get("LCS_PIPELINE"):                      # A/B: force the pipelined form on (1) or off (0), LCS_PIPELINE_CHUNK levels
         piped = os.environ["LCS_PIPELINE"] != "0" and bool(args.fuse_levels)
@@ -671,7 +671,8 @@ def main():
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="c2 only: pack the whole series, then advect (default at order 3: the two pipelined on two streams)")
+                    help="c2 only: pack the whole series, then advect (the default everywhere since round 5; LCS_PIPELINE=1 forces "
+                         "the form that packs chunk k+1 on a side stream while chunk k is advected)")
     ap.add_argument("--no-live-counters", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in the default "
                          "one-GPU c3 run (the hash-stamped summaries under profiles/ are replayed instead; also skipped with "
