@@ -144,6 +144,27 @@ def row_sharded(name, ny_global, nx, nt, weak, balance_levels=0):
     return out
 
 
+def interleaved(name, ny_global, nx, nt, N, chunk):
+    """A costed alternative to contiguous row blocks (NOT what sharded.py does): rank r takes the row chunks r, r + N, r + 2N, ...
+    of `chunk` rows, each extended by the HALO rows either side that its sigma rows need (advected redundantly: no exchange), all
+    in ONE lc_advect call over the concatenated rows.  Every rank then holds every latitude band.  The existing ABI carries it:
+    only the pole-row rule looks at a seed's global row index (row0 + local row), so row0 = 0 for the rank holding the first
+    rows, ny_global - n_local for the one holding the last, and anything in between otherwise."""
+    u, v, lat, lon = flows.era5_like_on_device(torch, eng.device, nt=nt)
+    field = eng.prepare_field(u, v, lat, lon, 1)
+    slat, slon = flows.seed_grid(ny_global, nx, lat, lon)
+    slon_d = eng.to_device(slon, np.float32)
+    H = sharded.HALO
+    ranks = []
+    for r in range(N):
+        rows = np.concatenate([np.arange(max(c0 - H, 0), min(c0 + chunk + H, ny_global)) for c0 in range(r * chunk, ny_global, N * chunk)])
+        row0 = 0 if rows[0] == 0 else (ny_global - rows.size if rows[-1] == ny_global - 1 else 3)
+        sl = eng.to_device(slat[rows], np.float32)
+        a = timed(lambda: eng.advect(field, sl, slon_d, dt, K, 1, True, 0, nt - 1, row0=row0, ny_global=ny_global))
+        ranks.append({"rank": r, "rows": int(rows.size), "advect_ms": round(a, 4), "kernel": eng.last_advect_kernel()})
+    return {"workload": name, "N": N, "chunk_rows": chunk, "ranks": ranks, "worst_advect_ms": max(q["advect_ms"] for q in ranks)}
+
+
 def ensemble(name, n_members, seeds, nt, nsteps):
     u, v, lat, lon = flows.era5_like_on_device(torch, eng.device, nt=nt)
     out = {"workload": name, "members": n_members, "seeds": seeds, "nsteps": nsteps, "per_N": {}}
@@ -183,6 +204,8 @@ for w in which:
         r = row_sharded("c3 strong (4096^2 in all)", 4096, 4096, 97, False)
     elif w == "c4":
         r = row_sharded("c4 strong (8192^2 x 384)", 8192, 8192, 385, False)
+    elif w.startswith("c4i"):       # c4i128: 8 ranks, interleaved chunks of 128 rows with redundant halo rows
+        r = interleaved(f"c4 strong, 8 ranks, interleaved chunks of {w[3:]} rows", 8192, 8192, 385, 8, int(w[3:]))
     elif w.startswith("c4b"):       # c4b32: rows cut by the cost measured over the first 32 levels
         r = row_sharded(f"c4 strong, rows cut by measured cost ({w[3:]} pilot levels)", 8192, 8192, 385, False, int(w[3:]))
     elif w.startswith("c3sb"):
