@@ -162,3 +162,27 @@ def test_config3_return_traj_whole_line_stores_full_size(eng, c3):
         g = 0.1 + 0.9 * (lev - 1) / 23.0
         positions_check(eng, f, slat, slon, rows, cols, xg[lev], yg[lev], (o[np.float32][0][lev], o[np.float32][1][lev]),
                         (o[np.float64][0][lev], o[np.float64][1][lev]), f"C3 traj level {lev}", (1e-4 * g, 5e-4 * g, 2e-3 * g), nsteps=lev)
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_config2_float32_wind_full_size_subset_vs_oracle(eng, order):
+    """configs[1]'s shape as reanalysis data reach the reference: a float32 wind on float64 coordinates, seeds = field nodes
+    (LCS/trajectory.py:68-70, 86-87, 110-112: numpy promotes).  The kernels that keep the wind float32
+    (`advect_lds64w_kernel<4, true>`; at order 3 `advect_lds64w_o3_kernel<4, true>` on float64 coefficients that the one-pass
+    prefilter forms straight from the float32 planes) at full size, a seed subset against the oracle run on the same float32
+    arrays -- which reproduces numpy's promotion by being numpy."""
+    from oracle import lcs_oracle as O
+    u, v, lat, lon = flows.config2(nt=13)
+    u32, v32 = u.astype(np.float32), v.astype(np.float32)
+    f = eng.prepare_field(u32, v32, lat, lon, order)
+    assert f.wind_f32 and f.dtype == np.float64
+    x, y = eng.advect(f, lat, lon, -900.0, SETTLS_order=4, interp_order=order, cyclic_xboundary=True)
+    assert eng.last_advect_kernel() == {1: "advect_lds64w_kernel<4, true>", 3: "advect_lds64w_o3_kernel<4, true>"}[order], eng.last_advect_kernel()
+    rows, cols = _subset(1024, 24, order), _subset(1024, 24, 0)
+    xr_, yr_ = O.parcel_propagation(u32, v32, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=order,
+                                    cyclic_xboundary=True, seed_lat=lat[rows], seed_lon=lon[cols])
+    assert xr_.dtype == np.float64
+    xg, yg = x[rows][:, cols].cpu().numpy(), y[rows][:, cols].cpu().numpy()
+    print(f"C2 float32 wind order {order}: max |dx| {np.abs(xg - xr_).max():.3e} |dy| {np.abs(yg - yr_).max():.3e} deg")
+    np.testing.assert_allclose(xg, xr_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(yg, yr_, rtol=0, atol=1e-9)
