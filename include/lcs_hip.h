@@ -38,7 +38,7 @@ extern "C" {
  * client built against 100 must be rebuilt), lc_ctx_get_level_chunk, lc_ctx_set/get_f64_fidelity, lc_advect_ex and
  * lc_sample_raw added, lc_field_pack accepts packed_dev == NULL at order 1 (fused-level image only).  lc_version() returns the value the LIBRARY
  * was built with: compare it with this macro before any other call (tests/c/abi_smoke.c, _capi.load do). */
-#define LC_VERSION 102 /* 0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify, LC_F64_WIND_F32_LIN32 */
+#define LC_VERSION 103 /* 0.1.3: + lc_ctx_last_pack_kernel (0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify, LC_F64_WIND_F32_LIN32) */
 
 typedef struct lc_ctx lc_ctx;
 
@@ -173,6 +173,11 @@ const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx);
 int lc_ctx_last_advect_launches(const lc_ctx *ctx);
 /* The same for the context's last lc_sigma / lc_flowmap_gradient call. */
 const char *lc_ctx_last_sigma_kernel(const lc_ctx *ctx);
+/* The kernel the last lc_field_pack launched for its first stage (interleave / spline prefilter; "" before any): e.g.
+ * "pack_fused_kernel", "prefilter_fir_kernel", "prefilter_fused_stream_kernel<double>" (float64 order 3, both axes of 64
+ * nodes or more: both prefilter sweeps in one pass), "prefilter_cols_stream_kernel + prefilter_rows_stream_kernel".  The pads
+ * / fused-level pass that follows is not named.  Same lifetime as lc_ctx_last_advect_kernel's string. */
+const char *lc_ctx_last_pack_kernel(const lc_ctx *ctx);
 /* Wave-state audit (diagnostic; no reference counterpart).  mode 1: float32 lc_advect calls that dispatch to the one-seed
  * LDS-tile kernels (orders 1 and 3 below 2^23 seeds per call, SETTLS_order > 0, no whole-line trajectory stores) run their "verify" instances:
  * after the iterations of every time level each wave reads back the tile of the wind image it staged in LDS for that

@@ -79,6 +79,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->last_advect_kernel = "";
     c->last_advect_launches = 0;
     c->last_sigma_kernel = "";
+    c->last_pack_kernel = "";
     c->verify_dev = nullptr;
     c->trunc = nullptr;
     *out = c;
@@ -225,6 +226,7 @@ extern "C" int lc_ctx_read_verify(lc_ctx *ctx, unsigned *out16, int reset) {
 extern "C" const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_advect_kernel : ""; }
 extern "C" int lc_ctx_last_advect_launches(const lc_ctx *ctx) { return ctx ? ctx->last_advect_launches : 0; }
 extern "C" const char *lc_ctx_last_sigma_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_sigma_kernel : ""; }
+extern "C" const char *lc_ctx_last_pack_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_pack_kernel : ""; }
 
 extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
     if (!ctx) return LC_OK;

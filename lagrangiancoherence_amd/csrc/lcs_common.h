@@ -32,6 +32,7 @@ struct lc_ctx {
     int last_advect_launches;  // kernel launches the last lc_advect made (level chunks)
     const char *last_advect_kernel;
     const char *last_sigma_kernel;
+    const char *last_pack_kernel;   // what the last lc_field_pack launched for the prefilter / interleave stage (lc_ctx_last_pack_kernel)
     unsigned *verify_dev;  // NULL, or 16 uint32 wave-state counters in device memory (lc_ctx_set_verify)
     lc_trunc_cache *trunc;
 };

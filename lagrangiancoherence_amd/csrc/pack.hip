@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(FS_MAXW * 64) prefilter_fused_stream_kernel(co
     __shared__ double ends[2][FS_ROWS][FS_C][2];
     __shared__ double zp[2][8];
     for (int i = threadIdx.x; i < 2 * FS_ROWS * FS_C * 2; i += blockDim.x) (&ends[0][0][0][0])[i] = 0.0;  // (the rows beside the workgroup's stay 0)
-    const double z = -0.26794919243112270647, gain = 6.0, zend = z / (z * z - 1.0);
+    const double z = -0.26794919243112270647, gain = 6.0;
     const int nw = blockDim.x >> 6, xout = 32 * (nw - 2);
     // the 8 XCDs take consecutive runs of (level, x block) items: blocks i, i + 8, ... (one XCD) are neighbours in x
     // (the items past split.n_whole come in split.pieces row pieces each: lcplan::fused_prefilter_split; every XCD takes an
@@ -1048,6 +1048,7 @@ int pack_impl(lc_ctx *ctx, const TIN *u, const TIN *v, int nt, int ny, int nx, i
         const int nchunk = (nt + PACK_LV - 1) / PACK_LV;
         hipLaunchKernelGGL(pack_fused_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nchunk < 65535 ? nchunk : 65535),
                            dim3(threads), 0, ctx->stream, u, v, packed, ext, nt, ny, nx);
+        ctx->last_pack_kernel = "pack_fused_kernel";
         LC_HIP_CHECK(hipGetLastError());
         return LC_OK;
     }
@@ -1060,6 +1061,7 @@ int pack_impl(lc_ctx *ctx, const TIN *u, const TIN *v, int nt, int ny, int nx, i
             const dim3 grid((nx + FT - 1) / FT, (ny + FT - 1) / FT, nt * (both ? 2 : 1));
             hipLaunchKernelGGL(prefilter_fir_kernel, grid, dim3(256), 0, ctx->stream, u, v, packed, both ? ext : nullptr, nt, ny, nx,
                                cubic_fir_taps());
+            ctx->last_pack_kernel = "prefilter_fir_kernel";
             if (ext && nt >= 2 && !both) {  // ext = 2 img[t] - img[t+1] from the finished coefficients (pads rewritten, same values)
                 const int nchunk = (nt + PACK_LV - 1) / PACK_LV;
                 hipLaunchKernelGGL(pads_ext_kernel<T>, dim3((nx + LC_PAD + 255) / 256, ny + LC_PAD < 65535 ? ny + LC_PAD : 65535, nchunk < 65535 ? nchunk : 65535), dim3(threads), 0, ctx->stream, packed, ext, nt, ny, nx);
@@ -1084,6 +1086,7 @@ int pack_impl(lc_ctx *ctx, const TIN *u, const TIN *v, int nt, int ny, int nx, i
                 hipLaunchKernelGGL(prefilter_fused_stream_kernel<TIN>, dim3(per * 8), dim3(nw * 64), 0, ctx->stream, u, v, packed, nt, ny, nx, nxb,
                                    split);
                 fused = true;
+                ctx->last_pack_kernel = std::is_same<TIN, float>::value ? "prefilter_fused_stream_kernel<float>" : "prefilter_fused_stream_kernel<double>";
             }
             if (cols_stream && !fused)
                 hipLaunchKernelGGL(prefilter_cols_stream_kernel<TIN>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, ctx->stream, u, v,
@@ -1092,6 +1095,11 @@ int pack_impl(lc_ctx *ctx, const TIN *u, const TIN *v, int nt, int ny, int nx, i
         if (!cols_stream)
             hipLaunchKernelGGL((prefilter_cols_kernel<T, TIN>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0,
                                ctx->stream, u, v, packed, nt, ny, nx);
+        if (!fused)   // one sweep per axis: the streaming form where the axis is long enough (float64), the two-march kernels otherwise
+            ctx->last_pack_kernel = (cols_stream && stream && nx >= RS_RING) ? "prefilter_cols_stream_kernel + prefilter_rows_stream_kernel"
+                                    : cols_stream                            ? "prefilter_cols_stream_kernel + prefilter_rows_kernel"
+                                    : (stream && nx >= RS_RING)              ? "prefilter_cols_kernel + prefilter_rows_stream_kernel"
+                                                                             : "prefilter_cols_kernel + prefilter_rows_kernel";
         if (fused) {
         } else if (stream && nx >= RS_RING) {
             if constexpr (sizeof(T) == 8)
@@ -1108,6 +1116,7 @@ int pack_impl(lc_ctx *ctx, const TIN *u, const TIN *v, int nt, int ny, int nx, i
     } else {  // orders 2, 4, 5: generic pole lists, thread per line
         hipLaunchKernelGGL((pack_interior_kernel<T, TIN>), dim3(blocks), dim3(threads), 0, ctx->stream, u, v, packed, ny, nx,
                            nodes);
+        ctx->last_pack_kernel = "pack_interior_kernel + prefilter_general_kernel";
         const PoleList P = spline_poles(order);
         const size_t l0 = (size_t)nt * nx * 2, l1 = (size_t)nt * ny * 2;
         hipLaunchKernelGGL(prefilter_general_kernel<T>, dim3((unsigned)((l0 + 63) / 64)), dim3(64), 0, ctx->stream, packed, nt,

@@ -260,6 +260,10 @@ class Engine:
         return self.lib.lc_ctx_last_sigma_kernel(self.ctx).decode()
 
     # ------------------------------------------------------------------ plumbing
+    def last_pack_kernel(self) -> str:
+        """The kernel the last ``lc_field_pack`` launched for its interleave / prefilter stage (``lc_ctx_last_pack_kernel``)."""
+        return self.lib.lc_ctx_last_pack_kernel(self.ctx).decode()
+
     def _use_current_stream(self):
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         _capi.check(self.lib.lc_ctx_set_stream(self.ctx, C.c_void_p(s)), self.lib)

@@ -40,6 +40,7 @@ def test_config3_full_size_subset_vs_oracle(eng, c3, order):
     from oracle import lcs_oracle as O
     u, v, lat, lon, slat, slon = c3
     f = eng.prepare_field(u, v, lat, lon, order)
+    assert eng.last_pack_kernel() == {1: "pack_fused_kernel", 3: "prefilter_fir_kernel"}[order], eng.last_pack_kernel()
     x, y = eng.advect(f, slat, slon, -900.0, SETTLS_order=4, interp_order=order, cyclic_xboundary=True)
     # the kernel BASELINE configs[2] is dispatched to (asserted so a change of the launcher's size thresholds cannot
     # silently move the configuration onto a kernel variant without an oracle anchor)
@@ -118,6 +119,7 @@ def test_config2_order3_full_size_subset_vs_oracle(eng):
     from oracle import lcs_oracle as O
     u, v, lat, lon = flows.config2(nt=13)
     f = eng.prepare_field(u, v, lat, lon, 3)
+    assert eng.last_pack_kernel() == "prefilter_fused_stream_kernel<double>", eng.last_pack_kernel()   # both prefilter sweeps in one pass (round 5)
     x, y = eng.advect(f, lat, lon, -900.0, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
     assert eng.last_advect_kernel() == "advect_lds64_o3_kernel<4, true>", eng.last_advect_kernel()
     rows, cols = _subset(1024, 24, 3), _subset(1024, 24, 0)
@@ -176,6 +178,7 @@ def test_config2_float32_wind_full_size_subset_vs_oracle(eng, order):
     u32, v32 = u.astype(np.float32), v.astype(np.float32)
     f = eng.prepare_field(u32, v32, lat, lon, order)
     assert f.wind_f32 and f.dtype == np.float64
+    assert eng.last_pack_kernel() == {1: "pack_fused_kernel", 3: "prefilter_fused_stream_kernel<float>"}[order], eng.last_pack_kernel()
     x, y = eng.advect(f, lat, lon, -900.0, SETTLS_order=4, interp_order=order, cyclic_xboundary=True)
     assert eng.last_advect_kernel() == {1: "advect_lds64w_kernel<4, true>", 3: "advect_lds64w_o3_kernel<4, true>"}[order], eng.last_advect_kernel()
     rows, cols = _subset(1024, 24, order), _subset(1024, 24, 0)

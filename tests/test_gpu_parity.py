@@ -773,7 +773,10 @@ def test_one_pass_prefilter_matches_the_recursive_sweeps(eng, O, monkeypatch):
     monkeypatch.setenv("LCS_FIR_PREFILTER", "0")
     eng0 = Engine(0)
     monkeypatch.delenv("LCS_FIR_PREFILTER")
-    a, b = eng.prepare_field(u, v, lat, lon, 3), eng0.prepare_field(u, v, lat, lon, 3)
+    a = eng.prepare_field(u, v, lat, lon, 3)
+    assert eng.last_pack_kernel() == "prefilter_fir_kernel", eng.last_pack_kernel()
+    b = eng0.prepare_field(u, v, lat, lon, 3)
+    assert eng0.last_pack_kernel() == "prefilter_cols_kernel + prefilter_rows_kernel", eng0.last_pack_kernel()
     scale = float(np.abs(u).max())
     for name in ("cub", "ext"):
         x, y = _np(getattr(a, name)).astype(np.float64), _np(getattr(b, name)).astype(np.float64)
@@ -808,7 +811,12 @@ def test_float64_streaming_prefilter_matches_the_two_march_sweeps_and_scipy(eng,
     monkeypatch.setenv("LCS_FIR_PREFILTER", "0")
     eng0 = Engine(0)
     monkeypatch.delenv("LCS_FIR_PREFILTER")
-    a, b = eng.prepare_field(u, v, lat, lon, 3), eng0.prepare_field(u, v, lat, lon, 3)
+    a = eng.prepare_field(u, v, lat, lon, 3)
+    cols, rows = ("prefilter_cols_stream_kernel" if ny >= 64 else "prefilter_cols_kernel"), ("prefilter_rows_stream_kernel" if nx >= 64 else "prefilter_rows_kernel")
+    if os.environ.get("LCS_FUSED_PREFILTER", "1") != "0":
+        assert eng.last_pack_kernel() == ("prefilter_fused_stream_kernel<double>" if ny >= 64 and nx >= 64 else f"{cols} + {rows}"), eng.last_pack_kernel()
+    b = eng0.prepare_field(u, v, lat, lon, 3)
+    assert eng0.last_pack_kernel() == "prefilter_cols_kernel + prefilter_rows_kernel", eng0.last_pack_kernel()
     scale = float(np.abs(u).max())
     for name in ("cub", "ext"):
         x, y = _np(getattr(a, name)), _np(getattr(b, name))
