@@ -169,14 +169,60 @@ def pmc_passes(counter_sets, kernels, bench_args, timeout_s: float = 150.0):
                 for r in csv.DictReader(open(f)):
                     if r["Counter_Name"] not in counters:
                         continue
-                    name = r["Kernel_Name"].replace("void ", "")           # "void (anonymous namespace)::kernel<...>((anonymous namespace)::Args<T>)"
-                    name = (name.split("(anonymous namespace)::", 1)[1] if "(anonymous namespace)::" in name else name).split("(")[0]
+                    name = short_kernel_name(r["Kernel_Name"])
                     for k in kernels:
                         if kernel_name_matches(name, k):
                             vals.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return vals, None
+
+
+def short_kernel_name(name: str) -> str:
+    """rocprofv3's "void (anonymous namespace)::kernel<...>((anonymous namespace)::Args<T>)" -> "kernel<...>"."""
+    name = name.replace("void ", "")
+    return (name.split("(anonymous namespace)::", 1)[1] if "(anonymous namespace)::" in name else name).split("(")[0]
+
+
+def kernel_trace_pass(bench_args, steps: int = 5, warmup: int = 1, timeout_s: float = 150.0):
+    """ONE `rocprofv3 --kernel-trace --stats` child pass of this same command (`steps` headline steps, nothing else): the
+    profiler's own per-kernel durations ON THE BOX THAT PRODUCED THE LINE, so that the committed kernel-trace summary and
+    `kernel_ms` (HIP events of the timed region) can be held against each other in one record.  No counters in this pass
+    (tracing and --pmc never share a pass).  Returns ({kernel: {"calls", "avg_ms", "min_ms", "max_ms"}}, None) for this
+    library's kernels, or ({}, why)."""
+    import csv
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {}, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="lcs_kt_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(tmp, "kt"), "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-secondary",
+               "--no-live-counters"] + list(bench_args)
+        p = subprocess.Popen(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
+                             stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.wait()
+            return {}, f"rocprofv3 --kernel-trace --stats pass exceeded {timeout_s:.0f} s"
+        if rc != 0:
+            return {}, f"rocprofv3 --kernel-trace --stats pass exited {rc}"
+        out = {}
+        for f in glob.glob(os.path.join(tmp, "kt", "**", "*_kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "anonymous namespace)::" not in r["Name"] or "at::native" in r["Name"]:
+                    continue
+                out[short_kernel_name(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                                     "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6}
+        return (out, None) if out else ({}, "no kernel of this library in the kernel-trace statistics")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def live_traffic(kernels, bench_args, timeout_s: float = 150.0):
@@ -208,7 +254,7 @@ def live_limiting_unit(kernel, steps_per_launch, bench_args, timeout_s: float = 
     der = derived_unit_figures(c, steps_per_launch)
     if not der:
         return {"error": "no launch of " + kernel + " in the counter passes"}
-    return {"limiting_unit": {k: round(v, 4) for k, v in der.items() if v is not None},
+    return {"limiting_unit": {k: round(v, 4) for k, v in der.items() if v is not None}, "counters": c,
             "source": "live: four `rocprofv3 --pmc` child passes of this command (2 steps each; counter sets: UNIT_SETS in bench.py), "
                       "per-launch averages"}
 
@@ -238,6 +284,19 @@ def stamped_counters(kernel: str, workload: dict, csrc: str):
     return out
 
 
+def binding_of(bound, lu):
+    """{"unit", "frac"} of the unit that limits an advect kernel, from its derived counter figures (None without them)."""
+    if not lu:
+        return None
+    if bound == "valu" and lu.get("valu_issue_frac") is not None:
+        return {"unit": "valu_issue", "frac": lu["valu_issue_frac"],
+                "definition": "SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x CUs): cycles in which a CU's SIMDs issue vector instructions"}
+    if lu.get("tcp_lookups_per_cu_cycle") is not None:
+        return {"unit": "vector_l1_lookups", "frac": lu["tcp_lookups_per_cu_cycle"],
+                "definition": "TCP_TOTAL_CACHE_ACCESSES / CU-cycles (one tag lookup per CU and cycle)"}
+    return None
+
+
 def roofline(kernel, bound, pts_per_launch, launches_ms, K, order, s_p, s_f, fused, compulsory_bytes, workload, csrc, n_kernel=1):
     """The roofline object of ONE advect kernel launch (per GPU).  `launches_ms`: mean HIP-event duration of one lc_advect
     call, which is `n_kernel` consecutive launches of the same kernel (level chunks): particle-timesteps, bytes and time
@@ -256,6 +315,13 @@ def roofline(kernel, bound, pts_per_launch, launches_ms, K, order, s_p, s_f, fus
         "flops_per_particle_timestep": fl, "kernel_ms": launches_ms, "kernel_launches_per_advect": n_kernel,
         "traffic": tr,
         "algorithmic_GBps": pts_per_launch * by / sec / 1e9, "algorithmic_bytes_per_particle_timestep": by,
+        # SURVEY 8d's byte figure over the HBM peak.  NOT a fraction of anything the kernel does (it charges 2+4K scalar
+        # 4-tap interpolations per step to memory; the kernel takes 1+K interleaved 2x2 windows, K of them from LDS): a
+        # value above 1 says the byte model does not describe the kernel, not that the kernel beats the memory system.
+        "algorithmic_over_hbm_peak": pts_per_launch * by / sec / 1e9 / HBM_PEAK_GBPS,
+        # the unit that actually binds, as a fraction of ITS peak (the share of cycles in which the SIMDs issue a vector
+        # instruction -- or the vector L1's lookup rate for the direct-gather kernels); null without counters
+        "binding": binding_of(bound, st.get("limiting_unit")),
         "hbm": {"peak_GBps": HBM_PEAK_GBPS, "compulsory_bytes": compulsory_bytes,
                 "compulsory_frac": compulsory_bytes / sec / 1e9 / HBM_PEAK_GBPS,
                 "traffic_bytes": tr, "hbm_traffic_frac": (tr / sec / 1e9 / HBM_PEAK_GBPS) if tr else None,
@@ -267,6 +333,31 @@ def roofline(kernel, bound, pts_per_launch, launches_ms, K, order, s_p, s_f, fus
                 "algorithmic_GBps is SURVEY 8d's tap-byte figure (cache-served, may exceed HBM peak); "
                 "traffic / limiting_unit are replayed from hash-stamped rocprofv3 summaries or null",
     }
+
+
+def save_profiles(out_dir, line, workload, build_id, kt, live, lu, advect_kernel, sigma_kernel, tag="c3_o1"):
+    """The default run's live profiler passes as files (the layout of profiles/rNN/<tag>_*: stamped_counters() reads them back)."""
+    import csv
+    os.makedirs(out_dir, exist_ok=True)
+    if kt:
+        with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "avg_ms", "min_ms", "max_ms"])
+            for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1]["calls"]):
+                w.writerow([k, v["calls"], "%.4f" % v["avg_ms"], "%.4f" % v["min_ms"], "%.4f" % v["max_ms"]])
+    kernels = {k: {"hbm_bytes_per_launch": v["traffic"], "launches": v["launches"]} for k, v in live.items() if isinstance(v, dict) and "traffic" in v}
+    if kernels:
+        json.dump({"workload": workload, "csrc_hash": build_id, "kernels": kernels,
+                   "note": "bench.py --save-profiles: hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts half), "
+                           "from this run's own `rocprofv3 --pmc` child passes"},
+                  open(os.path.join(out_dir, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    if lu.get("limiting_unit"):
+        json.dump({"workload": workload, "csrc_hash": build_id,
+                   "kernels": {advect_kernel: {**{k: v for k, v in lu.get("counters", {}).items()}, "derived": lu["limiting_unit"]}},
+                   "note": "bench.py --save-profiles: per-launch averages of this run's own `rocprofv3 --pmc` child passes (UNIT_SETS); "
+                           "GRBM_GUI_ACTIVE is summed over 8 XCDs"},
+                  open(os.path.join(out_dir, tag + "_pmc_sq_tcp.json"), "w"), indent=1, sort_keys=True)
+    json.dump(line, open(os.path.join(out_dir, tag + "_bench_stdout.json"), "w"))
 
 
 def cpu_baseline(flows, u, v, lat, lon, dt, K, order, nsteps):
@@ -469,6 +560,17 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
     nt = int(ud.shape[0])
     ny, nx = int(slat_d.numel()), int(slon_d.numel())
     sig32 = lambda r: eng.sigma(r[0], r[1], slat_d, dlat, dlon)
+    # SETTLS_order 0 (the LIBRARY default, LCS/trajectory.py:14, LCS/LCS.py:26: one Euler sample per level, the direct-gather
+    # kernel -- include/lcs_hip.h), 1 and 2 on the headline field ("also report K=0 and order 3")
+    for Kx in (0, 1, 2):
+        case(f"c3 K={Kx}", ny * nx * (nt - 1), Kx, 1, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 1),
+             lambda f, Kx=Kx: eng.advect(f, slat_d, slon_d, -900.0, Kx, 1, True), sig32)
+        if "error" not in out[f"c3 K={Kx}"]:
+            e = out[f"c3 K={Kx}"]
+            by = b_adv(Kx, 1, 4, 4)
+            e["algorithmic_bytes_per_particle_timestep"] = by
+            e["algorithmic_GBps"] = ny * nx * (nt - 1) * by / (e["kernel_ms"]["advect"] / 1e3) / 1e9
+            e["algorithmic_over_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBPS
     case("c3 order 3", ny * nx * (nt - 1), K, 3, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 3),
          lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 3, True), sig32)
     case("c3 return_traj", ny * nx * (nt - 1), K, 1, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 1),
@@ -520,6 +622,61 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
              lambda f: sharded.ensemble_advect(eng, f, s5lat_d, s5lon_d, -900.0, list(range(c5_m)), c5_steps, K, 1, True), c5_sigma)
     except Exception as exc:
         out["c4 on one GPU"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    return out
+
+
+def config1_dropin(flows, with_oracle: bool, reps: int = 5):
+    """BASELINE configs[0] -- the reference's own example (examples/ideal_vortex.py:220-223,262-288: 89 x 180 nodes, 8
+    levels, float64, order 3) -- END TO END through the drop-in surface a reference user calls:
+    ``LagrangianCoherence.LCS.LCS.LCS(timestep, SETTLS_order=4)(ds, isglobal=True, interp_to_common_grid=False,
+    truncation=None)`` and ``trajectory.parcel_propagation(U, V, ...)``, host arrays in, labelled arrays out (xarray
+    objects where xarray is installed; tests/labelled.py's stand-in otherwise: the same adapter code).  Wall time per
+    call, median of `reps` after one warm-up -- launch- and host-bound (16 020 seeds): what the stock example costs a user.
+    `with_oracle`: the CPU oracle's time for the same two computations on this host, beside it."""
+    import pandas as pd
+    try:
+        import xarray as xr
+        mk = lambda a, name: xr.DataArray(a, dims=['latitude', 'longitude', 'time'], coords=coords, name=name)
+        mkds = lambda U, V: xr.Dataset({'u': U, 'v': V})
+        container = "xarray"
+    except ImportError:
+        from tests import labelled
+        mk = lambda a, name: labelled.DataArray(a, ['latitude', 'longitude', 'time'], coords, name=name)
+        mkds = lambda U, V: labelled.Dataset({'u': U, 'v': V})
+        container = "tests/labelled.py stand-in (no xarray in this image)"
+    from LagrangianCoherence.LCS import LCS as LCSmod, trajectory
+    u, v, lat, lon = flows.config1()
+    coords = {'latitude': lat, 'longitude': lon, 'time': pd.date_range('2000-01-01', periods=u.shape[0], freq='6h').values}
+    ds = mkds(mk(u.transpose(1, 2, 0), 'u'), mk(v.transpose(1, 2, 0), 'v'))
+
+    def med(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
+    lcs_ms = med(lambda: LCSmod.LCS(timestep=-6 * 3600, timedim='time', SETTLS_order=4)(
+        ds.copy(), isglobal=True, interp_to_common_grid=False, truncation=None, verbose=False))
+    pp_ms = med(lambda: trajectory.parcel_propagation(ds.u, ds.v, timestep=-6 * 3600, propdim='time', SETTLS_order=4, copy=True,
+                                                      return_traj=True, cyclic_xboundary=True, verbose=False))
+    n = int(lat.size * lon.size) * (int(u.shape[0]) - 1)
+    out = {"config": "BASELINE configs[0]: examples/ideal_vortex.py, 89x180 nodes = seeds, 8 levels (7 steps of 6 h), float64, "
+                     "SETTLS_order 4, interp_order 3 (the default), cyclic", "container": container,
+           "LCS_call_ms": lcs_ms, "parcel_propagation_return_traj_ms": pp_ms,
+           "LCS_particle_timesteps_per_s": n / (lcs_ms / 1e3),
+           "note": "wall time of the Python call, host arrays in / labelled arrays out: H2D of 2 x 1 MB, prefilter, advect, sigma, D2H "
+                   "and the adapter's sorting / labelling; launch- and host-bound at this size"}
+    if with_oracle:
+        from oracle import lcs_oracle as O
+        t0 = time.perf_counter()
+        O.lcs(u, v, lat, lon, timestep=-21600.0, SETTLS_order=4, interp_order=3, cyclic_xboundary=True)
+        t1 = time.perf_counter()
+        O.parcel_propagation(u, v, lat, lon, timestep=-21600.0, SETTLS_order=4, interp_order=3, cyclic_xboundary=True, return_traj=True)
+        t2 = time.perf_counter()
+        out["cpu_oracle_lcs_ms"], out["cpu_oracle_parcel_propagation_ms"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+        out["cpu_oracle"] = "oracle/lcs_oracle.py on one host core (numpy + scipy restatement; the reference itself adds xarray overhead)"
     return out
 
 
@@ -677,6 +834,11 @@ def main():
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in the default "
                          "one-GPU c3 run (the hash-stamped summaries under profiles/ are replayed instead; also skipped with "
                          "--no-secondary / --no-cpu-baseline and when the run is itself under rocprofv3)")
+    ap.add_argument("--save-profiles", default=None, metavar="DIR",
+                    help="default one-GPU c3 run: also write what the live profiler passes measured -- the kernel-trace "
+                         "statistics, the traffic and SQ / TCP counter summaries (the format profiles/*/c3_o1_* has, stamped "
+                         "with the library's build id) and the line itself -- into DIR: profiles/rNN/ regenerated by the run "
+                         "that produced the number")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the non-headline workloads the default one-GPU c3 run appends under \"secondary\"")
     ap.add_argument("--traj", action="store_true",
@@ -940,6 +1102,7 @@ def main():
     if sig is not None:
         assert bool(torch.isfinite(sig).all()), "non-finite sigma in the benchmark output"
     advect_kernel = eng.last_advect_kernel()
+    pack_kernel = eng.last_pack_kernel()
 
     # ---- halo check (outside the timed region): the rows received must equal, bit for bit, the same rows
     # advected redundantly by this rank (LCS_NATIVE_HALO=1 times and checks the C ABI's lc_halo_exchange instead)
@@ -1094,8 +1257,13 @@ def main():
         del sig, x_ext, y_ext, field          # the headline's outputs: the secondary cases reuse the memory
         torch.cuda.empty_cache()
         out["secondary"] = secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dlat, dlon)
+        try:
+            out["secondary"]["c1 through the drop-in"] = config1_dropin(flows, not args.no_cpu_baseline)
+        except Exception as exc:
+            out["secondary"]["c1 through the drop-in"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     # ---- roofline.traffic measured by this run (default one-GPU run only): two counter-only child passes of this command ----
     profiled = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)      # this run is itself under rocprofv3
+    to_save = None
     if plain and not (args.no_live_counters or args.no_secondary or args.no_cpu_baseline or profiled):
         sk = out["roofline_sigma"]["kernel"]        # (the headline's: the secondary cases have launched others since)
         torch.cuda.empty_cache()
@@ -1124,12 +1292,50 @@ def main():
                                                 "so is limiting_unit; the *_replayed fields are the committed profiles/ summaries' values")
             else:
                 rf["limiting_unit_live_error"] = lu["error"]
+            rf["binding"] = binding_of(rf["bound"], rf["limiting_unit"])
             rf["hbm"]["counter_passes_s"] = round(time.time() - t_live, 1)
         else:
             rf["hbm"]["traffic_live_error"] = live.get("error", "advect kernel not in the counter passes")
+            lu = {}
+        # ---- K = 0: the one setting where SURVEY 8d's bytes (48 B) could bind on HBM -- its measured traffic, two more passes ----
+        k0 = out.get("secondary", {}).get("c3 K=0")
+        if k0 and "error" not in k0:
+            lv0 = live_traffic([k0["kernel"]], ["--settls", "0"])
+            if k0["kernel"] in lv0:
+                k0["traffic"] = lv0[k0["kernel"]]["traffic"]
+                k0["hbm_traffic_frac"] = k0["traffic"] / (k0["advect_kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBPS
+                k0["traffic_source"] = lv0["source"]
+            else:
+                k0["traffic_live_error"] = lv0.get("error")
+        # ---- the profiler's own kernel durations on THIS box: one --kernel-trace --stats child pass of this command ----
+        t_kt = time.time()
+        kt, kt_err = kernel_trace_pass([], steps=args.steps, warmup=args.warmup)
+        if kt_err:
+            out["kernel_ms_rocprof"] = {"error": kt_err}
+        else:
+            def avg_of(name):
+                hit = [v for k, v in kt.items() if kernel_name_matches(k, name)]
+                return hit[0] if hit else None
+            ka, ks_, kp = avg_of(advect_kernel), avg_of(sk), avg_of(pack_kernel or "pack_fused_kernel")
+            n_adv = rf["kernel_launches_per_advect"]
+            per_step = {"pack": kp["avg_ms"] if kp else None, "advect": ka["avg_ms"] * n_adv if ka else None,
+                        "sigma": ks_["avg_ms"] if ks_ else None}
+            tot = sum(v for v in per_step.values() if v is not None)
+            out["kernel_ms_rocprof"] = {
+                **per_step, "sum": tot, "fits_in_ms_per_step": bool(tot <= out["ms_per_step"]),
+                "advect_kernel_avg_ms": ka["avg_ms"] if ka else None, "advect_kernel_min_max_ms": [ka["min_ms"], ka["max_ms"]] if ka else None,
+                "advect_kernel_calls": ka["calls"] if ka else None, "pass_s": round(time.time() - t_kt, 1),
+                "source": f"live: one `rocprofv3 --kernel-trace --stats` child pass of this command ({args.steps} steps, "
+                          f"{args.warmup} warm-up) after the timed region; per step = the kernel's average duration x its launches "
+                          "per step; kernel_ms beside it is the HIP-event time of the timed region itself"}
+            rf["kernel_ms_rocprof"] = ka["avg_ms"] if ka else None
+        if args.save_profiles:
+            to_save = (kt, live, lu, sk)
     # ---- CPU baseline: the oracle (numpy+scipy port) on a bounded sample, rank 0, N=1 only ----
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(flows, u, v, lat, lon, dt, K, order, nsteps)
+    if to_save is not None:
+        save_profiles(args.save_profiles, out, wl, build_id, to_save[0], to_save[1], to_save[2], advect_kernel, to_save[3])
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

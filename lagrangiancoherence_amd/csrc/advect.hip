@@ -1356,12 +1356,43 @@ __device__ __forceinline__ f2 window_global(const float *__restrict__ lvl, const
     return start + fetch1_f(lvl, g, row_bytes);
 }
 
+// The Euler sample: the sample alone (order 1: no `0 + ...` in front of it -- the compiler may not drop an addition of +0,
+// x + 0 differs from x for x = -0 -- one packed add per seed and level less; the value is the direct-gather kernel's).
+template <int ORDER>
+__device__ __forceinline__ f2 euler_global(const float *__restrict__ lvl, const AdvectArgs<float> &A, const TapL &t) {
+    if (ORDER == 3) return window_global<3>(lvl, A, t, (f2){0.0f, 0.0f});
+    const unsigned x0 = min((unsigned)t.x0, (unsigned)(A.nx_f - 1)), y0 = min((unsigned)t.y0, (unsigned)(A.ny_f - 1));
+    TapF g;
+    g.byte_off = (__umul24(y0, (unsigned)A.pitch) + x0) * 8u + ((unsigned)A.pitch + 1u) * 8u;
+    g.tx = t.tx;
+    g.ty = t.ty;
+    return fetch1_f(lvl, g, (unsigned)A.pitch * 8u);
+}
+
 // trajectory.py:89-94 on a packed position: latitude clamp in one v_med3_f32 (a NaN input makes med3
 // return min3 = y_min, which is Q8's rule; ``ymax_v`` lives in a VGPR because a VOP3 takes one SGPR);
 // the cyclic wrap is the exact reference sequence in a rare branch.
 __device__ __forceinline__ void clamp_position_p(const AdvectArgs<float> &A, f2 &p, float ymax_v) {
     p.y = __builtin_amdgcn_fmed3f(p.y, A.y_min, ymax_v);
     if (A.cyclic) {
+        if (!(fabsf(p.x) < 180.0f)) {  // rare (Q7)
+            float x = p.x;
+            if (!(x > -180.0f)) x = pymod180<float>(x);
+            if (!(x < 180.0f)) x = -180.0f + pymod180<float>(x);
+            p.x = x;
+        }
+    } else if (p.x < A.x_min || p.x > A.x_max) {  // NaN stays NaN, as in the reference
+        if (A.clamp_flag) *A.clamp_flag = 1u;
+        p.x = p.x < A.x_min ? A.x_min : A.x_max;
+    }
+}
+
+// ... with the boundary kind known at compile time (the kernels are instantiated per kind: no uniform branch on A.cyclic,
+// one v_cmp + one exec-masked rare block per call)
+template <bool CYCLIC>
+__device__ __forceinline__ void clamp_position_c(const AdvectArgs<float> &A, f2 &p, float ymax_v) {
+    p.y = __builtin_amdgcn_fmed3f(p.y, A.y_min, ymax_v);
+    if (CYCLIC) {
         if (!(fabsf(p.x) < 180.0f)) {  // rare (Q7)
             float x = p.x;
             if (!(x > -180.0f)) x = pymod180<float>(x);
@@ -1574,14 +1605,14 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
                 const unsigned ebase = etile_addr + (unsigned)(lx - sox) * 8u + (unsigned)(ly - soy) * ((unsigned)E::PITCH * 8u);
                 e = window_lds<ORDER, E::PITCH, VERIFY>(ebase, epitch_bytes, rx, ry, t, zero);
             } else {
-                e = window_global<ORDER>(lvl, A, t, zero);
+                e = euler_global<ORDER>(lvl, A, t);
             }
             f2 pn = dd * e + p;
             bad |= x_needs_care(pn.x);
             if (bad) {  // exact sequence
                 c0 = index_coords(A, p);
                 t = tap_of(c0);
-                e = window_global<ORDER>(lvl, A, t, zero);
+                e = euler_global<ORDER>(lvl, A, t);
                 pn = dd * e + p;
                 clamp_position_p(A, pn, ymax_v);
             }
@@ -1725,8 +1756,14 @@ constexpr int SPL = 2;  // seeds per lane
 #ifndef LCS_LDS2_COLS
 #define LCS_LDS2_COLS 16
 #endif
+#ifndef LCS_LDS2_PITCH
+#define LCS_LDS2_PITCH (LCS_LDS2_COLS + 4)
+#endif
 struct Lds2Geom {  // staging: a tile row = COLS/2 lanes x 16 bytes
     static constexpr int COLS = LCS_LDS2_COLS, LANES_PER_ROW = COLS / 2, ROWS_PER_PASS = 64 / LANES_PER_ROW;
+    // one pass of 64 lanes covers the tile, or the tile is a whole number of full passes (a row count that 64 lanes do not
+    // divide -- 12 x 10 nodes: 6 lanes per row, 10 rows, lanes 60..63 over -- has the spare lanes repeat the last row)
+    static_assert(LCS_LDS2_ROWS % ROWS_PER_PASS == 0 || LCS_LDS2_ROWS < ROWS_PER_PASS + 1, "tile rows per staging pass");
 };
 
 #ifdef LCS_STAMPS  // diagnostic build only: where a wave's cycles go (s_memtime), summed over waves and levels
@@ -1776,6 +1813,15 @@ constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byt
 #ifndef LCS_LDS2_MINWAVES
 #define LCS_LDS2_MINWAVES 1
 #endif
+// DEFER_X (round 6): the longitude wrap / clamp of trajectory.py:93-97,119-123 is deferred exactly as the latitude clamp
+// already was.  A longitude the reference would touch -- x <= -180 or x >= 180 (cyclic), x < x_min or x > x_max (not) -- maps
+// to an index outside [0, n-1), which the NEXT sample's window test flags by itself, and the exact-redo path starts by
+// applying both clamps to the position it was handed; the level ends with one clamp of each kind (stores, next Euler
+// sample).  Same values as clamping after every update (the clamps are pure functions of the position), one v_cmp + one
+// s_or fewer per sample: 10 VALU and 10 SALU of the 260 / 134 per wave-level.  -DLCS_LDS2_DEFER_X=0 is the round-5 form.
+#ifndef LCS_LDS2_DEFER_X
+#define LCS_LDS2_DEFER_X 1
+#endif
 template <int KFIX, bool CYCLIC, int MODE>
 __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgpu_num_sgpr(LCS_LDS2_NUM_SGPR)))
     advect_lds2_kernel(const AdvectArgs<float> A0) {
@@ -1784,6 +1830,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES, GROUP = MODE == PATCH_PAIR;
     constexpr int NS = SPL;  // seeds per lane (member groups: members per lane)
     constexpr int ORDER = 1;
+    constexpr bool DEFER_X = LCS_LDS2_DEFER_X != 0;
     const int K = KFIX >= 0 ? KFIX : A.K;
     typedef Lds2Geom G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = LCS_LDS2_ROWS;
@@ -1792,7 +1839,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     // once per sample (2 per sample and seed), and a window is two 16-byte reads instead of four 8-byte ones.
     // Same values as n00 + tx * (n01 - n00): results stay bit-identical to the other float kernels.
     // Pitch 20 entries: rows shift 16 banks, no conflicts between neighbouring rows for ds_read_b128.
-    constexpr int LT_PITCH = LT_COLS + 4;
+    constexpr int LT_PITCH = LCS_LDS2_PITCH;
     constexpr int WIN = 2, WOFF = LC_PAD_LO;
     __shared__ __attribute__((aligned(16))) f4 s_tiles[BLOCK / 64][LT_ROWS * LT_PITCH];
     // PATCH_LINES: two slabs (alternating by level) of the workgroup's 16 x 32 longitudes and latitudes
@@ -1889,9 +1936,9 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     const float *elv = A.ext + (size_t)A.t0 * A.level_elems;
     const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
     const float kpred = 0.5f * (float)(K > 0 ? K - 1 : 0);
-    const int st_row = lane / G::LANES_PER_ROW, st_col = (lane % G::LANES_PER_ROW) * 2;
+    const int st_row = min(lane / G::LANES_PER_ROW, LT_ROWS - 1), st_col = (lane % G::LANES_PER_ROW) * 2;
     const unsigned st_off = ((unsigned)st_row * (unsigned)pad_cols + (unsigned)st_col) * 8u;
-    constexpr int NPASS = LT_ROWS / G::ROWS_PER_PASS;
+    constexpr int NPASS = (LT_ROWS + G::ROWS_PER_PASS - 1) / G::ROWS_PER_PASS;
     // node c+2 of the lane's tile row (the x-difference of node c+1 needs it): loaded with the tile, 8 more bytes
     // per lane; the last lane of a row re-reads its own node instead (its entry c+1 is never a window origin)
     const unsigned st_next = st_off + (st_col + 2 < LT_COLS ? 16u : 0u);
@@ -1961,9 +2008,9 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
         for (int q = 0; q < NS; ++q) {
             const TapL t = tap_of(c0[q]);
             bad[q] = ((unsigned)t.x0 > (unsigned)(A.nx_f - 2)) | ((unsigned)t.y0 > (unsigned)(A.ny_f - 2));
-            e[q] = window_global<ORDER>(lvl, A, t, zero);
+            e[q] = euler_global<ORDER>(lvl, A, t);
             pn[q] = dd[q] * e[q] + p[q];
-            bad[q] |= x_needs_care(pn[q].x);
+            if (!DEFER_X) bad[q] |= x_needs_care(pn[q].x);
             anybad |= bad[q];
         }
         if (anybad) {  // exact sequence for the lanes / seeds that need it
@@ -1971,9 +2018,9 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
             for (int q = 0; q < NS; ++q) {
                 if (bad[q]) {
                     const TapL t = tap_of(index_coords(A, p[q]));
-                    e[q] = window_global<ORDER>(lvl, A, t, zero);
+                    e[q] = euler_global<ORDER>(lvl, A, t);
                     pn[q] = dd[q] * e[q] + p[q];
-                    clamp_position_p(A, pn[q], ymax_v);
+                    if (!DEFER_X) clamp_position_p(A, pn[q], ymax_v);
                 }
             }
         }
@@ -2003,7 +2050,12 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
             __builtin_amdgcn_wave_barrier();
             const int sox = ox - WOFF, soy = oy - WOFF;
             const int hx = min(sox + LT_COLS - WIN, A.nx_f - 2), hy = min(soy + LT_ROWS - WIN, A.ny_f - 2);
-            const int lx = max(sox, 0), ly = max(soy, 0);
+            // DEFER_X: column 0 and row 0 are left to the exact path.  A parcel sitting EXACTLY on lon_min = -180 has index
+            // 0.0 and must still meet Q7's `x > -180` test (every other longitude the reference would wrap or clamp maps
+            // to an index outside [0, n-1) and fails the window test by itself); and a NaN coordinate converts to index 0,
+            // so with origin 0 excluded it fails the window test on either axis and is clamped first (Q8: a NaN latitude
+            // becomes y_min while the longitude lives on) -- the round-5 form caught it through x_needs_care(NaN).
+            const int lx = max(sox, DEFER_X ? 1 : 0), ly = max(soy, DEFER_X ? 1 : 0);
             if (hx >= lx && hy >= ly) {
                 lo_x = lx;
                 lo_y = ly;
@@ -2046,7 +2098,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
                 const f2 r1 = c1.xy + t.tx * c1.zw;   // n10 + tx (n11 - n10)
                 const f2 ew = e[q] + (r0 + t.ty * (r1 - r0));  // e + sample of ext[t]
                 pn[q] = hd[q] * ew + p[q];
-                bad[q] |= x_needs_care(pn[q].x);
+                if (!DEFER_X) bad[q] |= x_needs_care(pn[q].x);
                 anybad |= bad[q];
             }
 #ifdef LCS_STAMPS
@@ -2068,10 +2120,13 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
                 for (int q = 0; q < NS; ++q) {
                     if (bad[q]) {  // exact sequence, global gather
                         f2 pc = p[q];
-                        pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
+                        if (DEFER_X)
+                            clamp_position_c<CYCLIC>(A, pc, ymax_v);  // the deferred clamps of the previous update (Q7 / Q8 / Q9)
+                        else
+                            pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
                         const TapL t = tap_of(index_coords(A, pc));
                         pn[q] = hd[q] * window_global<ORDER>(elv, A, t, e[q]) + pc;
-                        clamp_position_p(A, pn[q], ymax_v);
+                        if (!DEFER_X) clamp_position_p(A, pn[q], ymax_v);
                     }
                 }
             }
@@ -2079,7 +2134,12 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
             for (int q = 0; q < NS; ++q) p[q] = pn[q];
         }
 #pragma unroll
-        for (int q = 0; q < NS; ++q) p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);  // the level's one latitude clamp
+        for (int q = 0; q < NS; ++q) {  // the level's one latitude clamp -- and, with DEFER_X, its one longitude test
+            if (DEFER_X)
+                clamp_position_c<CYCLIC>(A, p[q], ymax_v);
+            else
+                p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);
+        }
         if (GROUP) {  // a member outside its own steps keeps its position, bit for bit
 #pragma unroll
             for (int q = 0; q < NS; ++q)
@@ -2333,7 +2393,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
             for (int q = 0; q < SPL; ++q) {
                 if (bad[q]) {
                     const TapL t = tap_of(index_coords(A, p[q]));
-                    e[q] = window_global<ORDER>(lvl, A, t, zero);
+                    e[q] = euler_global<ORDER>(lvl, A, t);
                     pn[q] = L.dd[q] * e[q] + p[q];
                     clamp_position_p(A, pn[q], ymax_v);
                 }

@@ -59,17 +59,21 @@ LCP_HD int fused_prefilter_waves(int nx, int max_waves) {
 // prefilter_fused_stream_kernel: row pieces of the workgroups that do not fill a round.  One workgroup per CU at a time, all
 // the same length: `items` (level, x block) columns-of-workgroups on `cus` CUs run in ceil(items / cus) rounds, the last one
 // with (items % cus) workgroups on an otherwise idle chip.  Those last ones are cut into row pieces so that the last round has
-// up to `cus` shorter workgroups: a piece restarts the latitude march 64 rows above its first row and runs 32 rows past its
-// last (FS_RESTART), so pieces are kept at 128 rows or more.  Returns the pieces per leftover item (1: no split).
-struct FusedSplit { int n_whole, pieces, piece_rows; };   // items run whole; pieces of each of the others; rows per piece (a multiple of 8)
+// up to `cus` shorter workgroups.  A piece starts the latitude march at its first row from the 64 rows above it
+// (fused_causal_restart) -- and so that a level's bits do NOT depend on whether, or where, this launch happened to cut it
+// (which follows from nt and the CU count: round 5's advisor finding), EVERY march restarts the same way at every row that
+// is a multiple of FUSED_PIECE_ALIGN, cut there or not, and pieces begin on such rows only.  Returns the pieces per leftover
+// item (1: no split).
+constexpr int FUSED_PIECE_ALIGN = 256;
+struct FusedSplit { int n_whole, pieces, piece_rows; };   // items run whole; pieces of each of the others; rows per piece (a multiple of FUSED_PIECE_ALIGN)
 LCP_HD FusedSplit fused_prefilter_split(int items, int cus, int ny) {
     FusedSplit f;
     const int left = cus > 0 ? items % cus : 0;
     f.n_whole = items - left;
     f.pieces = 1;
-    if (left > 0) f.pieces = imax(1, imin(cus / left, ny / 128));
-    f.piece_rows = ((ny + f.pieces - 1) / f.pieces + 7) / 8 * 8;
-    while (f.pieces > 1 && f.piece_rows * (f.pieces - 1) >= ny) --f.pieces;   // (rounding up to 8 rows may leave the last piece empty)
+    if (left > 0) f.pieces = imax(1, imin(cus / left, ny / FUSED_PIECE_ALIGN));
+    f.piece_rows = ((ny + f.pieces - 1) / f.pieces + FUSED_PIECE_ALIGN - 1) / FUSED_PIECE_ALIGN * FUSED_PIECE_ALIGN;
+    while (f.pieces > 1 && f.piece_rows * (f.pieces - 1) >= ny) --f.pieces;   // (rounding up may leave the last piece empty)
     return f;
 }
 

@@ -570,6 +570,29 @@ __device__ __forceinline__ void lanes_prefilter(double (&r)[FS_W], double (&ends
     }
 }
 
+// The causal value of row b from the 64 rows up to and including it, c+[b] = sum_{k < 64} z^k gain a[b - k] (rows before the
+// first: mirrored, scipy's start value at b = 0; rows past the last: the mirror extension the march runs on), by Horner from
+// the far end: |z|^64 = 2.5e-37 of what lies beyond.  ONE function for the start of a row piece and for the restart every
+// march makes at every multiple of FUSED_PIECE_ALIGN rows: a level's coefficients are the same bits whether this launch cut
+// the level there or not.
+template <typename TIN>
+__device__ __forceinline__ double fused_causal_restart(const TIN *__restrict__ src, int b, int n, size_t ss) {
+    constexpr double z = -0.26794919243112270647, gain = 6.0;
+    auto row = [&](int i) {
+        i = abs(i);
+        return (size_t)(i > n - 1 ? 2 * (n - 1) - i : i) * ss;
+    };
+    double acc = 0.0;
+    for (int i0 = b - 63; i0 <= b; i0 += 8) {
+        double a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = src[row(i0 + q)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_fma(z, acc, gain * a[q]);
+    }
+    return acc;
+}
+
 // One round of the fused kernel in phase P: the window (FS_W rows, first row s) sits at r[(j + FS_C P) % FS_W] -- the
 // round loop is unrolled over the FS_W / FS_C phases, so the window never moves (a shift by FS_C rows per round is 2 FS_H
 // register moves and, worse, doubles the window's live range at the point where the finished rows are still needed).
@@ -603,9 +626,21 @@ __device__ __forceinline__ void fused_round(double (&r)[FS_W], double (&ends)[2]
 #pragma unroll
     for (int j = 0; j < FS_C; ++j)
         if (s + j < y1) c[(size_t)(s + j) * cs] = W(j);
+    // row s + FS_W a multiple of FUSED_PIECE_ALIGN (uniform; s is a multiple of FS_C, so only the first of the new rows can
+    // be one): the march restarts there (fused_causal_restart: the finished rows' registers are free again by now)
+    if (((s + FS_W) & (lcplan::FUSED_PIECE_ALIGN - 1)) == 0) {
+        prev = fused_causal_restart(src, s + FS_W, n, ss);
+        W(0) = prev;
+#pragma unroll
+        for (int q = 1; q < FS_C; ++q) {
+            prev = __builtin_fma(z, prev, gain * a[q]);
+            W(q) = prev;
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < FS_C; ++q) {  // rows s + FS_W + q take the places of the rows just stored
-        prev = gain * a[q] + z * prev;
+        prev = __builtin_fma(z, prev, gain * a[q]);
         W(q) = prev;
     }
 }
@@ -651,6 +686,7 @@ __global__ void __launch_bounds__(FS_MAXW * 64) prefilter_fused_stream_kernel(co
         zp[0][threadIdx.x] = p;
         zp[1][7 - threadIdx.x] = p;
     }
+    __syncthreads();  // the zeroing of `ends` above strides over all threads: done before any wave stores its DPP rows' end values
 
     const int pitch = nx + LC_PAD;
     const size_t level = (size_t)(ny + LC_PAD) * pitch * 2;
@@ -664,19 +700,7 @@ __global__ void __launch_bounds__(FS_MAXW * 64) prefilter_fused_stream_kernel(co
     // causal value at the first row y0 is the sum of the 64 rows above it, c+[y0] = sum_k z^k gain a[|y0 - k|]: scipy's mirror
     // start value at y0 = 0 (prefilter_line_blocked's horizon), and the restart of a row piece anywhere else (|z|^64 = 2.5e-37)
     auto row = [&](int i) { return (size_t)(i > n - 1 ? 2 * (n - 1) - i : i) * ss; };   // rows past the end: mirrored
-    double c0 = gain * src[row(y0)], zi = z;
-    for (int i0 = 1; i0 < 64; i0 += 8) {
-        double a[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = src[(size_t)abs(y0 - min(i0 + q, 63)) * ss];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (i0 + q < 64) {
-                c0 += zi * (gain * a[q]);
-                zi *= z;
-            }
-        }
-    }
+    const double c0 = fused_causal_restart(src, y0, n, ss);   // (y0 = 0 or a multiple of FUSED_PIECE_ALIGN: where every march restarts)
     double r[FS_W];
     r[0] = c0;
     {
@@ -689,7 +713,7 @@ __global__ void __launch_bounds__(FS_MAXW * 64) prefilter_fused_stream_kernel(co
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 if (j0 + q < FS_W) {
-                    prev = gain * a[q] + z * prev;
+                    prev = __builtin_fma(z, prev, gain * a[q]);
                     r[j0 + q] = prev;
                 }
             }

@@ -74,6 +74,7 @@ class PackedField:
     v: "torch.Tensor | None" = None  # (lc_advect_ex: pole rows at any order, the Euler sample in float64) -- not copies: do not
     #                                  modify them in place while the field is in use (Engine._ensure_lin refuses if you did)
     planes_version: "tuple | None" = None  # (u._version, v._version) when the field was prepared
+    planes32_version: "tuple | None" = None  # (u32._version, v32._version): the float32 planes are borrowed too
     lin32: "torch.Tensor | None" = None    # wind_f32 at order 1: the order-1 image of the float32 wind AS float32 (LC_F64_WIND_F32_LIN32)
     u32: "torch.Tensor | None" = None      # wind_f32: the float32 planes as given (the float64 copies u, v are made when a call needs them)
     v32: "torch.Tensor | None" = None
@@ -515,6 +516,7 @@ class Engine:
         """``lc_advect_args`` of one call: the field's images, and its raw planes as the order-1 source where it has no
         lin image."""
         p = lambda t: t.data_ptr() if t is not None else None
+        self._check_planes(field)
         if field.u32 is not None and field.lin32 is None and interp_order == 3 == field.order and xmode != _capi.LC_X_CLAMP_REFERENCE_OUTER:
             # float32 wind on float64 coordinates at order 3: float64 coefficients, the float32 planes for the pole rows
             return _capi.AdvectArgs(
@@ -554,6 +556,19 @@ class Engine:
             field.u, field.v = self.to_device(field.u32, field.dtype), self.to_device(field.v32, field.dtype)
             field.planes_version = (field.u._version, field.v._version)
 
+    @staticmethod
+    def _check_planes(field: PackedField):
+        """The borrowed wind planes (``u`` / ``v``, and the float32 ``u32`` / ``v32`` of a float32 wind on float64 coordinates)
+        must not have been written in place since ``prepare_field``: the kernels read them live (pole rows, Euler samples)
+        next to images packed from their old values.  Called on EVERY path that builds a call's arguments."""
+        stale = (field.u is not None and field.planes_version is not None
+                 and (field.u._version, field.v._version) != field.planes_version) or \
+                (field.u32 is not None and field.planes32_version is not None
+                 and (field.u32._version, field.v32._version) != field.planes32_version)
+        if stale:
+            raise RuntimeError("the wind tensors given to prepare_field were modified in place afterwards: the field's packed "
+                               "images no longer match them (prepare the field again, or pass copies)")
+
     def _ensure_lin(self, field: PackedField, interp_order: int):
         """The order-1 source of a call on ``field``, checked and -- where it is an image that does not exist yet -- built.
 
@@ -563,10 +578,7 @@ class Engine:
         BORROWED from the caller when ``prepare_field`` was handed device tensors, so an in-place write to them since
         then (a time loop refilling its buffers) would silently change what the pole rows and the float64 Euler sample
         read while the packed images still hold the old wind: refused here by the tensors' version counters."""
-        if field.u is not None and field.planes_version is not None and \
-                (field.u._version, field.v._version) != field.planes_version:
-            raise RuntimeError("the wind tensors given to prepare_field were modified in place afterwards: the field's packed "
-                               "images no longer match them (prepare the field again, or pass copies)")
+        self._check_planes(field)
         if field.lin is None and field.dtype == np.dtype(np.float32) and interp_order == 1:
             field.lin = self._empty((self.lib.lc_packed_elems(field.nt, field.ny_f, field.nx_f),), field.dtype)
             self._use_current_stream()

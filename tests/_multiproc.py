@@ -7,7 +7,8 @@ checks, level by level, that the tile it staged in LDS still holds what it wrote
 slot it started in.  A mismatch is then judged ONCE:
 
 * no wave's state changed  ->  the difference is the library's: the test FAILS, with the report;
-* some wave's LDS tile changed under it (``tile_changed`` > 0)  ->  the wave's context was saved and restored by the
+* the mismatch is on a rank that ran the plain (product) kernel instances (rank 0 of the sharded tests: no audit)  ->  FAILS;
+* some wave's LDS tile changed under it (``tile_changed`` > 0) on an audited rank  ->  the wave's context was saved and restored by the
   driver (time slicing between the processes) and came back different: nothing a kernel can defend against or cause
   (a wave's tile is written by that wave alone).  The test is reported as XFAIL with the evidence -- visible in the
   summary, not a pass.
@@ -45,6 +46,11 @@ def judge_worker_results(results):
         assert isinstance(r, dict), f"rank {rank}: {r}"
     audits = [r.get("wave_state_audit") for _, r in bad]
     text = json.dumps(dict(("rank%d" % rank, r) for rank, r in bad), indent=1)[:6000]
+    # a rank that ran the plain (product) instances has no audit: its mismatch is never excused
+    unaudited = [rank for rank, r in bad if not r.get("wave_state_audit")]
+    if unaudited:
+        raise AssertionError(f"rank(s) {unaudited} ran the product kernel instances (no wave-state audit) and differ from the "
+                             "unsharded result:\n" + text)
     if outside_interference(audits):
         pytest.xfail("a sharded result differed from the unsharded one AND the audit saw a wave's LDS tile change under it: "
                      "platform, not library\n" + text)

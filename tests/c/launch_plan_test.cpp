@@ -103,7 +103,8 @@ static void test_tile_order() {
             for (int ny : {64, 100, 128, 255, 256, 720, 1024, 4097}) {
                 const FusedSplit f = fused_prefilter_split(items, cus, ny);
                 CHECK(f.n_whole % cus == 0 && f.n_whole <= items && items - f.n_whole < cus, "items %d cus %d: %d whole", items, cus, f.n_whole);
-                CHECK(f.pieces >= 1 && f.piece_rows % 8 == 0, "pieces %d of %d rows", f.pieces, f.piece_rows);
+                // pieces begin on the rows at which EVERY march restarts (a level's bits must not depend on the cut)
+                CHECK(f.pieces >= 1 && f.piece_rows % FUSED_PIECE_ALIGN == 0, "pieces %d of %d rows", f.pieces, f.piece_rows);
                 CHECK((long)f.pieces * f.piece_rows >= ny && (long)(f.pieces - 1) * f.piece_rows < ny, "pieces %d x %d rows cover %d", f.pieces, f.piece_rows, ny);
                 CHECK(f.pieces == 1 || f.piece_rows >= 128, "piece of %d rows", f.piece_rows);     // (a piece restarts 64 rows above its own)
                 CHECK((long)(items - f.n_whole) * f.pieces <= (cus > items - f.n_whole ? cus : items - f.n_whole), "last round: %d x %d on %d CUs", items - f.n_whole, f.pieces, cus);
@@ -111,7 +112,7 @@ static void test_tile_order() {
             }
     {
         const FusedSplit f = fused_prefilter_split(804, 256, 1024);   // BASELINE configs[1] at order 3: 201 levels x 4 workgroups
-        CHECK(f.n_whole == 768 && f.pieces == 7 && f.piece_rows == 152, "configs[1]: %d whole, %d pieces of %d rows", f.n_whole, f.pieces, f.piece_rows);
+        CHECK(f.n_whole == 768 && f.pieces == 4 && f.piece_rows == 256, "configs[1]: %d whole, %d pieces of %d rows", f.n_whole, f.pieces, f.piece_rows);
     }
     std::printf("fused prefilter: %ld shapes\n", cases);
 }

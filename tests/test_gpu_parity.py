@@ -845,6 +845,30 @@ def test_float64_streaming_prefilter_matches_the_two_march_sweeps_and_scipy(eng,
         eng2.close()
 
 
+def test_float64_order3_coefficients_do_not_depend_on_how_the_launch_cut_the_level(eng):
+    """Round 5's advisor finding: prefilter_fused_stream_kernel cuts the workgroups of its last round into row pieces
+    (lcplan::fused_prefilter_split: which levels, and into how many pieces, follows from nt and the CU count), and a piece used
+    to restart the latitude march from a 64-term sum where a whole march carries its recursion on -- the same level came out
+    in different bits as part of another series length.  Now EVERY march restarts at every multiple of FUSED_PIECE_ALIGN
+    (256) rows by the same function, and pieces begin there only.  Packed here: the same levels of a 600-row field (room for
+    a cut at rows 256 and 512) as a series of 2, 3, 5 and 9 levels -- items % CUs and the cut differ from one to the next --
+    and as sub-ranges; every level's coefficient image must be identical in all of them, bit for bit."""
+    ny, nx, nt = 600, 130, 9
+    u, v, lat, lon = _rand_field(4242, nt=nt, ny=ny, nx=nx, dtype=np.float64, scale=20.0)
+    full = _np(eng.prepare_field(u, v, lat, lon, 3).cub).reshape(-1, ny + 3, nx + 3, 2)[:nt].copy()
+    assert eng.last_pack_kernel() == "prefilter_fused_stream_kernel<double>", eng.last_pack_kernel()
+    assert np.isfinite(full).all()
+    for n in (2, 3, 5):
+        part = _np(eng.prepare_field(u[:n], v[:n], lat, lon, 3).cub).reshape(-1, ny + 3, nx + 3, 2)[:n]
+        assert np.array_equal(part, full[:n]), f"levels 0..{n - 1} packed as a series of {n} differ from the same levels of a series of {nt}"
+    tail = _np(eng.prepare_field(u[4:], v[4:], lat, lon, 3).cub).reshape(-1, ny + 3, nx + 3, 2)[:nt - 4]
+    assert np.array_equal(tail, full[4:]), "levels 4..8 packed on their own differ from the same levels of the whole series"
+    # and the restart rows are what scipy's recursion gives, to the same few last bits as everywhere else
+    from oracle import lcs_oracle as O
+    scale = float(np.abs(u).max())
+    np.testing.assert_allclose(full[1, 1:ny + 1, 1:nx + 1, 0], O.spline_prefilter_mirror(u[1]), rtol=0, atol=2e-14 * scale)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("order", [1, 3])
 def test_launch_geometry_does_not_change_results(dtype, order, monkeypatch):
