@@ -74,10 +74,10 @@ class PackedField:
     v: "torch.Tensor | None" = None  # (lc_advect_ex: pole rows at any order, the Euler sample in float64) -- not copies: do not
     #                                  modify them in place while the field is in use (Engine._ensure_lin refuses if you did)
     planes_version: "tuple | None" = None  # (u._version, v._version) when the field was prepared
-    planes32_version: "tuple | None" = None  # (u32._version, v32._version): the float32 planes are borrowed too
     lin32: "torch.Tensor | None" = None    # wind_f32 at order 1: the order-1 image of the float32 wind AS float32 (LC_F64_WIND_F32_LIN32)
     u32: "torch.Tensor | None" = None      # wind_f32: the float32 planes as given (the float64 copies u, v are made when a call needs them)
     v32: "torch.Tensor | None" = None
+    planes32_version: "tuple | None" = None  # (u32._version, v32._version) when the field was prepared: borrowed like u, v
 
 
 class Engine:
@@ -343,7 +343,7 @@ class Engine:
                                                self._ptr(lin32), None), self.lib)
             la, lo = lat_f.astype(dtype), lon_f.astype(dtype)
             return PackedField(None, None, None, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
-                               True, 1, False, None, None, None, lin32, u32, v32)
+                               True, 1, False, None, None, None, lin32, u32, v32, (u32._version, v32._version))
         if wind_f32 and interp_order == 3 and lin_image is None:
             # ... and at order 3 (the reference's default): scipy's spline coefficients of a float32 field are float64
             # (spline_filter(output=float64) inside map_coordinates), so the coefficient image is packed in float64 STRAIGHT from
@@ -355,7 +355,7 @@ class Engine:
                                                self._ptr(cub), None), self.lib)
             la, lo = lat_f.astype(dtype), lon_f.astype(dtype)
             return PackedField(None, cub, None, nt, ny_f, nx_f, float(la[0]), float(la[-1]), float(lo[0]), float(lo[-1]), dtype,
-                               True, 3, False, None, None, None, None, u32, v32)
+                               True, 3, False, None, None, None, None, u32, v32, (u32._version, v32._version))
         ud = self.to_device(u, dtype)
         vd = self.to_device(v, dtype)
         if fuse_levels is None:
@@ -427,8 +427,15 @@ class Engine:
     # ------------------------------------------------------------------ K1
     def advect(self, field: PackedField, seed_lat, seed_lon, timestep, SETTLS_order=0, interp_order=1,
                cyclic_xboundary=True, t0=0, nsteps=None, return_traj=False, row0=0, ny_global=None, halo=None,
-               noncyclic_clamp=None, start=None, out=None):
+               noncyclic_clamp=None, start=None, out=None, global_rows=None):
         """Departure points of the seed rows given.  Returns (x, y[, traj_x, traj_y]) device tensors.
+
+        ``global_rows`` (instead of ``row0``): the rows given are NOT one contiguous block of the global grid but an
+        ascending selection of its rows (``sharded``'s interleaved chunks: several windows concatenated); entry i is the
+        global row of ``seed_lat[i]``.  Advection is per seed (LCS/trajectory.py:80-126) and the only thing the kernels
+        derive from a seed's global row is whether it is one of the ``interp_order`` rows next to either pole (Q3), so
+        the call is expressed through ``row0`` / ``ny_global`` values that mark exactly those rows (:meth:`pole_window`);
+        a selection that holds only part of a pole's rows, or holds them anywhere but at its own ends, is refused.
 
         ``out=(x, y)``: write the results into these ``(ny, nx)`` tensors (may be the ``start`` tensors: in place)
         instead of allocating.
@@ -447,6 +454,12 @@ class Engine:
         slon = self.to_device(seed_lon, dtype)
         ny, nx = int(slat.numel()), int(slon.numel())
         ny_global = ny if ny_global is None else int(ny_global)
+        whole = int(row0) == 0 and ny == ny_global
+        if global_rows is not None:
+            if int(row0) != 0 or halo:
+                raise ValueError("global_rows replaces row0 (and carries its own halo rows)")
+            row0, ny_global = self.pole_window(global_rows, ny, ny_global, int(interp_order))
+            whole = False
         nsteps = field.nt - 1 - t0 if nsteps is None else int(nsteps)
         n_lo, n_hi = halo if halo else (0, 0)
         if out is not None:
@@ -476,12 +489,30 @@ class Engine:
                 raise ValueError(f"start positions must be two ({ny}, {nx}) arrays")
         self._use_current_stream()
         a = self._advect_args(field, interp_order, slat, ny, slon, nx, row0, ny_global, sx, sy, timestep, SETTLS_order,
-                              x_boundary_mode(cyclic_xboundary, noncyclic_clamp, int(row0) == 0 and ny == ny_global),
+                              x_boundary_mode(cyclic_xboundary, noncyclic_clamp, whole),
                               t0, nsteps, 1, 0, x, y, tx, ty)
         _capi.check(self.lib.lc_advect_ex(self.ctx, C.byref(a)), self.lib)
         if halo:
             x, y = x_buf, y_buf
         return (x, y, tx, ty) if return_traj else (x, y)
+
+    @staticmethod
+    def pole_window(global_rows, ny: int, ny_global: int, order: int):
+        """``(row0, ny_global)`` to hand ``lc_advect`` for an ascending SELECTION of the global grid's rows, such that the
+        kernels' pole rule -- local row i is a pole row iff ``row0 + i < order`` or ``row0 + i >= ny_global - order`` (Q3: the
+        ``order`` rows next to either pole take the order-1 / 'constant' sample) -- marks exactly the selected rows that are
+        pole rows of the real grid.  The selection must hold a pole's rows completely and as its own first / last rows, or
+        not at all (``sharded.interleaved_chunks`` does: the first chunk starts at row 0, the last one ends at the last row)."""
+        g = np.asarray(global_rows, dtype=np.int64)
+        if g.shape != (ny,) or (ny > 1 and not np.all(np.diff(g) > 0)) or g[0] < 0 or g[-1] >= ny_global:
+            raise ValueError(f"global_rows: {ny} ascending row indices inside [0, {ny_global})")
+        is_pole = (g < order) | (g >= ny_global - order)
+        row0 = 0 if g[0] < order else order
+        nyg = row0 + ny + (0 if g[-1] >= ny_global - order else order)
+        i = np.arange(ny) + row0
+        if not np.array_equal((i < order) | (i >= nyg - order), is_pole):
+            raise ValueError("global_rows: the selection holds part of a pole's rows, or holds them elsewhere than at its ends")
+        return int(row0), int(nyg)
 
     def advect_batch(self, field: PackedField, seed_lat, seed_lon, timestep, n_members: int, nsteps: int, SETTLS_order=0,
                      interp_order=1, cyclic_xboundary=True, t0=0, t0_stride=1, start=None, out=None):

@@ -19,7 +19,8 @@ from __future__ import annotations
 HALO = 2  # rows; LCS/tools.py:202-207 (4th-order, +-2 points), SURVEY Q12
 
 __all__ = ["HALO", "row_partition", "halo_rows", "halo_exchange", "halo_exchange_into", "ensemble_partition",
-           "sharded_lcs", "ensemble_lcs", "ensemble_advect", "native_comm", "ENSEMBLE_CHUNK"]
+           "sharded_lcs", "ensemble_lcs", "ensemble_advect", "native_comm", "ENSEMBLE_CHUNK",
+           "interleaved_chunks", "interleaved_partition", "chunk_window", "interleaved_rows", "chunk_halo_exchange", "CHUNK_ROWS"]
 
 
 def row_partition(ny_global: int, world: int, rank: int):
@@ -31,6 +32,148 @@ def row_partition(ny_global: int, world: int, rank: int):
     base, rem = divmod(ny_global, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Interleaved, patch-aligned row chunks: the partition for STRONG scaling (a fixed grid over more ranks).
+#
+# Contiguous blocks hand every rank one latitude band, and the bands do not cost the same: on BASELINE configs[3]
+# (8192^2 x 384) the eight blocks take 11.3 ... 14.2 ms (the flow's jets, the polar rows' long zonal travel), the slowest
+# sets the step.  Here the rows are cut into chunks of CHUNK_ROWS rows and dealt to the ranks round robin --
+# rank r owns chunks r, r + world, r + 2 world, ... -- so every rank holds every band.  A rank advects all of its chunks in
+# ONE lc_advect call over the concatenated rows (advection is per seed, LCS/trajectory.py:80-126; the only thing the kernels
+# read of a seed's global row is the pole rule: Engine.advect(global_rows=...)), exchanges the 2 sigma-halo rows of every
+# chunk with the previous / next rank -- chunk k's neighbours k - 1 and k + 1 belong to ranks r - 1 and r + 1 (mod world: a
+# ring, where contiguous blocks form a line), all of a neighbour's rows in ONE message per direction -- and runs lc_sigma once
+# per chunk on its window (stencil reach LCS/tools.py:202-207).
+#
+# Two shape rules, both measured (profiles/r06/shard_costs_*.jsonl, profiles/r05/shard_costs_balanced.txt):
+#  * a chunk is a multiple of 64 rows that starts on a multiple of 64 local rows: the two-seed kernel's waves hold 8 x 16-seed
+#    patches, its workgroups 64 rows, and a patch that straddles two chunks has its seeds `world` chunks apart in latitude and
+#    leaves its LDS tile at every sample (unaligned 128-row chunks: 14.9-16.0 ms per rank of C4 against 11.9-12.7 aligned);
+#  * a rank's rows in all are a multiple of 512 where the grid allows it (8 XCDs x 64-row workgroup rows): 1040 rows -- 1024
+#    and the 16 halo rows of four chunks advected redundantly instead of exchanged, this file's first cut -- are 17 workgroup
+#    rows on 8 XCDs and took 13.8-15.3 ms per rank of C4 where 1024 rows take 11.9-12.7.  Hence the exchange, and no
+#    redundant rows (``redundant_halo=True`` remains as the cross-check: bit-identical, no communication).
+# Grids whose chunks do not deal out evenly (a rank would get more than 10 % over the mean) keep the contiguous blocks.
+# ---------------------------------------------------------------------------------------------------------------
+CHUNK_ROWS = 256   # rows of a chunk: 4 workgroup rows of the two-seed kernel
+CHUNK_WINDOW = CHUNK_ROWS   # (the name the first cut used)
+
+
+def interleaved_chunks(ny_global: int, world: int, chunk: int = CHUNK_ROWS):
+    """The chunks ``[(lo, hi), ...]`` of the interleaved partition, in row order; chunk ``k`` belongs to rank ``k % world``.
+    Chunk boundaries are the multiples of ``chunk`` (a last chunk thinner than the stencil needs joins the one before).
+    With fewer than two chunks per rank, or a deal that would leave some rank more than 10 % over the mean, it is
+    :func:`row_partition`: one contiguous block per rank."""
+    if world < 1 or chunk % 16 or chunk < 16:
+        raise ValueError("world >= 1 and a chunk that is a multiple of 16 rows")
+    if ny_global < world * HALO:
+        raise ValueError(f"{ny_global} rows cannot be split over {world} ranks with a {HALO}-row halo")
+    bounds = list(range(0, ny_global, chunk)) + [ny_global]
+    if len(bounds) > 2 and bounds[-1] - bounds[-2] < 2 * HALO:
+        del bounds[-2]
+    ch = [(bounds[k], bounds[k + 1]) for k in range(len(bounds) - 1)]
+    per = [sum(hi - lo for lo, hi in ch[r::world]) for r in range(world)]
+    if world == 1 or len(ch) < 2 * world or max(per) > 1.1 * ny_global / world:
+        return [row_partition(ny_global, world, r) for r in range(world)]
+    return ch
+
+
+def interleaved_partition(ny_global: int, world: int, rank: int, chunk: int = CHUNK_ROWS):
+    """The chunks ``[(lo, hi), ...]`` rank ``rank`` owns (ascending)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} not in [0,{world})")
+    return interleaved_chunks(ny_global, world, chunk)[rank::world]
+
+
+def chunk_window(ny_global: int, lo: int, hi: int):
+    """Rows ``[a, b)`` the sigma rows of the chunk ``[lo, hi)`` read: the chunk and its halo rows."""
+    n_lo, n_hi = halo_rows(ny_global, lo, hi)
+    return lo - n_lo, hi + n_hi
+
+
+def interleaved_rows(ny_global: int, chunks, with_halo: bool = False):
+    """Global row index of every row of ``chunks`` concatenated (``with_halo``: of their windows), as a list of ints."""
+    rows = []
+    for lo, hi in chunks:
+        a, b = chunk_window(ny_global, lo, hi) if with_halo else (lo, hi)
+        rows.extend(range(a, b))
+    return rows
+
+
+def chunk_halo_exchange(x_own, y_own, chunks, ny_global: int, rank: int, world: int, group=None):
+    """The halo exchange of the interleaved partition.  ``x_own`` / ``y_own``: ``(rows, nx)``, this rank's chunks concatenated.
+    Returns ``(x_win, y_win)``: every chunk's WINDOW (halo rows received + chunk) concatenated -- what ``lc_sigma`` reads,
+    chunk by chunk.  Ring: chunk k's lower halo is the last two rows of chunk k - 1 (rank ``rank - 1``), its upper halo the
+    first two rows of chunk k + 1 (rank ``rank + 1``), both mod ``world``; per neighbour and direction ONE message carrying
+    (x, y) of all chunks' rows.  Sends are posted [to previous, to next], receives [from next, from previous]: with two ranks
+    both neighbours are the same peer and point-to-point operations between a pair match in order."""
+    import torch
+    import torch.distributed as dist
+    if not (x_own.is_contiguous() and y_own.is_contiguous()) or x_own.shape != y_own.shape or x_own.dim() != 2:
+        raise ValueError("chunk_halo_exchange: x_own and y_own must be contiguous (rows, nx) buffers of one shape")
+    nx = x_own.shape[1]
+    offs, o = [], 0
+    for lo, hi in chunks:
+        offs.append(o)
+        o += hi - lo
+    if o != x_own.shape[0]:
+        raise ValueError("chunk_halo_exchange: the buffers do not hold the chunks' rows")
+    has_lo = [lo > 0 for lo, hi in chunks]                  # a chunk below exists (it is rank - 1's)
+    has_hi = [hi < ny_global for lo, hi in chunks]          # a chunk above exists (rank + 1's)
+    dev = x_own.device
+    idx = lambda rows: torch.as_tensor(rows, dtype=torch.long, device=dev)
+    first = idx([offs[i] + j for i in range(len(chunks)) if has_lo[i] for j in range(HALO)])                         # -> previous rank
+    last = idx([offs[i] + chunks[i][1] - chunks[i][0] - HALO + j for i in range(len(chunks)) if has_hi[i] for j in range(HALO)])  # -> next rank
+    send_prev = torch.stack([x_own.index_select(0, first), y_own.index_select(0, first)])
+    send_next = torch.stack([x_own.index_select(0, last), y_own.index_select(0, last)])
+    recv_next = torch.empty((2, HALO * sum(has_hi), nx), dtype=x_own.dtype, device=dev)      # the chunks above: their first rows
+    recv_prev = torch.empty((2, HALO * sum(has_lo), nx), dtype=x_own.dtype, device=dev)      # the chunks below: their last rows
+    prev, nxt = (rank - 1) % world, (rank + 1) % world
+    via_host = x_own.is_cuda and dist.get_backend(group) == "gloo"       # gloo cannot move device tensors (rehearsal layout only)
+    if via_host:
+        send_prev, send_next, rn, rp = send_prev.cpu(), send_next.cpu(), recv_next.cpu(), recv_prev.cpu()
+    else:
+        rn, rp = recv_next, recv_prev
+    ops = []
+    if send_prev.numel():
+        ops.append(dist.P2POp(dist.isend, send_prev, prev, group))
+    if send_next.numel():
+        ops.append(dist.P2POp(dist.isend, send_next, nxt, group))
+    if rn.numel():
+        ops.append(dist.P2POp(dist.irecv, rn, nxt, group))
+    if rp.numel():
+        ops.append(dist.P2POp(dist.irecv, rp, prev, group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if via_host:
+        recv_next.copy_(rn)
+        recv_prev.copy_(rp)
+    return _assemble_windows(x_own, y_own, chunks, ny_global, recv_prev, recv_next)
+
+
+def _assemble_windows(x_own, y_own, chunks, ny_global, recv_prev, recv_next):
+    """The chunks' windows, concatenated: [lower halo rows][chunk][upper halo rows] per chunk (2 x 2 small copies per chunk)."""
+    import torch
+    total = sum(chunk_window(ny_global, lo, hi)[1] - chunk_window(ny_global, lo, hi)[0] for lo, hi in chunks)
+    out = []
+    for t, k in ((x_own, 0), (y_own, 1)):
+        w = torch.empty((total, t.shape[1]), dtype=t.dtype, device=t.device)
+        o = src = ip = inx = 0
+        for lo, hi in chunks:
+            a, b = chunk_window(ny_global, lo, hi)
+            if lo - a:
+                w[o:o + lo - a].copy_(recv_prev[k, ip:ip + lo - a])
+                ip += lo - a
+            w[o + lo - a:o + lo - a + hi - lo].copy_(t[src:src + hi - lo])
+            if b - hi:
+                w[o + hi - a:o + b - a].copy_(recv_next[k, inx:inx + b - hi])
+                inx += b - hi
+            o += b - a
+            src += hi - lo
+        out.append(w)
+    return out[0], out[1]
 
 
 def halo_rows(ny_global: int, lo: int, hi: int):
@@ -75,6 +218,10 @@ def halo_exchange_into(x_ext, y_ext, n_lo: int, n_hi: int, rank: int, world: int
     n = x_ext.shape[0] - n_lo - n_hi
     if n < HALO:
         raise ValueError("local block thinner than the halo")
+    if not (x_ext.is_contiguous() and y_ext.is_contiguous()) or x_ext.shape != y_ext.shape or x_ext.dim() != 2:
+        # rows are sent from and received into the buffers themselves: a strided view would fail inside the transport, per
+        # operation and mid-batch, with the peers left waiting
+        raise ValueError("halo_exchange_into: x_ext and y_ext must be contiguous (rows, nx) buffers of one shape")
     if comm is not None:
         engine.halo_exchange(comm, x_ext, y_ext, n_lo, n_hi)
         return
@@ -143,8 +290,17 @@ def halo_exchange(x, y, rank: int, world: int, ny_global: int, lo: int, hi: int,
 
 def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, world: int, SETTLS_order=0,
                 interp_order=1, cyclic_xboundary=True, t0=0, nsteps=None, fd_fp32_cast=True,
-                tensor_layout="reference", group=None, redundant_halo=False, native_halo=False, noncyclic_clamp=None):
+                tensor_layout="reference", group=None, redundant_halo=False, native_halo=False, noncyclic_clamp=None,
+                partition="contiguous", window=CHUNK_ROWS):
     """This rank's rows of (sigma, x_dep, y_dep) for a row-sharded seed grid.
+
+    ``partition="interleaved"`` (strong scaling; see the comment above :func:`interleaved_chunks`): the rank owns the row
+    chunks ``rank, rank + world, ...``, advects them in ONE call and exchanges every chunk's halo rows with the previous / next
+    rank (a ring; ``redundant_halo=True``: advects the halo rows itself instead, no communication -- bit-identical, the
+    cross-check); the result's ``"rows"`` is then the list of its chunks ``[(lo, hi), ...]`` and ``sigma`` / ``x_dep`` /
+    ``y_dep`` hold those rows concatenated in that order (``"global_rows"``: the global row of every output row).  Values are
+    bit-identical to the unsharded run's rows.  The reference's non-cyclic outer-product clamp couples all rows through the
+    ranks' flags and keeps the contiguous partition; so do grids whose chunks do not deal out evenly.
 
     ``redundant_halo=True`` advects the halo rows locally instead of exchanging them
     (0.1 % extra work at 4096 rows/GPU); the results are bit-identical and the
@@ -161,6 +317,15 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
     seed_lat_global = np.asarray(seed_lat_global, dtype=field.dtype)
     seed_lon = np.asarray(seed_lon, dtype=field.dtype)
     nyg = seed_lat_global.size
+    if partition not in ("contiguous", "interleaved"):
+        raise ValueError("partition: 'contiguous' or 'interleaved'")
+    outer_clamp = (not cyclic_xboundary) and noncyclic_clamp in (None, "reference_outer")
+    if partition == "interleaved" and not outer_clamp:
+        chunks = interleaved_partition(nyg, world, rank, window)
+        if len(chunks) > 1:
+            return _interleaved_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank, world, SETTLS_order, interp_order,
+                                    cyclic_xboundary, t0, nsteps, fd_fp32_cast, tensor_layout, noncyclic_clamp, chunks, group,
+                                    redundant_halo)
     lo, hi = row_partition(nyg, world, rank)
     n_lo, n_hi = halo_rows(nyg, lo, hi)
     comm = native_comm(engine, rank, world, group) if (native_halo and world > 1) else None
@@ -190,6 +355,35 @@ def sharded_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank: int, w
                        in_row0=in_row0, out_row0=lo, n_out_rows=hi - lo, fd_fp32_cast=fd_fp32_cast,
                        tensor_layout=tensor_layout)
     return {"sigma": sig, "x_dep": x, "y_dep": y, "rows": (lo, hi)}
+
+
+def _interleaved_lcs(engine, field, seed_lat_global, seed_lon, timestep, rank, world, SETTLS_order, interp_order,
+                     cyclic_xboundary, t0, nsteps, fd_fp32_cast, tensor_layout, noncyclic_clamp, chunks, group, redundant_halo):
+    import numpy as np
+    import torch
+    nyg = seed_lat_global.size
+    rows = np.asarray(interleaved_rows(nyg, chunks, with_halo=redundant_halo), dtype=np.int64)
+    # one advect over the concatenated chunks (redundant_halo: over their windows, and then nothing is exchanged)
+    x_all, y_all = engine.advect(field, seed_lat_global[rows], seed_lon, timestep, SETTLS_order, interp_order, cyclic_xboundary,
+                                 t0, nsteps, ny_global=nyg, global_rows=rows, noncyclic_clamp=noncyclic_clamp)
+    if redundant_halo:
+        x_win, y_win = x_all, y_all
+    else:
+        x_win, y_win = chunk_halo_exchange(x_all, y_all, chunks, nyg, rank, world, group)
+    dlat = float(seed_lat_global[1] - seed_lat_global[0])
+    dlon = float(seed_lon[1] - seed_lon[0])
+    sig, xs, ys, off = [], [], [], 0
+    for lo, hi in chunks:
+        a, b = chunk_window(nyg, lo, hi)
+        xw, yw = x_win[off:off + b - a], y_win[off:off + b - a]
+        sig.append(engine.sigma(xw, yw, seed_lat_global[a:b], dlat, dlon, ny_global=nyg, in_row0=a, out_row0=lo,
+                                n_out_rows=hi - lo, fd_fp32_cast=fd_fp32_cast, tensor_layout=tensor_layout))
+        xs.append(xw[lo - a:lo - a + hi - lo])
+        ys.append(yw[lo - a:lo - a + hi - lo])
+        off += b - a
+    return {"sigma": torch.cat(sig), "x_dep": torch.cat(xs) if redundant_halo else x_all,
+            "y_dep": torch.cat(ys) if redundant_halo else y_all, "rows": chunks,
+            "global_rows": [r for lo, hi in chunks for r in range(lo, hi)]}
 
 
 ENSEMBLE_CHUNK = 16   # time levels per launch of ensemble_advect's level-major order (measured on config 5)

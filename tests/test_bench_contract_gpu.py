@@ -101,6 +101,36 @@ def test_bench_two_ranks_rehearsal_carries_a_halo_check(wk, extra, units, scalin
     assert abs(d["value"] - units / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
 
 
+def test_bench_two_ranks_strong_scaling_takes_the_interleaved_chunks():
+    """Strong scaling over N > 1 ranks whose 256-row chunks deal out evenly, two or more per rank (here 1024 x 1024 seeds over 2
+    ranks: chunks 0, 2 and 1, 3): bench.py deals the interleaved chunks (sharded.interleaved_chunks), advects a rank's chunks in
+    one lc_advect and exchanges every chunk's halo rows in one batch (a ring); the halo check -- every chunk's window equals the
+    same rows advected redundantly, bit for bit -- is in the line, and a corrupted row is reported there.  --partition
+    contiguous keeps the row blocks and the line exchange."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LCS_BENCH_BACKEND="gloo", LCS_BENCH_ONE_GPU="1")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "c4",
+            "--seeds", "1024", "--nt", "5"]
+
+    def run(extra=(), **more):
+        r = subprocess.run(base + list(extra), capture_output=True, text=True, timeout=900, cwd=ROOT, env={**env, **more})
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1]), r.stderr
+    d, _ = run()
+    hc = d["halo_check"]
+    from tests._multiproc import judge_halo_check
+    judge_halo_check(hc)
+    assert "interleaved chunks" in hc["timed_path"] and hc["timed_path_ok"] is True and hc["chunks_per_rank"] == 2
+    assert d["config"]["partition"].startswith("interleaved") and "interleaved chunks" in d["config"]["workload"]
+    assert d["per_rank"][0]["rows"] == [[0, 256], [512, 768]] and d["per_rank"][1]["rows"] == [[256, 512], [768, 1024]]
+    assert abs(d["value"] - 1024 * 1024 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+    d2, err = run(LCS_BENCH_CORRUPT_HALO_CHECK="1")
+    m = d2["halo_check"]["mismatch_rank0"]
+    assert d2["halo_check"]["timed_path_ok"] is False and m["n_seeds"] == 1 and m["window_rows"] == [3] and "halo check failed" in err
+    d3, _ = run(["--partition", "contiguous"])
+    assert d3["halo_check"]["timed_path"] == "torch.distributed" and d3["per_rank"][1]["rows"] == [512, 1024]
+
+
 def test_bench_reports_a_failed_halo_check_with_its_diagnosis():
     """A halo check that fails is REPORTED in the JSON line next to the number it discredits (not an assert, not a crash),
     with what differs and which of the two calls is unstable: here one interior element of rank 0's timed result is changed
@@ -186,7 +216,14 @@ def test_secondary_workloads_block_of_the_default_run():
                                     float(slon[1] - slon[0]), steps=2, warmup=1, c2_n=128, c2_nt=9,
                                     long_nt=25, c3_long_nt=11, c4_n=320, c5=(128, 4, 20))
     # ... and (round 5) north_star's own target shape and the other BASELINE configurations on one GPU
-    assert list(sec) == ["c3 order 3", "c3 return_traj", "c2", "c2 order 3", "c3 x 10 steps", "c4 on one GPU", "c5 on one GPU"]
+    # ... and (round 6) SETTLS_order 0 (the library default: the direct-gather kernel), 1 and 2 on the headline field
+    assert list(sec) == ["c3 K=0", "c3 K=1", "c3 K=2", "c3 order 3", "c3 return_traj", "c2", "c2 order 3", "c3 x 10 steps",
+                         "c4 on one GPU", "c5 on one GPU"]
+    assert sec["c3 K=0"]["kernel"] == "advect_kernel_f32<1>", sec["c3 K=0"]      # K = 0 has nothing to stage a tile for
+    for K in (0, 1, 2):
+        e = sec[f"c3 K={K}"]
+        assert e["algorithmic_bytes_per_particle_timestep"] == bench.b_adv(K, 1, 4, 4) == 48 + 64 * K
+        assert abs(e["algorithmic_over_hbm_peak"] * bench.HBM_PEAK_GBPS - e["algorithmic_GBps"]) < 1e-6 * e["algorithmic_GBps"]
     for name, d in sec.items():
         assert "error" not in d, (name, d)
         assert d["value"] > 0 and d["ms_per_step"] > 0 and 0 < d["frac"] <= 1 and d["advect_launches"] >= 1

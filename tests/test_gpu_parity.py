@@ -1000,6 +1000,15 @@ def test_float32_wind_on_float64_coordinates_follows_numpy_promotion(eng, O, ord
     f64 = eng.prepare_field(u32.astype(np.float64), v32.astype(np.float64), lat, lon, order)
     x64, y64 = eng.advect(f64, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
     assert np.abs(_np(y64) - yr_).max() > 100 * POS_ATOL64
+    # the float32 planes are BORROWED when they were device tensors (pole rows and Euler samples read them live next to
+    # images packed from their old values): an in-place write afterwards is refused on these paths too (round-5 advisor)
+    ud, vd = eng.to_device(u32, np.float32), eng.to_device(v32, np.float32)
+    fb = eng.prepare_field(ud, vd, lat, lon, order)
+    assert fb.u32 is ud and fb.planes32_version is not None
+    eng.advect(fb, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
+    vd.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        eng.advect(fb, lat, lon, -3600.0, SETTLS_order=3, interp_order=order)
 
 
 @pytest.mark.parametrize("K,cyclic", [(4, True), (3, True), (4, False), (0, True)])

@@ -70,10 +70,23 @@ def _worker(rank, world, port, order, q):
         lo, hi = out["rows"]
         ok = (torch.equal(out["sigma"], full["sigma"][lo:hi]) and torch.equal(out["x_dep"], full["x_dep"][lo:hi])
               and torch.equal(red["sigma"], out["sigma"]) and bool(torch.isfinite(out["sigma"]).all()))
-        q.put((rank, "ok" if ok else _differences({"sigma vs unsharded": (out["sigma"], full["sigma"][lo:hi]),
-                                                   "x_dep vs unsharded": (out["x_dep"], full["x_dep"][lo:hi]),
-                                                   "y_dep vs unsharded": (out["y_dep"], full["y_dep"][lo:hi]),
-                                                   "sigma, redundant halo vs exchanged": (red["sigma"], out["sigma"])}, eng)))
+        # the interleaved chunks (strong scaling): one lc_advect over the rank's concatenated chunks, their halo rows exchanged
+        # with the previous / next rank in one batch (a ring), sigma per chunk -- on a grid whose 32-row chunks deal out evenly
+        slat2, slon2 = flows.seed_grid(192, 320, lat, lon)
+        il = sharded.sharded_lcs(eng, f, slat2, slon2, -900.0, rank, world, SETTLS_order=4, interp_order=order,
+                                 partition="interleaved", window=32)
+        full2 = eng.lcs(f, slat2, slon2, -900.0, SETTLS_order=4, interp_order=order)
+        g = torch.as_tensor(il["global_rows"], device=full2["sigma"].device)
+        ok2 = (isinstance(il["rows"], list) and len(il["rows"]) == 192 // 32 // world and torch.equal(il["sigma"], full2["sigma"][g])
+               and torch.equal(il["x_dep"], full2["x_dep"][g]) and torch.equal(il["y_dep"], full2["y_dep"][g]))
+        pairs = {"sigma vs unsharded": (out["sigma"], full["sigma"][lo:hi]),
+                 "x_dep vs unsharded": (out["x_dep"], full["x_dep"][lo:hi]),
+                 "y_dep vs unsharded": (out["y_dep"], full["y_dep"][lo:hi]),
+                 "sigma, redundant halo vs exchanged": (red["sigma"], out["sigma"])}
+        if not ok2 and isinstance(il["rows"], list):
+            pairs.update({"interleaved sigma vs unsharded": (il["sigma"], full2["sigma"][g]),
+                          "interleaved x_dep vs unsharded": (il["x_dep"], full2["x_dep"][g])})
+        q.put((rank, "ok" if ok and ok2 else _differences(pairs, eng)))
         eng.close()
     except Exception:  # pragma: no cover
         import traceback
@@ -86,6 +99,38 @@ def _worker(rank, world, port, order, q):
 def test_sharded_engine_bit_identical_to_unsharded(world, order):
     from tests._multiproc import judge_worker_results
     judge_worker_results(_run_ranks(_worker, world, (order,)))
+
+
+@pytest.mark.parametrize("order,dtype", [(1, "float32"), (3, "float32"), (1, "float64")])
+def test_interleaved_chunks_bit_identical_to_unsharded_on_the_real_engine(order, dtype):
+    """sharded_lcs(partition="interleaved", redundant_halo=True) on the GPU, every rank's share computed in this one process
+    (the halo rows advected redundantly, so no process group is needed; the exchanged form runs in the two- / three-process
+    test above): the concatenated chunk windows go through ONE lc_advect whose row0 / ny_global mark exactly the selected pole
+    rows (Engine.pole_window), sigma runs per chunk on its window -- positions and sigma of every owned row equal the
+    unsharded run's, bit for bit, for 2 and 3 ranks, at both orders and in float64."""
+    import numpy as np
+    from lagrangiancoherence_amd import flows, sharded
+    from lagrangiancoherence_amd.engine import Engine
+    eng = Engine(0)
+    u, v, lat, lon = flows.era5_like(nt=7, ny=72, nx=144)
+    if dtype == "float64":
+        u, v, lat, lon = (a.astype(np.float64) for a in (u, v, lat, lon))
+    slat, slon = flows.seed_grid(192, 320, lat, lon)
+    slat, slon = slat.astype(dtype), slon.astype(dtype)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    full = eng.lcs(f, slat, slon, -900.0, SETTLS_order=4, interp_order=order)
+    for world in (2, 3):
+        seen = []
+        for rank in range(world):
+            out = sharded.sharded_lcs(eng, f, slat, slon, -900.0, rank, world, SETTLS_order=4, interp_order=order,
+                                      partition="interleaved", window=32, redundant_halo=True)
+            assert out["rows"] == sharded.interleaved_partition(192, world, rank, 32) and len(out["rows"]) == 6 // world
+            g = torch.as_tensor(out["global_rows"], device=full["sigma"].device)
+            seen += out["global_rows"]
+            for k in ("sigma", "x_dep", "y_dep"):
+                assert torch.equal(out[k], full[k][g]), (world, rank, k)
+        assert sorted(seen) == list(range(192))
+    eng.close()
 
 
 def test_native_rccl_communicator_single_rank():

@@ -144,25 +144,56 @@ def row_sharded(name, ny_global, nx, nt, weak, balance_levels=0):
     return out
 
 
-def interleaved(name, ny_global, nx, nt, N, chunk):
-    """A costed alternative to contiguous row blocks (NOT what sharded.py does): rank r takes the row chunks r, r + N, r + 2N, ...
-    of `chunk` rows, each extended by the HALO rows either side that its sigma rows need (advected redundantly: no exchange), all
-    in ONE lc_advect call over the concatenated rows.  Every rank then holds every latitude band.  The existing ABI carries it:
-    only the pole-row rule looks at a seed's global row index (row0 + local row), so row0 = 0 for the rank holding the first
-    rows, ny_global - n_local for the one holding the last, and anything in between otherwise."""
+def interleaved(name, ny_global, nx, nt, redundant=False):
+    """The PRODUCT's strong-scaling partition (sharded.interleaved_chunks, round 6), every rank's share on this one GPU as
+    bench.py's member_pass_chunks issues it: ONE lc_advect over the rank's concatenated chunks (Engine.advect(global_rows=...)),
+    lc_sigma once per chunk on its window; the ring exchange of the chunks' halo rows is the one term that cannot be measured
+    here (`redundant`: the first cut instead -- every chunk's halo rows advected redundantly, no exchange: 1040 rows per rank
+    of C4 where the exchange form has 1024).  step(N) = pack + max over ranks (advect + sigma); efficiency = step(1) / (N step(N))."""
     u, v, lat, lon = flows.era5_like_on_device(torch, eng.device, nt=nt)
+    out = {"workload": name, "ny_global": ny_global, "nx": nx, "nt": nt,
+           "partition": "sharded.interleaved_chunks" + (", halo rows advected redundantly" if redundant else ", halo rows exchanged"), "per_N": {}}
+    out["pack_ms"] = timed(lambda: eng.prepare_field(u, v, lat, lon, 1))
     field = eng.prepare_field(u, v, lat, lon, 1)
     slat, slon = flows.seed_grid(ny_global, nx, lat, lon)
-    slon_d = eng.to_device(slon, np.float32)
-    H = sharded.HALO
-    ranks = []
-    for r in range(N):
-        rows = np.concatenate([np.arange(max(c0 - H, 0), min(c0 + chunk + H, ny_global)) for c0 in range(r * chunk, ny_global, N * chunk)])
-        row0 = 0 if rows[0] == 0 else (ny_global - rows.size if rows[-1] == ny_global - 1 else 3)
-        sl = eng.to_device(slat[rows], np.float32)
-        a = timed(lambda: eng.advect(field, sl, slon_d, dt, K, 1, True, 0, nt - 1, row0=row0, ny_global=ny_global))
-        ranks.append({"rank": r, "rows": int(rows.size), "advect_ms": round(a, 4), "kernel": eng.last_advect_kernel()})
-    return {"workload": name, "N": N, "chunk_rows": chunk, "ranks": ranks, "worst_advect_ms": max(q["advect_ms"] for q in ranks)}
+    slat_d, slon_d = eng.to_device(slat, np.float32), eng.to_device(slon, np.float32)
+    dlat, dlon = float(slat[1] - slat[0]), float(slon[1] - slon[0])
+    for N in (1, 2, 4, 8):
+        ranks = []
+        for r in range(N):
+            chunks = sharded.interleaved_partition(ny_global, N, r)
+            rows = np.asarray(sharded.interleaved_rows(ny_global, chunks, with_halo=redundant), dtype=np.int64)
+            sl = slat_d[torch.as_tensor(rows, device=slat_d.device)].contiguous()
+            box = {}
+
+            def adv():
+                box["xy"] = eng.advect(field, sl, slon_d, dt, K, 1, True, 0, nt - 1, ny_global=ny_global, global_rows=rows)
+            a = timed(adv, 2 if N == 1 else REPS)
+            x_all, y_all = box["xy"]
+            if not redundant:      # the windows the exchange would deliver: here the chunk rows with NaN halo rows (timing only)
+                nanrows = torch.full((2, 2 * sharded.HALO * len(chunks), nx), float("nan"), dtype=x_all.dtype, device=x_all.device)
+                x_all, y_all = sharded._assemble_windows(x_all, y_all, chunks, ny_global, nanrows, nanrows)
+
+            def sig():
+                off = 0
+                for lo, hi in chunks:
+                    w0, w1 = sharded.chunk_window(ny_global, lo, hi)
+                    eng.sigma(x_all[off:off + w1 - w0], y_all[off:off + w1 - w0], slat_d[w0:w1], dlat, dlon, ny_global=ny_global,
+                              in_row0=w0, out_row0=lo, n_out_rows=hi - lo)
+                    off += w1 - w0
+            sg = timed(sig)
+            ranks.append({"rank": r, "chunks": len(chunks), "own_rows": int(sum(h - l for l, h in chunks)), "advected_rows": int(rows.size),
+                          "advect_ms": round(a, 4), "sigma_ms": round(sg, 4), "kernel": eng.last_advect_kernel()})
+            del box, x_all, y_all
+        worst = max(q["advect_ms"] + q["sigma_ms"] for q in ranks)
+        adv_ms = [q["advect_ms"] for q in ranks]
+        out["per_N"][N] = {"ranks": ranks, "step_ms_without_exchange": round(out["pack_ms"] + worst, 4),
+                           "advect_spread": round((max(adv_ms) - min(adv_ms)) / (sum(adv_ms) / len(adv_ms)), 4)}
+        torch.cuda.empty_cache()
+    s1 = out["per_N"][1]["step_ms_without_exchange"]
+    for N, d in out["per_N"].items():
+        d["efficiency"] = round(s1 / (N * d["step_ms_without_exchange"]), 4)
+    return out
 
 
 def ensemble(name, n_members, seeds, nt, nsteps):
@@ -204,8 +235,10 @@ for w in which:
         r = row_sharded("c3 strong (4096^2 in all)", 4096, 4096, 97, False)
     elif w == "c4":
         r = row_sharded("c4 strong (8192^2 x 384)", 8192, 8192, 385, False)
-    elif w.startswith("c4i"):       # c4i128: 8 ranks, interleaved chunks of 128 rows with redundant halo rows
-        r = interleaved(f"c4 strong, 8 ranks, interleaved chunks of {w[3:]} rows", 8192, 8192, 385, 8, int(w[3:]))
+    elif w in ("c4p", "c4pr"):      # the product's interleaved chunks (strong scaling), 1 / 2 / 4 / 8 ranks; c4pr: halo rows redundant
+        r = interleaved("c4 strong (8192^2 x 384), interleaved 256-row chunks", 8192, 8192, 385, w.endswith("r"))
+    elif w in ("c3sp", "c3spr"):
+        r = interleaved("c3 strong (4096^2 x 96), interleaved 256-row chunks", 4096, 4096, 97, w.endswith("r"))
     elif w.startswith("c4b"):       # c4b32: rows cut by the cost measured over the first 32 levels
         r = row_sharded(f"c4 strong, rows cut by measured cost ({w[3:]} pilot levels)", 8192, 8192, 385, False, int(w[3:]))
     elif w.startswith("c3sb"):
