@@ -851,9 +851,9 @@ def main():
                     help="c3 only: weak (default) = --seeds rows per GPU, strong = one --seeds x --seeds grid over all ranks")
     ap.add_argument("--seeds", type=int, default=None, help="seed rows (per GPU when weak) and seed columns")
     ap.add_argument("--partition", default="auto", choices=["auto", "contiguous", "interleaved"],
-                    help="N > 1, strong scaling (c4, c3 --scaling strong): auto / interleaved = interleaved 256-row chunks (every rank holds "
-                         "every latitude band; ring exchange of the chunks' halo rows) when they deal out evenly, two or more per rank; "
-                         "contiguous = row blocks + the line exchange (what weak scaling always uses)")
+                    help="N > 1: auto / contiguous = row blocks + the 2-row line exchange; interleaved (strong scaling only: c4, c3 --scaling "
+                         "strong) = interleaved 256-row chunks, every rank holding every latitude band, ring exchange of the chunks' halo "
+                         "rows (when they deal out evenly, two or more per rank; measured: profiles/r06/shard_costs_*.jsonl)")
     ap.add_argument("--nt", type=int, default=None, help="time levels (default 97 / 385 / 264 for c3 / c4 / c5)")
     ap.add_argument("--settls", type=int, default=4)
     ap.add_argument("--order", type=int, default=1)
@@ -1008,12 +1008,14 @@ def main():
     n_lo, n_hi = sharded.halo_rows(ny_global, lo, hi) if rworld > 1 else (0, 0)
     slat_d = eng.to_device(slat, np.float32)      # seeds resident too: the event brackets hold kernels only
     slon_d = eng.to_device(slon, np.float32)
-    # STRONG scaling (c4, c3 --scaling strong) over N > 1 ranks: the interleaved, patch-aligned row chunks (sharded.py: rank r
-    # owns chunks r, r + N, ... of 256 rows, advects them in ONE lc_advect, exchanges every chunk's 2 + 2 halo rows with ranks
-    # r - 1 / r + 1 in one batch -- a ring) -- every rank holds every latitude band instead of one.  --partition contiguous keeps
-    # the row blocks + the line exchange (always so for weak scaling, and when the chunks do not deal out evenly).
+    # --partition interleaved (strong scaling: c4, c3 --scaling strong): the interleaved 256-row chunks of sharded.py -- rank r
+    # owns chunks r, r + N, ..., advects them in ONE lc_advect, exchanges every chunk's 2 + 2 halo rows with ranks r - 1 / r + 1 in
+    # one batch (a ring) -- so that every rank holds every latitude band instead of one.  Built and measured in round 6
+    # (profiles/r06/shard_costs_*.jsonl) and NOT the default: on C4 at 8 ranks the rank that draws a polar chunk is slower than
+    # the slowest contiguous block (the chunk's four workgroup rows land on four of its eight XCDs), 0.70 against 0.74; at 2 and
+    # 4 ranks the two partitions are within 1 %.  auto = contiguous row blocks + the line exchange.
     chunks = None
-    if rworld > 1 and scaling == "strong" and args.partition != "contiguous" and not args.traj:
+    if rworld > 1 and scaling == "strong" and args.partition == "interleaved" and not args.traj:
         mine = sharded.interleaved_partition(ny_global, world, rank)
         if len(mine) > 1:
             chunks = mine
@@ -1023,6 +1025,7 @@ def main():
         n_own = sum(h - l for l, h in chunks)
         lo, hi = 0, n_own                          # (hi - lo = the rank's own rows: what the per-GPU figures below count)
         n_lo = n_hi = 0
+    dlat, dlon = float(slat[1] - slat[0]), float(slon[1] - slon[0])
     torch.cuda.synchronize()
 
     # LCS_NATIVE_HALO=1: halo exchange through the C ABI (lc_halo_exchange, RCCL directly) instead of

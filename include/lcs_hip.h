@@ -38,7 +38,7 @@ extern "C" {
  * client built against 100 must be rebuilt), lc_ctx_get_level_chunk, lc_ctx_set/get_f64_fidelity, lc_advect_ex and
  * lc_sample_raw added, lc_field_pack accepts packed_dev == NULL at order 1 (fused-level image only).  lc_version() returns the value the LIBRARY
  * was built with: compare it with this macro before any other call (tests/c/abi_smoke.c, _capi.load do). */
-#define LC_VERSION 103 /* 0.1.3: + lc_ctx_last_pack_kernel (0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify, LC_F64_WIND_F32_LIN32) */
+#define LC_VERSION 104 /* 0.1.4: + lc_ctx_set_host_pipeline, lc_ctx_set_xcd_split (0.1.3: + lc_ctx_last_pack_kernel; 0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify, LC_F64_WIND_F32_LIN32) */
 
 typedef struct lc_ctx lc_ctx;
 
@@ -165,6 +165,24 @@ enum lc_f64_fidelity { LC_F64_AUTO = 0, LC_F64_EXACT_ORDER = 1, LC_F64_FAST = 2 
 #define LC_EXACT_ORDER_MAX_SEEDS (1 << 18)
 int lc_ctx_set_f64_fidelity(lc_ctx *ctx, int mode);
 int lc_ctx_get_f64_fidelity(const lc_ctx *ctx, int *mode_out);
+/* How the one-call host routes move their host buffers (no reference counterpart: LCS/LCS.py:129-157 runs on host arrays).
+ *   1 (default)  through a ring of four 32 MB pinned staging buffers filled / emptied by a few host threads (kept on the context
+ *                from the first call that needs it: 128 MB of pinned memory, freed by lc_ctx_destroy): pageable caller memory
+ *                then travels at the bus rate whatever state its pages are in (hipMemcpy from pages the runtime has not pinned
+ *                before runs at a quarter of it), the upload is cut at time-level boundaries and the pack + advect kernels of level
+ *                chunk c run while chunk c + 1 is on the bus (cyclic_x = LC_X_CYCLIC, fused levels, no trajectories, 32 steps or
+ *                more; lc_advect_from continuation: bit-identical to the serial form), only the levels [t0, t0 + nsteps] travel,
+ *                and the caller's output pages are touched by a background thread meanwhile.  A host with no pinned memory to
+ *                give falls back to 0 by itself.
+ *   0            plain hipMemcpyAsync of the whole series on the context's stream, then pack, advect, sigma, copies back.
+ * LCS_HOST_PIPELINE (0 / 1) sets the initial value, read ONCE in lc_ctx_create. */
+int lc_ctx_set_host_pipeline(lc_ctx *ctx, int on);
+/* How lc_advect deals the workgroups of a launch to the 8 XCDs: -1 (default) by the launch's shape -- whole workgroup rows
+ * cyclically, eighths of a row when the row count would leave the XCDs more than 15 % apart; 0 whole rows always; n > 0 a
+ * 1 / n part of a row per chunk.  (A seed block whose rows do not cost alike -- the polar rows of a global grid take several
+ * times longer -- ends on the XCD that drew them; 8 spreads every row over all XCDs at ~4-15 % on launches that were even.)
+ * LCS_XCD_SPLIT sets the initial value, read ONCE in lc_ctx_create. */
+int lc_ctx_set_xcd_split(lc_ctx *ctx, int split);
 /* Name of the kernel the context's last lc_advect call launched (static string, "" before the first call);
  * what a profiler shows, so a benchmark labels its numbers with the kernel that actually ran. */
 const char *lc_ctx_last_advect_kernel(const lc_ctx *ctx);
@@ -490,8 +508,10 @@ int lc_comm_flag_allreduce(void *comm /* lc_comm* */, void *flags_dev, size_t co
 
 /* ---- one-call host entry point ----------------------------------------------
  * What a reference-side binding would call from LCS.__call__ (LCS/LCS.py:129-157):
- * host arrays in, host arrays out; upload, pack, advect, sigma, download, sync.
- * Any of sigma_out / x_out / y_out / traj_x / traj_y may be NULL. */
+ * host arrays in, host arrays out; upload, pack, advect, sigma, download, sync -- with the upload overlapped with the
+ * kernels level chunk by level chunk and every transfer staged through pinned memory (lc_ctx_set_host_pipeline, the
+ * default); keep the context across calls: it owns the staging ring.  The output buffers may be written (zeros) before the
+ * results arrive.  Any of sigma_out / x_out / y_out / traj_x / traj_y may be NULL. */
 int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, int dtype,
                 int nt, int ny_f, int nx_f,
                 const void *lat_f_host, const void *lon_f_host,

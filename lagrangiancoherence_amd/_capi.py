@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblcs_hip.so")
 
-LC_VERSION = 103     # include/lcs_hip.h: the ABI these prototypes describe (checked against lc_version() in load())
+LC_VERSION = 104     # include/lcs_hip.h: the ABI these prototypes describe (checked against lc_version() in load())
 LC_F32, LC_F64, LC_F64_WIND_F32, LC_F64_WIND_F32_LIN32 = 0, 1, 2, 3
 LC_OK, LC_EINVAL, LC_EUNSUPPORTED, LC_EHIP, LC_ENOMEM, LC_ERCCL = 0, -1, -2, -3, -4, -5
 LC_LAYOUT_REFERENCE, LC_LAYOUT_PHYSICAL = 0, 1
@@ -38,6 +38,8 @@ PROTOTYPES = {
     "lc_ctx_get_level_chunk": (_i, [_vp, C.POINTER(_i)]),
     "lc_ctx_set_f64_fidelity": (_i, [_vp, _i]),
     "lc_ctx_get_f64_fidelity": (_i, [_vp, C.POINTER(_i)]),
+    "lc_ctx_set_host_pipeline": (_i, [_vp, _i]),
+    "lc_ctx_set_xcd_split": (_i, [_vp, _i]),
     "lc_ctx_set_flag_allreduce": (_i, [_vp, _vp, _vp]),
     "lc_ctx_last_advect_kernel": (C.c_char_p, [_vp]),
     "lc_ctx_last_advect_launches": (_i, [_vp]),

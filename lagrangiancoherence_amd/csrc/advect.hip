@@ -1770,6 +1770,7 @@ struct Lds2Geom {  // staging: a tile row = COLS/2 lanes x 16 bytes
 __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_cause[4];  // seed-samples outside the tile in x, in y, of those below (x < lo), (y < lo)
 __device__ unsigned long long g_redo[3][3][3];  // [latitude band 0-30 / 30-60 / 60-90][third of the levels][samples, with redo, seeds redone]
+__device__ unsigned long long g_hist[2][5];     // wave-levels by the number of their K = 4 iterations with a redo: [0] all, [1] those whose PREVIOUS level had >= 3
 #define LCS_STAMP(i)                                           \
     {                                                          \
         const long long _t = __builtin_amdgcn_s_memtime();     \
@@ -1822,6 +1823,22 @@ constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byt
 #ifndef LCS_LDS2_DEFER_X
 #define LCS_LDS2_DEFER_X 1
 #endif
+// DIRECT LEVELS (round 6).  Which waves leave their tiles is not spread thin: on C3, 77 % of the wave-levels have no redo in
+// any of their four iterations and 17 % have one in ALL four (2.5 / 1.7 / 1.3 % in one / two / three), and a wave that had
+// three or more is at four again in the next level 92 times in 100 (-DLCS_STAMPS, g_hist: patches the flow has stretched
+// beyond the tile, polar rows whose zonal travel is longer than the tile -- they stay that way).  Such a wave pays for the
+// tile (staging, 2 x 17 instructions of window arithmetic per iteration) and then for the exact sequence on top (2 x 27) in
+// every iteration.  So a wave whose level had >= 3 iterations with a redo takes the next LCS_LDS2_DIRECT_LEVELS levels
+// DIRECT: no tile, every lane through the exact sequence (the redo block, unmasked); then one level with a tile again, which
+// decides anew.  Same functions, same values (a seed's bits do not depend on which path served it).  0 = never.
+// MEASURED AND NOT ADOPTED (profiles/r06/direct_levels_ab.txt): C3 advect 5.99-6.03 ms without, 6.13-6.15 / 6.15-6.20 /
+// 6.23-6.25 ms with 3 / 7 / 15 direct levels -- the instructions saved (~12 % of the VALU stream) are vector-L1 lookups
+// spent: a direct level gathers 2 x 16 bytes per sample for ALL 64 lanes of the wave where the redo path gathers for the
+// ~29 % that left the tile, and the vector L1 already answers 0.73 lookups per CU-cycle.  (A launch made of polar rows alone
+// does gain: rank 7 of 8 of C4, 14.2 -> 13.0 ms.)  Kept as a compile-time option, off.
+#ifndef LCS_LDS2_DIRECT_LEVELS
+#define LCS_LDS2_DIRECT_LEVELS 0
+#endif
 template <int KFIX, bool CYCLIC, int MODE>
 __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgpu_num_sgpr(LCS_LDS2_NUM_SGPR)))
     advect_lds2_kernel(const AdvectArgs<float> A0) {
@@ -1831,6 +1848,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     constexpr int NS = SPL;  // seeds per lane (member groups: members per lane)
     constexpr int ORDER = 1;
     constexpr bool DEFER_X = LCS_LDS2_DEFER_X != 0;
+    constexpr int DIRECT_LEVELS = DEFER_X ? LCS_LDS2_DIRECT_LEVELS : 0;
     const int K = KFIX >= 0 ? KFIX : A.K;
     typedef Lds2Geom G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = LCS_LDS2_ROWS;
@@ -1951,8 +1969,15 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
 #ifdef LCS_STAMPS
     long long acc_t[5] = {0, 0, 0, 0, 0}, last_t = __builtin_amdgcn_s_memtime();
     unsigned long long acc_n[3] = {0, 0, 0};
+    int prev_redos = 0;
 #endif
+    int direct_left = 0;  // wave-uniform: levels this wave still takes without a tile
     for (int s = 0; s < nlev; ++s) {
+        const bool direct = DIRECT_LEVELS > 0 && direct_left > 0;
+        if (direct) --direct_left;
+#ifdef LCS_STAMPS
+        int level_redos = 0;
+#endif
         f2 c0[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) c0[q] = to_index(p[q]);
@@ -1984,7 +2009,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
         int ox = 0, oy = 0;
         f4 stage[NPASS];
         f2 stage_next[NPASS];
-        if (K > 0) {
+        if (K > 0 && !direct) {
             // (anchoring a pair's tile half way between its two members instead: 276.4 against 276.4 ms on config 5)
             const f2 ca = dprev * (1.0f + kpred) + of_anchor(c0);
             const int rxm = __builtin_amdgcn_readlane((int)floor_to_uint(ca.x), CENTRE);
@@ -2034,7 +2059,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
         // ---- 3. tile into LDS ------------------------------------------------------------------------
         int lo_x = 0x40000000, lo_y = 0x40000000, lim_x = 0, lim_y = 0;  // no tile: nothing is "inside"
         unsigned base_addr = tile_addr;
-        if (K > 0) {
+        if (K > 0 && !direct) {
             __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
 #pragma unroll
             for (int r = 0; r < NPASS; ++r) {
@@ -2069,6 +2094,19 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
 #endif
         LCS_STAMP(2)  // wait for the tile + LDS write
         // ---- 4. K iterations out of LDS (latitude clamp deferred to the redo path / the level's end) -----
+        int redos = 0;  // iterations of this level in which some lane needed the exact sequence (wave-uniform)
+        if (direct) {   // (see LCS_LDS2_DIRECT_LEVELS) the exact sequence for every lane, no tile
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    f2 pc = p[q];
+                    clamp_position_c<CYCLIC>(A, pc, ymax_v);
+                    const TapL t = tap_of(index_coords(A, pc));
+                    p[q] = hd[q] * window_global<ORDER>(elv, A, t, e[q]) + pc;
+                }
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             anybad = false;
@@ -2107,6 +2145,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
                 if (lane == 0) {
                     acc_n[0] += 1;
                     acc_n[1] += (m0 | m1) ? 1 : 0;
+                    level_redos += (m0 | m1) ? 1 : 0;
                     acc_n[2] += __popcll(m0) + __popcll(m1);
                     const int band = min(2, (int)(fabsf(A.seed_lat[min(iy0, A.ny - 1)]) / 30.0f)), third = min(2, 3 * s / A.nsteps);
                     atomicAdd(&g_redo[band][third][0], 1ull);
@@ -2115,6 +2154,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
                 }
             }
 #endif
+            if (DIRECT_LEVELS > 0) redos += __ballot(anybad) != 0ull;
             if (anybad) {
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
@@ -2133,6 +2173,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
 #pragma unroll
             for (int q = 0; q < NS; ++q) p[q] = pn[q];
         }
+        if (DIRECT_LEVELS > 0 && redos >= 3) direct_left = DIRECT_LEVELS;
 #pragma unroll
         for (int q = 0; q < NS; ++q) {  // the level's one latitude clamp -- and, with DEFER_X, its one longitude test
             if (DEFER_X)
@@ -2169,6 +2210,13 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
         asm volatile("" : : "v"(p[0].x), "v"(p[1].x));
 #endif
         LCS_STAMP(3)  // K iterations
+#ifdef LCS_STAMPS
+        if (lane == 0) {
+            atomicAdd(&g_hist[0][min(level_redos, 4)], 1ull);
+            if (prev_redos >= 3) atomicAdd(&g_hist[1][min(level_redos, 4)], 1ull);
+            prev_redos = level_redos;
+        }
+#endif
         lvl += A.level_elems;
         elv += A.level_elems;
     }
@@ -4015,6 +4063,14 @@ extern "C" int lc_debug_read_cause(unsigned long long *out4, int reset) {
     if (reset) {
         unsigned long long z[4] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_cause), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+extern "C" int lc_debug_read_hist(unsigned long long *out10, int reset) {
+    if (hipMemcpyFromSymbol(out10, HIP_SYMBOL(g_hist), sizeof(g_hist)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[10] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_hist), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
 }

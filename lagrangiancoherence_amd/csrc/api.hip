@@ -1,10 +1,12 @@
 // C ABI glue: contexts, device memory, error strings, field packing entry point,
 // Gaussian smoothing of the departure fields, and the one-call host entry point.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include "hostxfer.h"
 #include "lcs_common.h"
 
 static thread_local char g_err[1024] = "";
@@ -82,6 +84,10 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->last_pack_kernel = "";
     c->verify_dev = nullptr;
     c->trunc = nullptr;
+    c->xfer = nullptr;
+    c->host_timing = getenv("LCS_HOST_TIMING") != nullptr;
+    c->host_pipeline = 1;
+    if (const char *ev = getenv("LCS_HOST_PIPELINE")) c->host_pipeline = ev[0] != '0';  // read once, here
     *out = c;
     return LC_OK;
 }
@@ -111,6 +117,20 @@ extern "C" int lc_ctx_set_f64_fidelity(lc_ctx *ctx, int mode) {
     LC_REQUIRE(ctx, "lc_ctx_set_f64_fidelity: null context");
     LC_REQUIRE(mode >= LC_F64_AUTO && mode <= LC_F64_FAST, "lc_ctx_set_f64_fidelity: mode %d (LC_F64_AUTO / LC_F64_EXACT_ORDER / LC_F64_FAST)", mode);
     ctx->f64_fidelity = mode;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_set_host_pipeline(lc_ctx *ctx, int on) {
+    LC_REQUIRE(ctx, "lc_ctx_set_host_pipeline: null context");
+    LC_REQUIRE(on == 0 || on == 1, "lc_ctx_set_host_pipeline: 0 or 1");
+    ctx->host_pipeline = on;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_set_xcd_split(lc_ctx *ctx, int split) {
+    LC_REQUIRE(ctx, "lc_ctx_set_xcd_split: null context");
+    LC_REQUIRE(split >= -1 && split <= 64, "lc_ctx_set_xcd_split: -1 (by shape), 0 (whole rows) or 1 .. 64");
+    ctx->xcd_split = split;
     return LC_OK;
 }
 
@@ -233,6 +253,7 @@ extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     lc_trunc_cache_free(ctx->trunc);
+    lc_host_xfer::destroy(ctx->xfer);
     if (ctx->verify_dev) (void)hipFree(ctx->verify_dev);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -492,6 +513,11 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     const double dlat = dtype == LC_F32 ? (double)((float)s_lat1 - (float)s_lat0) : s_lat1 - s_lat0;
     const double dlon = dtype == LC_F32 ? (double)((float)s_lon1 - (float)s_lon0) : s_lon1 - s_lon0;
 
+    // LCS_HOST_TIMING: wall-clock marks of this call (ms since entry) -- allocations done, last upload piece handed to the DMA
+    // engine, kernels finished, results in the caller's buffers
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(); };
+    double t_alloc = 0, t_up = 0, t_kernels = 0;
     DevBuf u, v, lin, cub, ext, slat, slon, x, y, tx, ty, sig, gx, gy, gtmp;
     LC_TRY(u.alloc(fbytes));
     LC_TRY(v.alloc(fbytes));
@@ -507,21 +533,157 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
         LC_TRY(ty.alloc(sbytes * (size_t)(nsteps + 1)));
     }
     hipStream_t st = ctx->stream;
-    LC_HIP_CHECK(hipMemcpyAsync(u.p, u_host, fbytes, hipMemcpyHostToDevice, st));
-    LC_HIP_CHECK(hipMemcpyAsync(v.p, v_host, fbytes, hipMemcpyHostToDevice, st));
-    LC_HIP_CHECK(hipMemcpyAsync(slat.p, seed_lat_host, ny * es, hipMemcpyHostToDevice, st));
-    LC_HIP_CHECK(hipMemcpyAsync(slon.p, seed_lon_host, nx * es, hipMemcpyHostToDevice, st));
     // one combined sample per SETTLS iteration (ext image of the matching order) in float32, and in float64 beyond the
     // size / setting where the reference's own operation order is kept (lc_ctx_set_f64_fidelity)
     const bool fusable = (interp_order == 1 || interp_order == 3) && !f64_exact_order(ctx, dtype, ny, nx);
     if (settls_order > 0 && fusable) LC_TRY(ext.alloc(lc_packed_elems(nt - 1, ny_f, nx_f) * es));
-    if (need_lin || (interp_order == 1 && ext.p))
-        LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, 1, lin.p, interp_order == 1 ? ext.p : nullptr));
-    if (interp_order != 1) LC_TRY(lc_field_pack(ctx, u.p, v.p, dtype, nt, ny_f, nx_f, interp_order, cub.p, ext.p));
-    LC_TRY(advect_with_raw(ctx, lin.p, cub.p, ext.p, u.p, v.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny,
-                           slon.p, nx, timestep, settls_order, interp_order, cyclic_x, t0, nsteps, x.p, y.p, tx.p, ty.p));
+    if (sigma_out) LC_TRY(sig.alloc(sbytes));
+
+    // ---- transfers: the staging ring (hostxfer.h), or plain hipMemcpyAsync when it cannot be had / is switched off --------
+    lc_host_xfer *hx = nullptr;
+    if (ctx->host_pipeline) {
+        if (!ctx->xfer) {
+            hipError_t e = hipSuccess;
+            ctx->xfer = lc_host_xfer::create(&e);
+            if (!ctx->xfer) (void)hipGetLastError();  // (no pinned memory / stream to be had: the plain copies below)
+        }
+        hx = ctx->xfer;
+    }
+    // whatever happens below, no DMA of this call is left running into / out of buffers that are about to be freed
+    struct Drain {
+        lc_host_xfer *hx;
+        hipStream_t st;
+        ~Drain() {
+            if (hx) hx->drain();
+            (void)hipStreamSynchronize(st);
+        }
+    } drain{hx, st};
+    lc_prefault touch;  // (declared after `drain`: joined first)
+    hipEvent_t ev_ready = nullptr, ev_up = nullptr, ev_done = nullptr;
+    struct Events {
+        hipEvent_t *e[3];
+        ~Events() {
+            for (auto p : e)
+                if (*p) (void)hipEventDestroy(*p);
+        }
+    } events{{&ev_ready, &ev_up, &ev_done}};
+    auto up = [&](void *dev, const void *host, size_t bytes) -> int {
+        if (!bytes) return LC_OK;
+        if (hx) {
+            LC_HIP_CHECK(hx->upload(dev, host, bytes));
+        } else {
+            LC_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+        }
+        return LC_OK;
+    };
+    auto down = [&](void *host, const void *dev, size_t bytes) -> int {
+        if (hx) {
+            LC_HIP_CHECK(hx->download(host, dev, bytes));
+        } else {
+            LC_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+        }
+        return LC_OK;
+    };
+    if (hx) {
+        LC_HIP_CHECK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        LC_HIP_CHECK(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+        LC_HIP_CHECK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        // the copy stream starts after whatever the caller's stream was doing with this memory (nothing, normally)
+        LC_HIP_CHECK(hipEventRecord(ev_ready, st));
+        LC_HIP_CHECK(hipStreamWaitEvent(hx->copy, ev_ready, 0));
+        std::vector<std::pair<void *, size_t>> outs;
+        if (sigma_out) outs.emplace_back(sigma_out, sbytes);
+        if (x_out) outs.emplace_back(x_out, sbytes);
+        if (y_out) outs.emplace_back(y_out, sbytes);
+        if (traj_x) {
+            outs.emplace_back(traj_x, sbytes * (size_t)(nsteps + 1));
+            outs.emplace_back(traj_y, sbytes * (size_t)(nsteps + 1));
+        }
+        touch.start(outs);
+    }
+    t_alloc = ms_since();
+    LC_TRY(up(slat.p, seed_lat_host, ny * es));
+    LC_TRY(up(slon.p, seed_lon_host, nx * es));
+
+    // ---- upload || pack + advect, level chunk by level chunk ------------------------------------------------------------------
+    // Chunk c covers the steps [s0, s1): it needs the wind levels t0 + s0 ... t0 + s1 (the first of them arrived with chunk
+    // c - 1), packs the images of exactly those levels (lc_field_pack on the sub-range: the level two chunks share is packed by
+    // both, same values) and continues the advection in place (lc_advect_from: LCS/trajectory.py:80-126 carries only the
+    // positions from level to level) -- bit-identical to the serial form.  While its kernels run on the context's stream, the
+    // host threads and the DMA engine are already moving chunk c + 1.  Only the levels the call uses travel.
+    // Serial form (one upload of the used levels, one pack, one advect): the reference's non-cyclic outer-product clamp (it
+    // restarts the series), trajectories, the exact-order float64 form, orders other than 1 / 3, short series.
+    const size_t lvl_bytes = (size_t)ny_f * nx_f * es, le = lc_packed_elems(1, ny_f, nx_f);
+    const int PIPE_LEVELS = 16;
+    const bool piped = hx && cyclic_x == LC_X_CYCLIC && ext.p && !traj_x && nsteps >= 2 * PIPE_LEVELS;
+    auto pack_levels = [&](int l0, int nlev) -> int {  // images of wind levels [l0, l0 + nlev), ext of [l0, l0 + nlev - 1)
+        const char *ul = (const char *)u.p + (size_t)l0 * lvl_bytes, *vl = (const char *)v.p + (size_t)l0 * lvl_bytes;
+        void *el = ext.p ? (char *)ext.p + (size_t)l0 * le * es : nullptr;
+        if (need_lin || (interp_order == 1 && ext.p))
+            LC_TRY(lc_field_pack(ctx, ul, vl, dtype, nlev, ny_f, nx_f, 1, lin.p ? (char *)lin.p + (size_t)l0 * le * es : nullptr,
+                                 interp_order == 1 ? el : nullptr));
+        if (interp_order != 1)
+            LC_TRY(lc_field_pack(ctx, ul, vl, dtype, nlev, ny_f, nx_f, interp_order, (char *)cub.p + (size_t)l0 * le * es, el));
+        return LC_OK;
+    };
+    if (piped) {
+        for (int s0 = 0; s0 < nsteps; s0 += PIPE_LEVELS) {
+            const int s1 = std::min(nsteps, s0 + PIPE_LEVELS), first = t0 + s0 + (s0 ? 1 : 0), last = t0 + s1;
+            LC_TRY(up((char *)u.p + (size_t)first * lvl_bytes, (const char *)u_host + (size_t)first * lvl_bytes, (size_t)(last - first + 1) * lvl_bytes));
+            LC_TRY(up((char *)v.p + (size_t)first * lvl_bytes, (const char *)v_host + (size_t)first * lvl_bytes, (size_t)(last - first + 1) * lvl_bytes));
+            LC_HIP_CHECK(hipEventRecord(ev_up, hx->copy));
+            LC_HIP_CHECK(hipStreamWaitEvent(st, ev_up, 0));
+            LC_TRY(pack_levels(t0 + s0, s1 - s0 + 1));
+            lc_advect_args a = {};
+            a.struct_size = sizeof(a);
+            a.packed_lin = lin.p;
+            a.packed_cub = cub.p;
+            a.packed_ext = ext.p;
+            a.u_raw = u.p;
+            a.v_raw = v.p;
+            a.dtype = dtype;
+            a.nt = nt;
+            a.ny_f = ny_f;
+            a.nx_f = nx_f;
+            a.lat_min = lat_min;
+            a.lat_max = lat_max;
+            a.lon_min = lon_min;
+            a.lon_max = lon_max;
+            a.seed_lat_dev = slat.p;
+            a.ny = ny;
+            a.seed_lon_dev = slon.p;
+            a.nx = nx;
+            a.row0 = 0;
+            a.ny_global = ny;
+            a.x_start = s0 ? x.p : nullptr;
+            a.y_start = s0 ? y.p : nullptr;
+            a.timestep = timestep;
+            a.settls_order = settls_order;
+            a.interp_order = interp_order;
+            a.cyclic_x = cyclic_x;
+            a.t0 = t0 + s0;
+            a.nsteps = s1 - s0;
+            a.n_members = 1;
+            a.x_out = x.p;
+            a.y_out = y.p;
+            LC_TRY(lc_advect_ex(ctx, &a));
+        }
+    } else {
+        // only the levels [t0, t0 + nsteps] are read (the pack of the whole series below touches the others' device memory:
+        // they travel too unless the call uses a sub-range, in which case the images of the used levels alone are packed)
+        const bool sub = hx && nsteps >= 1 && (t0 > 0 || t0 + nsteps < nt - 1) && cyclic_x != LC_X_CLAMP_REFERENCE_OUTER;
+        const int l0 = sub ? t0 : 0, nlev = sub ? nsteps + 1 : nt;
+        LC_TRY(up((char *)u.p + (size_t)l0 * lvl_bytes, (const char *)u_host + (size_t)l0 * lvl_bytes, (size_t)nlev * lvl_bytes));
+        LC_TRY(up((char *)v.p + (size_t)l0 * lvl_bytes, (const char *)v_host + (size_t)l0 * lvl_bytes, (size_t)nlev * lvl_bytes));
+        if (hx) {
+            LC_HIP_CHECK(hipEventRecord(ev_up, hx->copy));
+            LC_HIP_CHECK(hipStreamWaitEvent(st, ev_up, 0));
+        }
+        LC_TRY(pack_levels(l0, nlev));
+        LC_TRY(advect_with_raw(ctx, lin.p, cub.p, ext.p, u.p, v.p, dtype, nt, ny_f, nx_f, lat_min, lat_max, lon_min, lon_max, slat.p, ny,
+                               slon.p, nx, timestep, settls_order, interp_order, cyclic_x, t0, nsteps, x.p, y.p, tx.p, ty.p));
+    }
     if (sigma_out) {
-        LC_TRY(sig.alloc(sbytes));
         const void *xs = x.p, *ys = y.p;
         if (gauss_sigma > 1e-15) {  // sigma = 0: scipy returns an unsmoothed copy
             LC_TRY(gx.alloc(sbytes));
@@ -534,16 +696,30 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
         }
         LC_TRY(lc_sigma(ctx, xs, ys, dtype, 0, ny, nx, ny, slat.p, dlat, dlon, fd_fp32_cast, tensor_layout, 0, ny,
                         sig.p));
-        LC_HIP_CHECK(hipMemcpyAsync(sigma_out, sig.p, sbytes, hipMemcpyDeviceToHost, st));
     }
-    if (x_out) LC_HIP_CHECK(hipMemcpyAsync(x_out, x.p, sbytes, hipMemcpyDeviceToHost, st));
-    if (y_out) LC_HIP_CHECK(hipMemcpyAsync(y_out, y.p, sbytes, hipMemcpyDeviceToHost, st));
+    t_up = ms_since();
+    // ---- results down: the departure points travel while nothing else does; sigma (0.07 ms of kernel) last ---------------
+    if (hx) {
+        LC_HIP_CHECK(hipEventRecord(ev_done, st));
+        LC_HIP_CHECK(hipStreamWaitEvent(hx->copy, ev_done, 0));
+        touch.join();
+        if (ctx->host_timing) {
+            LC_HIP_CHECK(hipEventSynchronize(ev_done));
+            t_kernels = ms_since();
+        }
+    }
+    if (x_out) LC_TRY(down(x_out, x.p, sbytes));
+    if (y_out) LC_TRY(down(y_out, y.p, sbytes));
+    if (sigma_out) LC_TRY(down(sigma_out, sig.p, sbytes));
     if (traj_x) {
-        LC_HIP_CHECK(hipMemcpyAsync(traj_x, tx.p, sbytes * (size_t)(nsteps + 1), hipMemcpyDeviceToHost, st));
-        LC_HIP_CHECK(hipMemcpyAsync(traj_y, ty.p, sbytes * (size_t)(nsteps + 1), hipMemcpyDeviceToHost, st));
+        LC_TRY(down(traj_x, tx.p, sbytes * (size_t)(nsteps + 1)));
+        LC_TRY(down(traj_y, ty.p, sbytes * (size_t)(nsteps + 1)));
     }
     LC_HIP_CHECK(hipStreamSynchronize(st));
-    return LC_OK;  // DevBuf destructors free after the sync
+    if (ctx->host_timing)
+        std::fprintf(stderr, "lc_lcs_host: %s, buffers allocated %.2f ms, uploads and launches issued %.2f, kernels done %.2f, results down %.2f\n",
+                     piped ? "pipelined" : (hx ? "staged" : "plain copies"), t_alloc, t_up, t_kernels, ms_since());
+    return LC_OK;  // `drain` waits for both streams, then the DevBuf destructors free
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,216 @@
+// Host <-> device transfers of the one-call host routes (lc_lcs_host): a pinned staging ring fed by a few host threads.
+//
+// What the reference-side binding hands lc_lcs_host is ordinary (pageable) memory: numpy arrays.  Measured on an MI355X box
+// (tools/host_route_probe.hip, profiles/r06/host_route_probe.txt), configs[2]'s 805 MB of wind up and 201 MB of results down:
+//   hipMemcpy from / to pageable memory the runtime has not seen before   14.4 GB/s up, 12.2 GB/s down (it pins the pages
+//                                                                         on the fly: the same range again runs at 56 GB/s)
+//   hipHostRegister of the range, then DMA                                53.6 ms to register 805 MB, then 56.6 GB/s
+//   a ring of 32 MB pinned buffers filled by >= 2 host threads            52.8-53.8 GB/s, whatever the caller's pages are
+// -- so the ring: the DMA of piece k runs while the threads copy piece k + 1, and the upload is cut at time-level boundaries
+// so that the pack and advect kernels of level chunk c run while chunk c + 1 is on the bus (api.hip: lc_lcs_host).
+// Downloads mirror it (DMA into the ring, threads copy out); the pages of the caller's fresh output arrays are touched by a
+// background thread during the upload, so the copy-out does not pay their faults.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+struct lc_host_xfer {
+    static constexpr int RING = 4;
+    size_t piece = (size_t)32 << 20;
+    char *pin[RING] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t dma_done[RING] = {nullptr, nullptr, nullptr, nullptr};  // the last DMA out of / into the slot
+    bool in_flight[RING] = {false, false, false, false};
+    int next = 0;
+    hipStream_t copy = nullptr;  // H2D / D2H DMAs (own non-blocking stream)
+
+    // a few persistent worker threads: parallel_copy() splits one memcpy between them and the calling thread
+    struct Slice {
+        char *dst;
+        const char *src;
+        size_t n;
+    };
+    std::vector<std::thread> workers;
+    std::vector<Slice> slices;  // one per worker, valid while `generation` is odd-numbered work
+    std::mutex m;
+    std::condition_variable wake, finished;
+    unsigned long generation = 0;
+    int pending = 0;
+    bool quit = false;
+
+    void worker(int id) {
+        unsigned long seen = 0;
+        for (;;) {
+            Slice s;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                wake.wait(lk, [&] { return quit || generation != seen; });
+                if (quit) return;
+                seen = generation;
+                s = slices[(size_t)id];
+            }
+            if (s.n) std::memcpy(s.dst, s.src, s.n);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--pending == 0) finished.notify_one();
+            }
+        }
+    }
+
+    void parallel_copy(void *dst, const void *src, size_t n) {
+        const size_t parts = workers.size() + 1;
+        if (workers.empty() || n < ((size_t)1 << 20)) {
+            std::memcpy(dst, src, n);
+            return;
+        }
+        const size_t per = ((n + parts - 1) / parts + 63) / 64 * 64;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t w = 0; w < workers.size(); ++w) {
+                const size_t b = std::min(n, (w + 1) * per), e = std::min(n, (w + 2) * per);
+                slices[w] = Slice{(char *)dst + b, (const char *)src + b, e - b};
+            }
+            pending = (int)workers.size();
+            ++generation;
+        }
+        wake.notify_all();
+        std::memcpy(dst, src, std::min(n, per));
+        std::unique_lock<std::mutex> lk(m);
+        finished.wait(lk, [&] { return pending == 0; });
+    }
+
+    // ---- life cycle -------------------------------------------------------------------------------------------------
+    static lc_host_xfer *create(hipError_t *err) {
+        lc_host_xfer *x = new (std::nothrow) lc_host_xfer;
+        if (!x) {
+            *err = hipErrorOutOfMemory;
+            return nullptr;
+        }
+        hipError_t e = hipStreamCreateWithFlags(&x->copy, hipStreamNonBlocking);
+        for (int i = 0; i < RING && e == hipSuccess; ++i) {
+            e = hipHostMalloc((void **)&x->pin[i], x->piece, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&x->dma_done[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            *err = e;
+            destroy(x);
+            return nullptr;
+        }
+        unsigned hw = std::thread::hardware_concurrency();
+        const int nw = hw >= 8 ? 3 : (hw >= 4 ? 1 : 0);  // + the calling thread: 2 threads already reach the bus rate
+        x->slices.resize((size_t)nw);
+        try {
+            for (int i = 0; i < nw; ++i) x->workers.emplace_back(&lc_host_xfer::worker, x, i);
+        } catch (...) {  // no threads to be had: the calling thread copies alone
+            x->slices.resize(x->workers.size());
+        }
+        *err = hipSuccess;
+        return x;
+    }
+
+    static void destroy(lc_host_xfer *x) {
+        if (!x) return;
+        {
+            std::lock_guard<std::mutex> lk(x->m);
+            x->quit = true;
+        }
+        x->wake.notify_all();
+        for (auto &t : x->workers) t.join();
+        if (x->copy) (void)hipStreamSynchronize(x->copy);
+        for (int i = 0; i < RING; ++i) {
+            if (x->dma_done[i]) (void)hipEventDestroy(x->dma_done[i]);
+            if (x->pin[i]) (void)hipHostFree(x->pin[i]);
+        }
+        if (x->copy) (void)hipStreamDestroy(x->copy);
+        delete x;
+    }
+
+    // ---- transfers ---------------------------------------------------------------------------------------------------
+    // host -> device, enqueued on `copy`; returns when the last piece has been HANDED to the DMA engine (not when it arrived:
+    // record an event on `copy` for that)
+    hipError_t upload(void *dev, const void *host, size_t bytes) {
+        for (size_t off = 0; off < bytes; off += piece) {
+            const size_t n = std::min(piece, bytes - off);
+            const int s = next;
+            next = (next + 1) % RING;
+            if (in_flight[s]) {
+                hipError_t e = hipEventSynchronize(dma_done[s]);
+                if (e != hipSuccess) return e;
+                in_flight[s] = false;
+            }
+            parallel_copy(pin[s], (const char *)host + off, n);
+            hipError_t e = hipMemcpyAsync((char *)dev + off, pin[s], n, hipMemcpyHostToDevice, copy);
+            if (e == hipSuccess) e = hipEventRecord(dma_done[s], copy);
+            if (e != hipSuccess) return e;
+            in_flight[s] = true;
+        }
+        return hipSuccess;
+    }
+
+    // device -> host (after everything enqueued on `copy` so far); returns when the bytes are in `host`
+    hipError_t download(void *host, const void *dev, size_t bytes) {
+        const size_t np = (bytes + piece - 1) / piece;
+        auto issue = [&](size_t i) -> hipError_t {
+            const int s = (int)(i % RING);
+            const size_t off = i * piece, n = std::min(piece, bytes - off);
+            // (a slot still feeding an upload's DMA: that DMA is earlier on the same stream, the stream orders them)
+            hipError_t e = hipMemcpyAsync(pin[s], (const char *)dev + off, n, hipMemcpyDeviceToHost, copy);
+            if (e == hipSuccess) e = hipEventRecord(dma_done[s], copy);
+            in_flight[s] = e == hipSuccess;
+            return e;
+        };
+        for (size_t i = 0; i < std::min(np, (size_t)RING); ++i) {
+            hipError_t e = issue(i);
+            if (e != hipSuccess) return e;
+        }
+        for (size_t j = 0; j < np; ++j) {
+            const int s = (int)(j % RING);
+            hipError_t e = hipEventSynchronize(dma_done[s]);
+            if (e != hipSuccess) return e;
+            in_flight[s] = false;
+            const size_t off = j * piece, n = std::min(piece, bytes - off);
+            parallel_copy((char *)host + off, pin[s], n);
+            if (j + RING < np) {
+                e = issue(j + RING);
+                if (e != hipSuccess) return e;
+            }
+        }
+        next = 0;
+        return hipSuccess;
+    }
+
+    // every DMA handed over so far has finished (before device buffers they touch are freed, or after a failure)
+    void drain() {
+        if (copy) (void)hipStreamSynchronize(copy);
+        for (int i = 0; i < RING; ++i) in_flight[i] = false;
+    }
+};
+
+// Touches every page of a caller's output buffer from a background thread (a fresh numpy array is unfaulted: the copy-out
+// would pay 4 KB faults at a quarter of the copy rate).  Joined by the destructor.
+struct lc_prefault {
+    std::thread t;
+    void start(std::vector<std::pair<void *, size_t>> ranges) {
+        try {
+            t = std::thread([ranges] {
+                for (auto &r : ranges) {
+                    volatile char *p = (volatile char *)r.first;
+                    if (!p) continue;
+                    for (size_t o = 0; o < r.second; o += 4096) p[o] = 0;
+                    if (r.second) p[r.second - 1] = 0;
+                }
+            });
+        } catch (...) {  // no thread: the copy-out pays the faults
+        }
+    }
+    void join() {
+        if (t.joinable()) t.join();
+    }
+    ~lc_prefault() { join(); }
+};

@@ -903,9 +903,11 @@ class Engine:
 def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cyclic_xboundary=False,
              seed_lat=None, seed_lon=None, t0=0, nsteps=None, gauss_sigma=None, fd_fp32_cast=True,
              tensor_layout="reference", return_traj=False, want_sigma=True, device=0, noncyclic_clamp=None,
-             float64_fidelity=None):
+             float64_fidelity=None, pipeline=None):
     """numpy in, numpy out, via the one-call C entry point.  Returns a dict.
-    ``float64_fidelity``: ``'auto'`` (default) / ``'exact'`` / ``'fast'``, see :meth:`Engine.set_f64_fidelity`."""
+    ``float64_fidelity``: ``'auto'`` (default) / ``'exact'`` / ``'fast'``, see :meth:`Engine.set_f64_fidelity`.
+    ``pipeline`` (default on): the staged, level-chunk pipelined transfers of ``lc_ctx_set_host_pipeline``; ``False`` = the
+    serial form (plain copies of the whole series, then the kernels).  Results are bit-identical."""
     lib = _capi.load()
     dtype = common_dtype(u, v, lat_f, lon_f, seed_lat, seed_lon)
     u = np.ascontiguousarray(u, dtype=dtype)
@@ -929,11 +931,11 @@ def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cycli
     def p(a):
         return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
 
-    ctx = C.c_void_p()
-    _capi.check(lib.lc_ctx_create(int(device), C.byref(ctx)), lib)
-    try:
-        if float64_fidelity is not None:
-            _capi.check(lib.lc_ctx_set_f64_fidelity(ctx, Engine._FIDELITY[float64_fidelity]), lib)
+    ctx = _host_ctx(lib, device)
+    with _HOST_LOCK:
+        _capi.check(lib.lc_ctx_set_f64_fidelity(ctx, Engine._FIDELITY[float64_fidelity or "auto"]), lib)
+        on = (os.environ.get("LCS_HOST_PIPELINE", "1")[:1] != "0") if pipeline is None else bool(pipeline)
+        _capi.check(lib.lc_ctx_set_host_pipeline(ctx, int(on)), lib)
         gs = float(gauss_sigma) if isinstance(gauss_sigma, (float, int)) and not isinstance(gauss_sigma, bool) else 0.0
         _capi.check(lib.lc_lcs_host(
             ctx, p(u), p(v), _NP2LC[dtype], nt, ny_f, nx_f, p(lat_f), p(lon_f), p(seed_lat), ny, p(seed_lon), nx,
@@ -941,9 +943,26 @@ def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cycli
             int(t0), nsteps, gs,
             int(bool(fd_fp32_cast)), _LAYOUTS[tensor_layout], p(out.get("sigma")), p(out["x_dep"]), p(out["y_dep"]),
             p(out.get("traj_x")), p(out.get("traj_y"))), lib)
-    finally:
-        lib.lc_ctx_destroy(ctx)
     return out
+
+
+# The one-call routes' context per device, created on first use and kept for the life of the process: it owns the pinned
+# staging ring and the copy threads of lc_lcs_host (lc_ctx_set_host_pipeline), which cost far more to set up than a call
+# takes.  Calls through it are serialised (a context is not re-entrant).
+_HOST_CTX = {}
+_HOST_LOCK = __import__("threading").Lock()
+
+
+def _host_ctx(lib, device):
+    with _HOST_LOCK:
+        ctx = _HOST_CTX.get(int(device))
+        if ctx is None:
+            ctx = C.c_void_p()
+            _capi.check(lib.lc_ctx_create(int(device), C.byref(ctx)), lib)
+            _HOST_CTX[int(device)] = ctx
+            import atexit
+            atexit.register(lambda c=ctx: lib.lc_ctx_destroy(c))
+        return ctx
 
 
 def lcs_global_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, interp_to_common_grid=True,

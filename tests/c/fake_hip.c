@@ -67,6 +67,22 @@ hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : (g_last = hipError
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags) { (void)flags; *s = (hipStream_t)malloc(1); return *s ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { (void)s; return hipSuccess; }
+/* pinned host memory, events, cross-stream waits (the host routes' staging ring, csrc/hostxfer.h): host memory is host memory here,
+ * every "asynchronous" operation has completed when its call returns, so events are tokens and waits are no-ops.  Pinned
+ * allocations are counted like device ones (a leak of either shows in fake_hip_live()). */
+static int g_fail_host_malloc = 0;
+void fake_hip_fail_host_malloc(int on) { g_fail_host_malloc = on; }    /* 1: hipHostMalloc fails (the routes must fall back to plain copies) */
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags) {
+    (void)flags;
+    if (g_fail_host_malloc) { *p = NULL; return g_last = hipErrorOutOfMemory; }
+    return do_malloc(p, bytes);
+}
+hipError_t hipHostFree(void *p) { return do_free(p); }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags) { (void)flags; *e = (hipEvent_t)malloc(1); return *e ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { (void)e; (void)s; return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t e) { (void)e; return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags) { (void)s; (void)e; (void)flags; return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t bytes) { return do_malloc(p, bytes); }
 hipError_t hipMallocAsync(void **p, size_t bytes, hipStream_t s) { (void)s; return do_malloc(p, bytes); }
 hipError_t hipFree(void *p) { return do_free(p); }

@@ -21,6 +21,7 @@ int fake_hip_launches(void);
 int fake_hip_bad_frees(void);
 void fake_hip_fail_malloc_at(int n);
 void fake_hip_fail_memcpy_at(int n);
+void fake_hip_fail_host_malloc(int on);
 void fake_hip_reset_counts(void);
 }
 
@@ -101,6 +102,15 @@ int main() {
     lc_ctx *ctx = nullptr;
     CHECK(lc_ctx_create(3, &ctx) == LC_EINVAL && ctx == nullptr);   // the fake machine has one device
     CHECK(lc_ctx_create(0, &ctx) == LC_OK && ctx != nullptr);
+    {   // the staging ring of the host routes (csrc/hostxfer.h): created by the first call that needs it, kept on the context
+        const int before = fake_hip_live();
+        Case<float> w(5, 24, 40, 33, 47);
+        fake_hip_fail_host_malloc(1);     // no pinned memory to be had: the route falls back to plain copies and keeps nothing
+        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_live() == before);
+        fake_hip_fail_host_malloc(0);
+        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_live() == before + 4);   // four pinned pieces
+        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_live() == before + 4);   // ... once
+    }
     const int base = fake_hip_live();
     {
         Case<float> c(5, 24, 40, 33, 47);
@@ -132,6 +142,19 @@ int main() {
         sweep_failures(ctx, "lc_lcs_host float32 order 3 + gauss", [&] { return c.run(ctx, LC_F32, 4, 3, 1, 2.0, false); });
         sweep_failures(ctx, "lc_lcs_host float64 order 3", [&] { return d.run(ctx, LC_F64, 4, 3, 1, 0.0, true); });
         sweep_failures(ctx, "lc_lcs_host float64 outer clamp", [&] { return d.run(ctx, LC_F64, 2, 1, 2, 0.0, false); });
+        // a series long enough for the pipelined form (upload of level chunk c + 1 while chunk c is packed and advected: three
+        // chunks of 16 levels here), both orders and dtypes, a sub-range of the series, and every allocation / copy of it failing
+        Case<float> p(41, 24, 40, 33, 47);
+        Case<double> q(41, 24, 40, 33, 47);
+        CHECK(p.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && p.run(ctx, LC_F32, 4, 3, 1, 0.0, false) == LC_OK && fake_hip_live() == base);
+        CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_FAST) == LC_OK && q.run(ctx, LC_F64, 4, 1, 1, 0.0, false) == LC_OK && q.run(ctx, LC_F64, 2, 3, 1, 1.0, false) == LC_OK);
+        CHECK(lc_lcs_host(ctx, p.u.data(), p.v.data(), LC_F32, p.nt, p.ny_f, p.nx_f, p.lat.data(), p.lon.data(), p.slat.data(), p.ny, p.slon.data(), p.nx,
+                          -900.0, 4, 1, 1, 3, 35, 0.0, 1, 0, p.sigma.data(), p.x.data(), p.y.data(), nullptr, nullptr) == LC_OK);   // levels 3 .. 38 of 41
+        CHECK(lc_lcs_host(ctx, p.u.data(), p.v.data(), LC_F32, p.nt, p.ny_f, p.nx_f, p.lat.data(), p.lon.data(), p.slat.data(), p.ny, p.slon.data(), p.nx,
+                          -900.0, 4, 1, 1, 5, 7, 0.0, 1, 0, p.sigma.data(), p.x.data(), p.y.data(), nullptr, nullptr) == LC_OK);    // a short sub-range: serial form, those levels only
+        sweep_failures(ctx, "lc_lcs_host float32 order 1, pipelined", [&] { return p.run(ctx, LC_F32, 4, 1, 1, 0.0, false); });
+        sweep_failures(ctx, "lc_lcs_host float64 order 3, pipelined", [&] { return q.run(ctx, LC_F64, 4, 3, 1, 0.0, false); });
+        CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_AUTO) == LC_OK && fake_hip_live() == base);
     }
     {   // the reference's default global call form: regrid + T20 truncation (operator cache) + the path
         int gy = 0, gx = 0;

@@ -102,11 +102,11 @@ def test_bench_two_ranks_rehearsal_carries_a_halo_check(wk, extra, units, scalin
 
 
 def test_bench_two_ranks_strong_scaling_takes_the_interleaved_chunks():
-    """Strong scaling over N > 1 ranks whose 256-row chunks deal out evenly, two or more per rank (here 1024 x 1024 seeds over 2
-    ranks: chunks 0, 2 and 1, 3): bench.py deals the interleaved chunks (sharded.interleaved_chunks), advects a rank's chunks in
+    """--partition interleaved, strong scaling over N > 1 ranks whose 256-row chunks deal out evenly, two or more per rank (here
+    1024 x 1024 seeds over 2 ranks: chunks 0, 2 and 1, 3): bench.py deals the interleaved chunks (sharded.interleaved_chunks), advects a rank's chunks in
     one lc_advect and exchanges every chunk's halo rows in one batch (a ring); the halo check -- every chunk's window equals the
-    same rows advected redundantly, bit for bit -- is in the line, and a corrupted row is reported there.  --partition
-    contiguous keeps the row blocks and the line exchange."""
+    same rows advected redundantly, bit for bit -- is in the line, and a corrupted row is reported there.  The default
+    (measured faster at 8 ranks: profiles/r06/shard_costs_*.jsonl) stays the row blocks and the line exchange."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(LCS_BENCH_BACKEND="gloo", LCS_BENCH_ONE_GPU="1")
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "c4",
@@ -116,7 +116,7 @@ def test_bench_two_ranks_strong_scaling_takes_the_interleaved_chunks():
         r = subprocess.run(base + list(extra), capture_output=True, text=True, timeout=900, cwd=ROOT, env={**env, **more})
         assert r.returncode == 0, r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1]), r.stderr
-    d, _ = run()
+    d, _ = run(["--partition", "interleaved"])
     hc = d["halo_check"]
     from tests._multiproc import judge_halo_check
     judge_halo_check(hc)
@@ -124,10 +124,10 @@ def test_bench_two_ranks_strong_scaling_takes_the_interleaved_chunks():
     assert d["config"]["partition"].startswith("interleaved") and "interleaved chunks" in d["config"]["workload"]
     assert d["per_rank"][0]["rows"] == [[0, 256], [512, 768]] and d["per_rank"][1]["rows"] == [[256, 512], [768, 1024]]
     assert abs(d["value"] - 1024 * 1024 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
-    d2, err = run(LCS_BENCH_CORRUPT_HALO_CHECK="1")
+    d2, err = run(["--partition", "interleaved"], LCS_BENCH_CORRUPT_HALO_CHECK="1")
     m = d2["halo_check"]["mismatch_rank0"]
     assert d2["halo_check"]["timed_path_ok"] is False and m["n_seeds"] == 1 and m["window_rows"] == [3] and "halo check failed" in err
-    d3, _ = run(["--partition", "contiguous"])
+    d3, _ = run()                                         # the default: contiguous row blocks + the line exchange
     assert d3["halo_check"]["timed_path"] == "torch.distributed" and d3["per_rank"][1]["rows"] == [512, 1024]
 
 

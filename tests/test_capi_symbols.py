@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.lc_version() == 103
+    assert lib.lc_version() == 104 == _capi.LC_VERSION
     assert isinstance(lib.lc_last_error(), bytes)
 
 

@@ -1156,6 +1156,39 @@ def test_lcs_host_float32_route(eng):
         assert np.array_equal(out["sigma"], _np(r["sigma"]))
 
 
+@pytest.mark.parametrize("dtype,order", [(np.float32, 1), (np.float32, 3), (np.float64, 1), (np.float64, 3)])
+def test_lcs_host_pipelined_route_is_bit_identical_to_the_serial_route(eng, dtype, order):
+    """lc_ctx_set_host_pipeline (the default of the one-call host route since round 6): the wind travels through the pinned
+    staging ring in level chunks and the pack + advect kernels of chunk c run while chunk c + 1 is on the bus (44 levels here:
+    three chunks); a sub-range of the series moves only its own levels.  Bit-identical to the serial route (plain copies of the
+    whole series, one pack, one advect) and to the engine's, departure points and sigma; a series too short to pipeline, the
+    per-point clamp and trajectories (serial forms over the staged copies) too."""
+    from lagrangiancoherence_amd.engine import lcs_host
+    u, v, lat, lon = flows.era5_like(nt=44, ny=72, nx=144)
+    slat, slon = flows.seed_grid(90, 130, lat, lon)
+    u, v, lat, lon, slat, slon = (a.astype(dtype) for a in (u, v, lat, lon, slat, slon))
+    kw = dict(SETTLS_order=4, interp_order=order, cyclic_xboundary=True, seed_lat=slat, seed_lon=slon, float64_fidelity="fast")
+    a = lcs_host(u, v, lat, lon, -900.0, **kw)
+    b = lcs_host(u, v, lat, lon, -900.0, pipeline=False, **kw)
+    f = eng.prepare_field(u, v, lat, lon, order)
+    r = eng.lcs(f, slat, slon, -900.0, SETTLS_order=4, interp_order=order)
+    for k in ("x_dep", "y_dep", "sigma"):
+        assert a[k].dtype == dtype and np.array_equal(a[k], b[k]) and np.array_equal(a[k], _np(r[k])), k
+    assert np.isfinite(a["sigma"]).all()
+    # levels 5 .. 40 of the series (35 steps: pipelined, two chunks and a short one) and 7 .. 12 (serial, those levels only)
+    for t0, n in ((5, 35), (7, 5)):
+        a = lcs_host(u, v, lat, lon, -900.0, t0=t0, nsteps=n, **kw)
+        b = lcs_host(u, v, lat, lon, -900.0, t0=t0, nsteps=n, pipeline=False, **kw)
+        r = eng.lcs(f, slat, slon, -900.0, SETTLS_order=4, interp_order=order, t0=t0, nsteps=n)
+        for k in ("x_dep", "y_dep", "sigma"):
+            assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], _np(r[k])), (t0, n, k)
+    # trajectories and the per-point clamp: serial kernels, staged copies
+    kw2 = dict(kw, cyclic_xboundary=False, noncyclic_clamp="pointwise", return_traj=True)
+    a, b = lcs_host(u, v, lat, lon, -900.0, **kw2), lcs_host(u, v, lat, lon, -900.0, pipeline=False, **kw2)
+    for k in ("x_dep", "sigma", "traj_x", "traj_y"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
 @pytest.mark.parametrize("order", [1, 3])
 def test_float64_fused_levels_option(eng, O, order):
     """float64 default (fuse_levels=True): one sample of 2F[t]-F[t+1] per SETTLS iteration, index map by multiplication,

@@ -37,3 +37,9 @@ r = np.array(list(redo), dtype=np.float64).reshape(3, 3, 3)
 print("share of iteration wave-samples with a redo (rows: |lat| 0-30, 30-60, 60-90; columns: first / middle / last third of the levels)")
 print(np.round(100 * r[:, :, 1] / np.maximum(r[:, :, 0], 1), 1))
 print("share of seed-samples redone"); print(np.round(100 * r[:, :, 2] / np.maximum(r[:, :, 0] * 128, 1), 2))
+
+hist = (C.c_ulonglong * 10)()
+if hasattr(lib, "lc_debug_read_hist") and lib.lc_debug_read_hist(hist, 1) == 0:
+    h = np.array(list(hist), dtype=np.float64).reshape(2, 5)
+    print("wave-levels by the number of their 4 iterations with a redo (0..4):", np.round(100 * h[0] / max(h[0].sum(), 1), 1), "%")
+    print("... of the wave-levels whose previous level had >= 3 (%.1f %% of all):" % (100 * h[1].sum() / max(h[0].sum(), 1)), np.round(100 * h[1] / max(h[1].sum(), 1), 1), "%")
