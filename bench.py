@@ -707,6 +707,41 @@ def config1_dropin(flows, with_oracle: bool, reps: int = 5):
     return out
 
 
+def host_route_case(u, v, lat, lon, slat, slon, dt, K, order, nsteps, device, reps: int = 3):
+    """The headline workload through the ONE-CALL HOST ROUTE, `lc_lcs_host`: numpy arrays in, numpy arrays out -- what a
+    reference-side binding calls in place of LCS/LCS.py:129-157.  Never `value`: the wind crosses PCIe in
+    every call.  Median wall time of the Python call over `reps` calls after one warm-up (every call's results kept alive: freeing
+    200 MB is not the route's time), the C side's own marks of the median call, and the same call with the serial round-5
+    form (plain copies of the whole series, then the kernels) beside it."""
+    from lagrangiancoherence_amd.engine import lcs_host
+    ny, nx = len(slat), len(slon)
+    up_bytes, down_bytes = 2 * (nsteps + 1) * u.shape[1] * u.shape[2] * u.itemsize, 3 * ny * nx * u.itemsize
+
+    def timed(pipeline):
+        keep, ts = [], []
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            keep.append(lcs_host(u, v, lat, lon, dt, SETTLS_order=K, interp_order=order, cyclic_xboundary=True, seed_lat=slat, seed_lon=slon,
+                                 pipeline=pipeline))
+            ts.append((time.perf_counter() - t0) * 1e3)
+        i = 1 + int(np.argsort(ts[1:])[len(ts[1:]) // 2])
+        return ts[i], keep[i]["host_marks_ms"], ts
+    ms, marks, all_ms = timed(True)
+    ms0, _, _ = timed(False)
+    pts = ny * nx * nsteps
+    return {"value": pts / (ms / 1e3), "unit": "particle-timesteps/s", "ms_per_call": ms, "calls_ms": [round(t, 2) for t in all_ms],
+            "upload_MB": up_bytes / 1e6, "download_MB": down_bytes / 1e6,
+            "marks_ms": {k: round(x, 2) for k, x in marks.items()},
+            "split_ms": {"upload (bus-bound; pack + advect of level chunk c run under the upload of chunk c + 1)": round(marks["uploads_and_launches_issued"], 2),
+                         "kernels after the last upload": round(marks["kernels_done"] - marks["uploads_and_launches_issued"], 2),
+                         "download": round(marks["results_down"] - marks["kernels_done"], 2),
+                         "free + return": round(ms - marks["results_down"], 2)},
+            "upload_GBps": up_bytes / 1e6 / marks["uploads_and_launches_issued"] if marks["uploads_and_launches_issued"] > 0 else None,
+            "serial_form_ms_per_call": ms0, "serial_form_value": pts / (ms0 / 1e3),
+            "note": "lc_lcs_host: pageable numpy arrays in and out; staged through a pinned ring by host threads, upload cut into level "
+                    "chunks and overlapped with the kernels (lc_ctx_set_host_pipeline, the default); PCIe-inclusive, never `value`"}
+
+
 def run_c2(args, torch, flows, Engine, local_rank, csrc):
     """BASELINE configs[1] on one GPU (a parity config; reported for the float64 path's rate)."""
     K, order = args.settls, args.order
@@ -1347,6 +1382,11 @@ def main():
         del sig, x_ext, y_ext, field          # the headline's outputs: the secondary cases reuse the memory
         torch.cuda.empty_cache()
         out["secondary"] = secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dlat, dlon)
+        try:
+            torch.cuda.empty_cache()
+            out["secondary"]["c3 host route"] = host_route_case(u, v, lat, lon, slat, slon, dt, K, order, nsteps, local_rank)
+        except Exception as exc:
+            out["secondary"]["c3 host route"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         try:
             out["secondary"]["c1 through the drop-in"] = config1_dropin(flows, not args.no_cpu_baseline)
         except Exception as exc:

@@ -86,6 +86,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->trunc = nullptr;
     c->xfer = nullptr;
     c->host_timing = getenv("LCS_HOST_TIMING") != nullptr;
+    for (double &m : c->host_marks) m = 0.0;
     c->host_pipeline = 1;
     if (const char *ev = getenv("LCS_HOST_PIPELINE")) c->host_pipeline = ev[0] != '0';  // read once, here
     *out = c;
@@ -124,6 +125,12 @@ extern "C" int lc_ctx_set_host_pipeline(lc_ctx *ctx, int on) {
     LC_REQUIRE(ctx, "lc_ctx_set_host_pipeline: null context");
     LC_REQUIRE(on == 0 || on == 1, "lc_ctx_set_host_pipeline: 0 or 1");
     ctx->host_pipeline = on;
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_last_host_marks(const lc_ctx *ctx, double *ms4_out) {
+    LC_REQUIRE(ctx && ms4_out, "lc_ctx_last_host_marks: null pointer");
+    for (int i = 0; i < 4; ++i) ms4_out[i] = ctx->host_marks[i];
     return LC_OK;
 }
 
@@ -518,6 +525,14 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     const auto t_enter = std::chrono::steady_clock::now();
     auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(); };
     double t_alloc = 0, t_up = 0, t_kernels = 0;
+    struct ExitMark {  // (declared before the buffers: runs after they have been freed)
+        const std::chrono::steady_clock::time_point t0;
+        bool on;
+        ~ExitMark() {
+            if (on) std::fprintf(stderr, "lc_lcs_host: device buffers freed, returning at %.2f ms\n",
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    } exit_mark{t_enter, ctx->host_timing != 0};
     DevBuf u, v, lin, cub, ext, slat, slon, x, y, tx, ty, sig, gx, gy, gtmp;
     LC_TRY(u.alloc(fbytes));
     LC_TRY(v.alloc(fbytes));
@@ -614,8 +629,12 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     // Serial form (one upload of the used levels, one pack, one advect): the reference's non-cyclic outer-product clamp (it
     // restarts the series), trajectories, the exact-order float64 form, orders other than 1 / 3, short series.
     const size_t lvl_bytes = (size_t)ny_f * nx_f * es, le = lc_packed_elems(1, ny_f, nx_f);
-    const int PIPE_LEVELS = 16;
+    // Chunk lengths HALVE towards the end of the series (96 steps: 32, 24, 16, 12, 8, 4): what is left to compute when the last
+    // upload lands is the last chunk alone, so it is the shortest; a chunk's kernels (0.07 ms per level on configs[2]) are done
+    // well before the next, at least half as long, has travelled (0.14 ms per level).
+    const int PIPE_LEVELS = 16, PIPE_LAST = 4;
     const bool piped = hx && cyclic_x == LC_X_CYCLIC && ext.p && !traj_x && nsteps >= 2 * PIPE_LEVELS;
+    auto chunk_len = [&](int left) { return left <= PIPE_LAST ? left : std::max(PIPE_LAST, (left / 3 + 3) / 4 * 4); };
     auto pack_levels = [&](int l0, int nlev) -> int {  // images of wind levels [l0, l0 + nlev), ext of [l0, l0 + nlev - 1)
         const char *ul = (const char *)u.p + (size_t)l0 * lvl_bytes, *vl = (const char *)v.p + (size_t)l0 * lvl_bytes;
         void *el = ext.p ? (char *)ext.p + (size_t)l0 * le * es : nullptr;
@@ -627,8 +646,9 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
         return LC_OK;
     };
     if (piped) {
-        for (int s0 = 0; s0 < nsteps; s0 += PIPE_LEVELS) {
-            const int s1 = std::min(nsteps, s0 + PIPE_LEVELS), first = t0 + s0 + (s0 ? 1 : 0), last = t0 + s1;
+        for (int s0 = 0, s1; s0 < nsteps; s0 = s1) {
+            s1 = s0 + chunk_len(nsteps - s0);
+            const int first = t0 + s0 + (s0 ? 1 : 0), last = t0 + s1;
             LC_TRY(up((char *)u.p + (size_t)first * lvl_bytes, (const char *)u_host + (size_t)first * lvl_bytes, (size_t)(last - first + 1) * lvl_bytes));
             LC_TRY(up((char *)v.p + (size_t)first * lvl_bytes, (const char *)v_host + (size_t)first * lvl_bytes, (size_t)(last - first + 1) * lvl_bytes));
             LC_HIP_CHECK(hipEventRecord(ev_up, hx->copy));
@@ -703,19 +723,29 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
         LC_HIP_CHECK(hipEventRecord(ev_done, st));
         LC_HIP_CHECK(hipStreamWaitEvent(hx->copy, ev_done, 0));
         touch.join();
-        if (ctx->host_timing) {
-            LC_HIP_CHECK(hipEventSynchronize(ev_done));
-            t_kernels = ms_since();
+        LC_HIP_CHECK(hipEventSynchronize(ev_done));   // (the first download DMA waits for this event anyway: the host has nothing else to do)
+        t_kernels = ms_since();
+    }
+    {
+        std::vector<lc_host_xfer::Range> res;
+        if (x_out) res.push_back({x_out, x.p, sbytes});
+        if (y_out) res.push_back({y_out, y.p, sbytes});
+        if (sigma_out) res.push_back({sigma_out, sig.p, sbytes});
+        if (traj_x) {
+            res.push_back({traj_x, tx.p, sbytes * (size_t)(nsteps + 1)});
+            res.push_back({traj_y, ty.p, sbytes * (size_t)(nsteps + 1)});
+        }
+        if (hx) {
+            LC_HIP_CHECK(hx->download(res));   // one pipelined sequence of pieces over all of them
+        } else {
+            for (auto &r : res) LC_TRY(down(r.host, r.dev, r.bytes));
         }
     }
-    if (x_out) LC_TRY(down(x_out, x.p, sbytes));
-    if (y_out) LC_TRY(down(y_out, y.p, sbytes));
-    if (sigma_out) LC_TRY(down(sigma_out, sig.p, sbytes));
-    if (traj_x) {
-        LC_TRY(down(traj_x, tx.p, sbytes * (size_t)(nsteps + 1)));
-        LC_TRY(down(traj_y, ty.p, sbytes * (size_t)(nsteps + 1)));
-    }
     LC_HIP_CHECK(hipStreamSynchronize(st));
+    ctx->host_marks[0] = t_alloc;
+    ctx->host_marks[1] = t_up;
+    ctx->host_marks[2] = hx ? t_kernels : 0.0;
+    ctx->host_marks[3] = ms_since();
     if (ctx->host_timing)
         std::fprintf(stderr, "lc_lcs_host: %s, buffers allocated %.2f ms, uploads and launches issued %.2f, kernels done %.2f, results down %.2f\n",
                      piped ? "pipelined" : (hx ? "staged" : "plain copies"), t_alloc, t_up, t_kernels, ms_since());

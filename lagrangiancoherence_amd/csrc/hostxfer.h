@@ -103,7 +103,9 @@ struct lc_host_xfer {
             return nullptr;
         }
         unsigned hw = std::thread::hardware_concurrency();
-        const int nw = hw >= 8 ? 3 : (hw >= 4 ? 1 : 0);  // + the calling thread: 2 threads already reach the bus rate
+        // + the calling thread.  Two threads already feed the bus on the way up (the DMA of piece k hides behind the copy of
+        // k + 1); the way down ends with the copy-out of the last pieces, which is as fast as the threads are many
+        const int nw = hw >= 16 ? 7 : (hw >= 8 ? 3 : (hw >= 4 ? 1 : 0));
         x->slices.resize((size_t)nw);
         try {
             for (int i = 0; i < nw; ++i) x->workers.emplace_back(&lc_host_xfer::worker, x, i);
@@ -153,14 +155,29 @@ struct lc_host_xfer {
         return hipSuccess;
     }
 
-    // device -> host (after everything enqueued on `copy` so far); returns when the bytes are in `host`
-    hipError_t download(void *host, const void *dev, size_t bytes) {
-        const size_t np = (bytes + piece - 1) / piece;
+    // device -> host (after everything enqueued on `copy` so far); returns when the bytes are in the host buffers.  Several
+    // buffers go through ONE pipelined sequence of pieces: the DMA of piece k + 1 ... k + RING - 1 runs while the threads copy
+    // piece k out, across buffer boundaries (three 67 MB results one after the other would each pay the ring's fill and drain).
+    struct Range {
+        void *host;
+        const void *dev;
+        size_t bytes;
+    };
+    hipError_t download(const std::vector<Range> &ranges) {
+        struct Piece {
+            char *host;
+            const char *dev;
+            size_t n;
+        };
+        std::vector<Piece> pieces;
+        for (const Range &r : ranges)
+            for (size_t off = 0; off < r.bytes; off += piece)
+                pieces.push_back(Piece{(char *)r.host + off, (const char *)r.dev + off, std::min(piece, r.bytes - off)});
+        const size_t np = pieces.size();
         auto issue = [&](size_t i) -> hipError_t {
             const int s = (int)(i % RING);
-            const size_t off = i * piece, n = std::min(piece, bytes - off);
             // (a slot still feeding an upload's DMA: that DMA is earlier on the same stream, the stream orders them)
-            hipError_t e = hipMemcpyAsync(pin[s], (const char *)dev + off, n, hipMemcpyDeviceToHost, copy);
+            hipError_t e = hipMemcpyAsync(pin[s], pieces[i].dev, pieces[i].n, hipMemcpyDeviceToHost, copy);
             if (e == hipSuccess) e = hipEventRecord(dma_done[s], copy);
             in_flight[s] = e == hipSuccess;
             return e;
@@ -174,8 +191,7 @@ struct lc_host_xfer {
             hipError_t e = hipEventSynchronize(dma_done[s]);
             if (e != hipSuccess) return e;
             in_flight[s] = false;
-            const size_t off = j * piece, n = std::min(piece, bytes - off);
-            parallel_copy((char *)host + off, pin[s], n);
+            parallel_copy(pieces[j].host, pin[s], pieces[j].n);
             if (j + RING < np) {
                 e = issue(j + RING);
                 if (e != hipSuccess) return e;
@@ -184,6 +200,7 @@ struct lc_host_xfer {
         next = 0;
         return hipSuccess;
     }
+    hipError_t download(void *host, const void *dev, size_t bytes) { return download(std::vector<Range>{Range{host, dev, bytes}}); }
 
     // every DMA handed over so far has finished (before device buffers they touch are freed, or after a failure)
     void drain() {

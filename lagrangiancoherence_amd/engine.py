@@ -943,6 +943,10 @@ def lcs_host(u, v, lat_f, lon_f, timestep, SETTLS_order=0, interp_order=3, cycli
             int(t0), nsteps, gs,
             int(bool(fd_fp32_cast)), _LAYOUTS[tensor_layout], p(out.get("sigma")), p(out["x_dep"]), p(out["y_dep"]),
             p(out.get("traj_x")), p(out.get("traj_y"))), lib)
+        marks = (C.c_double * 4)()
+        lib.lc_ctx_last_host_marks(ctx, marks)
+    out["host_marks_ms"] = {"buffers_allocated": marks[0], "uploads_and_launches_issued": marks[1], "kernels_done": marks[2],
+                            "results_down": marks[3]}
     return out
 
 
