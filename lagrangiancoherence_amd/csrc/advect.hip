@@ -3925,7 +3925,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
         lc_set_error("lc_advect: the flag all-reduce of LC_X_CLAMP_REFERENCE_OUTER failed (lc_ctx_set_flag_allreduce callback returned non-zero)");
         return LC_ERCCL;
     };
-    const int chunk = lcplan::level_chunk(ctx->level_chunk, outer, (long long)ny * nx, n_members, K, total);
+    const int chunk = lcplan::level_chunk(ctx->level_chunk, outer, (long long)ny * nx, n_members, K, total, sizeof(T) == 8 && order == 1);
     for (int ci = 0, nci = lcplan::n_chunks(total, chunk); ci < nci; ++ci) {
         const int s0 = lcplan::chunk_first(ci, chunk);
         AdvectArgs<T> C = A;

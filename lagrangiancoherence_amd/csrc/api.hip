@@ -59,7 +59,7 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->xcd_split = -1;  // by the launch's shape (lcplan::xcd_chunk_tiles)
     if (const char *ev = getenv("LCS_XCD_SPLIT")) c->xcd_split = atoi(ev) >= 0 ? atoi(ev) : -1;  // read once, here (0: whole tile rows always)
     c->tile_order = -1;
-    if (const char *ev = getenv("LCS_TILE_ORDER")) c->tile_order = (ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : -1;  // read once, here
+    if (const char *ev = getenv("LCS_TILE_ORDER")) c->tile_order = (ev[0] >= '0' && ev[0] <= '3') ? ev[0] - '0' : -1;  // read once, here
     c->pole_blocks = 1;
     if (const char *ev = getenv("LCS_POLE_BLOCKS")) c->pole_blocks = ev[0] != '0';  // read once, here
     c->fir_prefilter = 1;
@@ -85,6 +85,9 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     c->verify_dev = nullptr;
     c->trunc = nullptr;
     c->xfer = nullptr;
+    c->host_ws = nullptr;
+    c->host_cache = 1;
+    if (const char *ev = getenv("LCS_HOST_CACHE")) c->host_cache = ev[0] != '0';  // read once, here
     c->host_timing = getenv("LCS_HOST_TIMING") != nullptr;
     for (double &m : c->host_marks) m = 0.0;
     c->host_pipeline = 1;
@@ -255,12 +258,15 @@ extern "C" int lc_ctx_last_advect_launches(const lc_ctx *ctx) { return ctx ? ctx
 extern "C" const char *lc_ctx_last_sigma_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_sigma_kernel : ""; }
 extern "C" const char *lc_ctx_last_pack_kernel(const lc_ctx *ctx) { return ctx ? ctx->last_pack_kernel : ""; }
 
+static void host_ws_destroy(lc_ctx *ctx);  // (below, with the one-call host route)
+
 extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
     if (!ctx) return LC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     lc_trunc_cache_free(ctx->trunc);
     lc_host_xfer::destroy(ctx->xfer);
+    host_ws_destroy(ctx);
     if (ctx->verify_dev) (void)hipFree(ctx->verify_dev);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -444,15 +450,63 @@ extern "C" int lc_gaussian_filter(lc_ctx *ctx, const void *in_dev, int dtype, in
 // One-call host entry point (LCS/LCS.py:129-157 on host arrays).
 // ---------------------------------------------------------------------------
 namespace {
+// The one-call host routes' device buffers.  hipMalloc + hipFree of configs[2]'s 2.6 GB cost 1.6 ms of a 21 ms call, every call:
+// a context keeps the buffers of its last call and hands them to the next one that fits them (same shapes: all of them);
+// lc_ctx_trim / lc_ctx_destroy free them.  No buffer is ever shared between two live DevBufs.
+struct HostWorkspace {
+    struct Slot {
+        void *p;
+        size_t bytes;
+    };
+    std::vector<Slot> free_list;
+    static constexpr size_t MAX_KEPT = 24;
+    void *take(size_t bytes) {  // the smallest kept buffer that holds `bytes` without being more than half as large again
+        size_t best = free_list.size();
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].bytes >= bytes && free_list[i].bytes <= bytes + bytes / 2 + (1u << 20) &&
+                (best == free_list.size() || free_list[i].bytes < free_list[best].bytes))
+                best = i;
+        if (best == free_list.size()) return nullptr;
+        void *p = free_list[best].p;
+        free_list[best] = free_list.back();
+        free_list.pop_back();
+        return p;
+    }
+    bool give(void *p, size_t bytes) {
+        if (free_list.size() >= MAX_KEPT) return false;
+        try {
+            free_list.push_back(Slot{p, bytes});
+        } catch (...) {
+            return false;
+        }
+        return true;
+    }
+    void trim() {
+        for (auto &s : free_list) (void)hipFree(s.p);
+        free_list.clear();
+    }
+};
+
 struct DevBuf {
     void *p = nullptr;
+    size_t bytes = 0;
+    HostWorkspace *ws = nullptr;  // NULL: plain hipMalloc / hipFree (lc_lcs_global_host, a context with the cache off)
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (!p) return;
+        if (!(ws && ws->give(p, bytes))) (void)hipFree(p);
     }
-    int alloc(size_t bytes) {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    int alloc(size_t n) {
+        bytes = n ? n : 1;
+        if (ws && (p = ws->take(bytes)) != nullptr) return LC_OK;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess && ws && !ws->free_list.empty()) {  // out of memory with buffers kept for later: let them go, once
+            (void)hipGetLastError();
+            ws->trim();
+            e = hipMalloc(&p, bytes);
+        }
         if (e != hipSuccess) {
-            lc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            lc_set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+            (void)hipGetLastError();
             p = nullptr;
             return e == hipErrorOutOfMemory ? LC_ENOMEM : LC_EHIP;
         }
@@ -460,6 +514,31 @@ struct DevBuf {
     }
 };
 
+}  // namespace
+
+static void host_ws_destroy(lc_ctx *ctx) {
+    if (!ctx->host_ws) return;
+    ((HostWorkspace *)ctx->host_ws)->trim();
+    delete (HostWorkspace *)ctx->host_ws;
+    ctx->host_ws = nullptr;
+}
+
+extern "C" int lc_ctx_trim(lc_ctx *ctx) {
+    LC_REQUIRE(ctx, "lc_ctx_trim: null context");
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->host_ws) ((HostWorkspace *)ctx->host_ws)->trim();
+    return LC_OK;
+}
+
+extern "C" int lc_ctx_set_host_cache(lc_ctx *ctx, int on) {
+    LC_REQUIRE(ctx, "lc_ctx_set_host_cache: null context");
+    LC_REQUIRE(on == 0 || on == 1, "lc_ctx_set_host_cache: 0 or 1");
+    ctx->host_cache = on;
+    if (!on) return lc_ctx_trim(ctx);
+    return LC_OK;
+}
+
+namespace {
 template <typename T>
 void coord_extremes(const void *lat, int n, double *lo, double *hi) {
     const T *p = (const T *)lat;
@@ -534,6 +613,10 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
         }
     } exit_mark{t_enter, ctx->host_timing != 0};
     DevBuf u, v, lin, cub, ext, slat, slon, x, y, tx, ty, sig, gx, gy, gtmp;
+    if (ctx->host_cache) {
+        if (!ctx->host_ws) ctx->host_ws = new (std::nothrow) HostWorkspace;
+        for (DevBuf *b : {&u, &v, &lin, &cub, &ext, &slat, &slon, &x, &y, &tx, &ty, &sig, &gx, &gy, &gtmp}) b->ws = (HostWorkspace *)ctx->host_ws;
+    }
     LC_TRY(u.alloc(fbytes));
     LC_TRY(v.alloc(fbytes));
     const bool need_lin = host_route_needs_lin(dtype, interp_order);

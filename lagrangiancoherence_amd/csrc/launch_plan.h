@@ -24,7 +24,15 @@ LCP_HD int imax(int a, int b) { return a > b ? a : b; }
 // b % 8 is still the XCD).  xcd_chunk = 0: XCD x takes the x-th contiguous eighth of the tiles.  xcd_chunk = C: chunks of
 // C tiles (whole tile rows) go to the XCDs cyclically.  Returns the tile a block works on; a value >= ntiles means the
 // block has no tile (the grid is rounded up).
-// tile_order: 0 as stored; 1 the last tile row first, then 0, 1, 2, ...; 2 from the poles inwards (last, 0, last-1, 1, ...).
+// tile_order: 0 as stored; 1 the last tile row first, then 0, 1, 2, ...; 2 from the poles inwards (last, 0, last-1, 1, ...);
+// 3 eight rows from the top, eight from the bottom, the next eight from the top, ... (snake_row) -- with whole tile rows dealt to
+// the XCDs cyclically, XCD x then holds the x-th row from the top AND the x-th from the bottom: where the rows' cost rises
+// towards ONE end (a row block of a sharded grid: one rank's latitudes) every XCD gets a dear row with a cheap one.  Order 2 is
+// for grids with two dear ends (the whole globe): there order 3 would hand XCD 0 both polar-most rows.
+LCP_HD int snake_row(int dr, int nty) {
+    const int a = dr / XCDS, x = dr - a * XCDS, k = (a >> 1) * XCDS + x;
+    return (a & 1) ? k : nty - 1 - k;
+}
 LCP_HD int tile_of_block(int b, int ntiles, int ntx, int xcd_chunk, int tile_order) {
     const int xcd = b % XCDS, j = b / XCDS;
     if (xcd_chunk <= 0) return xcd * ((ntiles + XCDS - 1) / XCDS) + j;
@@ -32,7 +40,8 @@ LCP_HD int tile_of_block(int b, int ntiles, int ntx, int xcd_chunk, int tile_ord
     const int d = (cj * XCDS + xcd) * xcd_chunk + r;  // position in dispatch order
     if (tile_order && d < ntiles) {
         const int dr = d / ntx, c = d - dr * ntx, nty = ntiles / ntx;
-        const int row = tile_order == 2 ? ((dr & 1) ? (dr >> 1) : nty - 1 - (dr >> 1)) : (dr == 0 ? nty - 1 : dr - 1);
+        const int row = tile_order == 3 ? snake_row(dr, nty)
+                        : tile_order == 2 ? ((dr & 1) ? (dr >> 1) : nty - 1 - (dr >> 1)) : (dr == 0 ? nty - 1 : dr - 1);
         return row * ntx + c;
     }
     return d;
@@ -116,7 +125,11 @@ LCP_HD int pole_row(int k, int lo, int hi, int ny) { return k < lo ? k : ny - hi
 // ---- level chunks ---------------------------------------------------------------------------------------------------------
 // A series of `total` levels runs as consecutive launches of at most `chunk` levels (lc_ctx_set_level_chunk).
 // By SETTLS_order: 32 levels per launch for K >= 3, 64 for K = 2, one launch for K <= 1 (profiles/r03).
-LCP_HD int chunk_for_k(int K) { return K >= 3 ? 32 : (K == 2 ? 64 : 0); }
+// float64 at order 1 with seeds on (or as dense as) the field's nodes -- BASELINE configs[1] -- wants HALF of that: its tiles are
+// fetched for one patch each (nothing to share between workgroups), what a chunk buys is the launch's shorter tail
+// (profiles/r06/level_chunk_sweep.txt: 8 / 12 / 16 / 20 / 24 / 32 levels: 3.02 / 2.94 / 2.91 / 2.92 / 2.95 / 3.09 ms;
+// order 3 and the float32 kernels: flat or best at 32-48).
+LCP_HD int chunk_for_k(int K, bool f64_order1 = false) { return K >= 3 ? (f64_order1 ? 16 : 32) : (K == 2 ? 64 : 0); }
 constexpr long long CHUNK_FROM_SEEDS = 1ll << 18;  // seeds per call from which the default chunks (measured)
 constexpr int OUTER_CHUNK = 16;                    // LC_X_CLAMP_REFERENCE_OUTER: levels between two reads of the clamp flag
 
@@ -126,11 +139,11 @@ constexpr int OUTER_CHUNK = 16;                    // LC_X_CLAMP_REFERENCE_OUTER
 // by the halo rows they advect redundantly): fixed 16 levels unless the caller set a value (which it sets on every rank).
 // It also makes the fused-prefix / exact-suffix split of a sharded run the split of the unsharded run (float32 results
 // stay bit-identical).
-LCP_HD int level_chunk(int ctx_level_chunk, bool outer, long long seeds_local, int n_members, int K, int total) {
+LCP_HD int level_chunk(int ctx_level_chunk, bool outer, long long seeds_local, int n_members, int K, int total, bool f64_order1 = false) {
     const int all = total > 0 ? total : 1;
     if (outer) return ctx_level_chunk > 0 ? ctx_level_chunk : OUTER_CHUNK;
     int want = ctx_level_chunk;
-    if (want < 0) want = seeds_local * (n_members > 1 ? n_members : 1) >= CHUNK_FROM_SEEDS ? chunk_for_k(K) : 0;
+    if (want < 0) want = seeds_local * (n_members > 1 ? n_members : 1) >= CHUNK_FROM_SEEDS ? chunk_for_k(K, f64_order1) : 0;
     return want > 0 ? want : all;
 }
 // Number of launches and the i-th launch's first level / level count.  A call with total = 0 still makes one (empty)

@@ -36,6 +36,8 @@ struct lc_ctx {
     unsigned *verify_dev;  // NULL, or 16 uint32 wave-state counters in device memory (lc_ctx_set_verify)
     lc_trunc_cache *trunc;
     struct lc_host_xfer *xfer;  // NULL until a one-call host route first needs it: the pinned staging ring + its threads (hostxfer.h)
+    void *host_ws;              // lc_lcs_host's device buffers of the last call, kept for the next one (api.hip: HostWorkspace; lc_ctx_trim frees them)
+    int host_cache;             // 1 (default): keep them; 0: hipMalloc / hipFree per call (LCS_HOST_CACHE at creation)
     double host_marks[4];       // the last lc_lcs_host call, ms since its entry: buffers allocated, uploads + launches issued, kernels done, results in the caller's buffers (lc_ctx_last_host_marks)
     int host_timing;            // lc_lcs_host: 1 = one line of wall-clock marks per call on stderr (LCS_HOST_TIMING at creation)
     int host_pipeline;          // lc_lcs_host: 1 (default) staged transfers, upload cut into level chunks and overlapped with pack + advect; 0 the serial round-5 form (LCS_HOST_PIPELINE at creation)

@@ -61,15 +61,18 @@ struct Case {
 // a route run once clean (to count its allocations and copies), then once per allocation / copy with that one failing
 template <typename F>
 static void sweep_failures(lc_ctx *ctx, const char *what, F route) {
+    // (lc_lcs_host keeps its device buffers on the context for the next call: lc_ctx_trim before every count and every run, so
+    //  that each run allocates everything anew and every allocation can be the one that fails)
+    auto live = [&] { lc_ctx_trim(ctx); return fake_hip_live(); };
     fake_hip_reset_counts();
-    const int live0 = fake_hip_live();
+    const int live0 = live();
     CHECK(route() == LC_OK);
-    CHECK(fake_hip_live() == live0);   // (the truncation operators stay cached on the context: counted in live0 from the second run on)
-    const int live1 = fake_hip_live();
+    CHECK(live() == live0);   // (the truncation operators stay cached on the context: counted in live0 from the second run on)
+    const int live1 = live();
     fake_hip_reset_counts();
     CHECK(route() == LC_OK);
     const int n_malloc = fake_hip_mallocs(), n_copy = fake_hip_copies();
-    CHECK(fake_hip_live() == live1 && n_malloc > 0 && n_copy > 0 && fake_hip_launches() > 0);
+    CHECK(live() == live1 && n_malloc > 0 && n_copy > 0 && fake_hip_launches() > 0);
     for (int k = 1; k <= n_malloc; ++k) {
         fake_hip_fail_malloc_at(k);
         const int rc = route();
@@ -78,7 +81,7 @@ static void sweep_failures(lc_ctx *ctx, const char *what, F route) {
             fprintf(stderr, "%s: allocation %d of %d failing gave status %d [%s]\n", what, k, n_malloc, rc, lc_last_error());
             exit(1);
         }
-        if (fake_hip_live() != live1) {
+        if (live() != live1) {
             fprintf(stderr, "%s: allocation %d of %d failing left %d buffers live (%d before) [%s]\n", what, k, n_malloc, fake_hip_live(), live1, lc_last_error());
             exit(1);
         }
@@ -88,14 +91,17 @@ static void sweep_failures(lc_ctx *ctx, const char *what, F route) {
         fake_hip_fail_memcpy_at(k);
         const int rc = route();
         fake_hip_fail_memcpy_at(0);
-        if (rc == LC_OK || fake_hip_live() != live1) {
+        if (rc == LC_OK || live() != live1) {
             fprintf(stderr, "%s: copy %d of %d failing gave status %d, %d buffers live (%d before) [%s]\n", what, k, n_copy, rc, fake_hip_live(), live1, lc_last_error());
             exit(1);
         }
         ++g_checks;
     }
-    CHECK(route() == LC_OK && fake_hip_live() == live1);
+    CHECK(route() == LC_OK && live() == live1);
 }
+
+// buffers allocated right now, not counting what lc_lcs_host keeps on the context for its next call
+#define LIVE_AFTER_TRIM() (lc_ctx_trim(ctx), fake_hip_live())
 
 int main() {
     CHECK(lc_version() == LC_VERSION);
@@ -106,25 +112,42 @@ int main() {
         const int before = fake_hip_live();
         Case<float> w(5, 24, 40, 33, 47);
         fake_hip_fail_host_malloc(1);     // no pinned memory to be had: the route falls back to plain copies and keeps nothing
-        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_live() == before);
+        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && LIVE_AFTER_TRIM() == before);
         fake_hip_fail_host_malloc(0);
-        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_live() == before + 4);   // four pinned pieces
-        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_live() == before + 4);   // ... once
+        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && LIVE_AFTER_TRIM() == before + 4);   // four pinned pieces
+        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && LIVE_AFTER_TRIM() == before + 4);   // ... once
     }
-    const int base = fake_hip_live();
+    {   // the device buffers of a call stay on the context for the next one: the second call of a shape allocates nothing,
+        // lc_ctx_trim returns them, lc_ctx_set_host_cache(0) stops keeping them
+        Case<float> w(5, 24, 40, 33, 47);
+        const int before = LIVE_AFTER_TRIM();
+        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_live() > before);
+        const int kept = fake_hip_live();
+        fake_hip_reset_counts();
+        CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_mallocs() == 0 && fake_hip_live() == kept);
+        CHECK(lc_ctx_trim(ctx) == LC_OK && fake_hip_live() == before && lc_ctx_trim(nullptr) == LC_EINVAL);
+        CHECK(lc_ctx_set_host_cache(ctx, 0) == LC_OK && w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && fake_hip_live() == before);
+        CHECK(lc_ctx_set_host_cache(ctx, 2) == LC_EINVAL && lc_ctx_set_host_cache(ctx, 1) == LC_OK);
+        double marks[4] = {-1, -1, -1, -1};
+        CHECK(lc_ctx_last_host_marks(ctx, marks) == LC_OK && marks[0] >= 0 && marks[3] >= marks[1] && lc_ctx_last_host_marks(ctx, nullptr) == LC_EINVAL);
+        CHECK(lc_ctx_set_host_pipeline(ctx, 0) == LC_OK && w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK);     // plain copies on request
+        CHECK(lc_ctx_set_host_pipeline(ctx, 3) == LC_EINVAL && lc_ctx_set_host_pipeline(ctx, 1) == LC_OK);
+        CHECK(lc_ctx_set_xcd_split(ctx, 8) == LC_OK && lc_ctx_set_xcd_split(ctx, -2) == LC_EINVAL && lc_ctx_set_xcd_split(ctx, -1) == LC_OK);
+    }
+    const int base = LIVE_AFTER_TRIM();
     {
         Case<float> c(5, 24, 40, 33, 47);
         Case<double> d(5, 24, 40, 33, 47);
         for (int order = 1; order <= 3; order += 2)
             for (int cyclic = 0; cyclic <= 2; ++cyclic) {   // LC_X_CLAMP_POINT, LC_X_CYCLIC, LC_X_CLAMP_REFERENCE_OUTER
-                CHECK(c.run(ctx, LC_F32, 4, order, cyclic, 0.0, false) == LC_OK && fake_hip_live() == base);
-                CHECK(d.run(ctx, LC_F64, 2, order, cyclic, 1.5, true) == LC_OK && fake_hip_live() == base);
+                CHECK(c.run(ctx, LC_F32, 4, order, cyclic, 0.0, false) == LC_OK && LIVE_AFTER_TRIM() == base);
+                CHECK(d.run(ctx, LC_F64, 2, order, cyclic, 1.5, true) == LC_OK && LIVE_AFTER_TRIM() == base);
             }
         CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_FAST) == LC_OK && d.run(ctx, LC_F64, 4, 3, 1, 0.0, false) == LC_OK);
         CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_EXACT_ORDER) == LC_OK && d.run(ctx, LC_F64, 4, 1, 1, 0.0, true) == LC_OK);
         CHECK(lc_ctx_set_f64_fidelity(ctx, 7) == LC_EINVAL && lc_ctx_set_f64_fidelity(ctx, LC_F64_AUTO) == LC_OK);
         CHECK(lc_ctx_set_level_chunk(ctx, 2) == LC_OK && c.run(ctx, LC_F32, 4, 1, 1, 0.0, true) == LC_OK);   // several launches per call
-        CHECK(lc_ctx_set_level_chunk(ctx, -1) == LC_OK && fake_hip_live() == base);
+        CHECK(lc_ctx_set_level_chunk(ctx, -1) == LC_OK && LIVE_AFTER_TRIM() == base);
         // refusals: nothing may stay allocated
         CHECK(c.run(ctx, 9, 4, 1, 1, 0.0, false) == LC_EINVAL);
         CHECK(c.run(ctx, LC_F32, -1, 1, 1, 0.0, false) == LC_EINVAL);
@@ -137,7 +160,7 @@ int main() {
                           -900.0, 4, 1, 1, 3, 4, 0.0, 1, 0, c.sigma.data(), nullptr, nullptr, nullptr, nullptr) == LC_EINVAL);   // steps beyond the series
         CHECK(lc_lcs_host(nullptr, c.u.data(), c.v.data(), LC_F32, c.nt, c.ny_f, c.nx_f, c.lat.data(), c.lon.data(), c.slat.data(), c.ny, c.slon.data(), c.nx,
                           -900.0, 4, 1, 1, 0, 4, 0.0, 1, 0, c.sigma.data(), nullptr, nullptr, nullptr, nullptr) == LC_EINVAL);
-        CHECK(fake_hip_live() == base && fake_hip_bad_frees() == 0);
+        CHECK(LIVE_AFTER_TRIM() == base && fake_hip_bad_frees() == 0);
         sweep_failures(ctx, "lc_lcs_host float32 order 1", [&] { return c.run(ctx, LC_F32, 4, 1, 1, 0.0, true); });
         sweep_failures(ctx, "lc_lcs_host float32 order 3 + gauss", [&] { return c.run(ctx, LC_F32, 4, 3, 1, 2.0, false); });
         sweep_failures(ctx, "lc_lcs_host float64 order 3", [&] { return d.run(ctx, LC_F64, 4, 3, 1, 0.0, true); });
@@ -146,7 +169,7 @@ int main() {
         // chunks of 16 levels here), both orders and dtypes, a sub-range of the series, and every allocation / copy of it failing
         Case<float> p(41, 24, 40, 33, 47);
         Case<double> q(41, 24, 40, 33, 47);
-        CHECK(p.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && p.run(ctx, LC_F32, 4, 3, 1, 0.0, false) == LC_OK && fake_hip_live() == base);
+        CHECK(p.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && p.run(ctx, LC_F32, 4, 3, 1, 0.0, false) == LC_OK && LIVE_AFTER_TRIM() == base);
         CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_FAST) == LC_OK && q.run(ctx, LC_F64, 4, 1, 1, 0.0, false) == LC_OK && q.run(ctx, LC_F64, 2, 3, 1, 1.0, false) == LC_OK);
         CHECK(lc_lcs_host(ctx, p.u.data(), p.v.data(), LC_F32, p.nt, p.ny_f, p.nx_f, p.lat.data(), p.lon.data(), p.slat.data(), p.ny, p.slon.data(), p.nx,
                           -900.0, 4, 1, 1, 3, 35, 0.0, 1, 0, p.sigma.data(), p.x.data(), p.y.data(), nullptr, nullptr) == LC_OK);   // levels 3 .. 38 of 41
@@ -154,7 +177,7 @@ int main() {
                           -900.0, 4, 1, 1, 5, 7, 0.0, 1, 0, p.sigma.data(), p.x.data(), p.y.data(), nullptr, nullptr) == LC_OK);    // a short sub-range: serial form, those levels only
         sweep_failures(ctx, "lc_lcs_host float32 order 1, pipelined", [&] { return p.run(ctx, LC_F32, 4, 1, 1, 0.0, false); });
         sweep_failures(ctx, "lc_lcs_host float64 order 3, pipelined", [&] { return q.run(ctx, LC_F64, 4, 3, 1, 0.0, false); });
-        CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_AUTO) == LC_OK && fake_hip_live() == base);
+        CHECK(lc_ctx_set_f64_fidelity(ctx, LC_F64_AUTO) == LC_OK && LIVE_AFTER_TRIM() == base);
     }
     {   // the reference's default global call form: regrid + T20 truncation (operator cache) + the path
         int gy = 0, gx = 0;

@@ -26,9 +26,9 @@ using namespace lcplan;
 static void test_tile_order() {
     long cases = 0;
     for (int ntx = 1; ntx <= 40; ntx += (ntx < 8 ? 1 : 7))
-        for (int nty = 1; nty <= 70; nty += (nty < 10 ? 1 : 9))
+        for (int nty : {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 16, 19, 28, 32, 37, 46, 48, 55, 64})
             for (int rows : {0, 1, 2, 4, 8})
-                for (int order = 0; order <= 2; ++order) {
+                for (int order = 0; order <= 3; ++order) {
                     const int ntiles = ntx * nty, chunk = rows * ntx;
                     const int grid = xcd_grid(ntiles, chunk);
                     CHECK(grid % XCDS == 0 && grid >= ntiles, "grid %d ntiles %d", grid, ntiles);
@@ -54,6 +54,16 @@ static void test_tile_order() {
                     }
                     if (chunk > 0 && order == 1 && nty >= 2)
                         CHECK(tile_of_block(0, ntiles, ntx, chunk, 1) / ntx == nty - 1, "order 1 starts at the last row");
+                    // snake order, whole rows per XCD: XCD x holds the x-th row from the top and the x-th from the bottom, ... --
+                    // the rows of one XCD pair up across the middle of the block (their indices sum to nty - 1 wherever both
+                    // rounds are whole)
+                    if (rows == 1 && order == 3 && nty % (2 * XCDS) == 0)
+                        for (int x = 0; x < XCDS; ++x) {
+                            long sum = 0, n = 0;
+                            for (int r = 0; r < nty; ++r)
+                                if (xcd_of_row[r] == x) sum += r, ++n;
+                            CHECK(n == nty / XCDS && 2 * sum == n * (nty - 1), "snake order: XCD %d holds %ld rows summing to %ld (nty %d)", x, n, sum, nty);
+                        }
                     ++cases;
                 }
     // chunks that are PARTS of a tile row (xcd_chunk_tiles with a split): still one block per tile, and the XCDs' shares of
@@ -61,7 +71,7 @@ static void test_tile_order() {
     for (int ntx = 1; ntx <= 1100; ntx = ntx * 3 + 1)
         for (int nty = 1; nty <= 70; nty += (nty < 20 ? 1 : 7))
             for (int split : {-1, 0, 4, 8})
-                for (int order = 0; order <= 2; ++order) {
+                for (int order = 0; order <= 3; ++order) {
                     const int ntiles = ntx * nty, chunk = xcd_chunk_tiles(ntx, nty, 1, split);
                     CHECK(chunk >= 1 && chunk <= ntx, "chunk %d of a row of %d tiles", chunk, ntx);
                     if (split == 0) CHECK(chunk == ntx, "no split: whole rows");
@@ -174,6 +184,8 @@ static void test_level_chunks() {
     CHECK(level_chunk(-1, false, (1ll << 18) - 1, 1, 4, 200) == 200, "below 2^18 seeds: one launch");
     CHECK(level_chunk(-1, false, 1ll << 18, 1, 4, 200) == 32, "K = 4: 32");
     CHECK(level_chunk(-1, false, 1ll << 18, 1, 3, 200) == 32, "K = 3: 32");
+    CHECK(level_chunk(-1, false, 1ll << 20, 1, 4, 200, true) == 16 && level_chunk(-1, false, 1ll << 20, 1, 2, 200, true) == 64, "float64 at order 1: 16 for K >= 3");
+    CHECK(level_chunk(-1, true, 1ll << 20, 1, 4, 200, true) == 16 && level_chunk(24, false, 1ll << 20, 1, 4, 200, true) == 24, "outer / explicit values do not change");
     CHECK(level_chunk(-1, false, 1ll << 18, 1, 2, 200) == 64, "K = 2: 64");
     CHECK(level_chunk(-1, false, 1ll << 24, 1, 1, 200) == 200, "K = 1: one launch");
     CHECK(level_chunk(-1, false, 1ll << 24, 1, 0, 200) == 200, "K = 0: one launch");
