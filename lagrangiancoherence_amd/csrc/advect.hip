@@ -1405,6 +1405,15 @@ __device__ __forceinline__ void clamp_position_c(const AdvectArgs<float> &A, f2 
     }
 }
 
+// DEFER_X (round 6): the longitude wrap / clamp of trajectory.py:93-97,119-123 is deferred exactly as the latitude clamp
+// already was.  A longitude the reference would touch -- x <= -180 or x >= 180 (cyclic), x < x_min or x > x_max (not) -- maps
+// to an index outside [0, n-1), which the NEXT sample's window test flags by itself, and the exact-redo path starts by
+// applying both clamps to the position it was handed; the level ends with one clamp of each kind (stores, next Euler
+// sample).  Same values as clamping after every update (the clamps are pure functions of the position), one v_cmp + one
+// s_or fewer per sample: 10 VALU and 10 SALU of the 260 / 134 per wave-level.  -DLCS_LDS2_DEFER_X=0 is the round-5 form.
+#ifndef LCS_LDS2_DEFER_X
+#define LCS_LDS2_DEFER_X 1
+#endif
 // Control flow: rocprof shows the VALU (~80 % of issue slots) and the CU's scalar pipe (SALU + branches,
 // ~75 %) saturating together, so the loop is written with ONE rare branch per sample instead of one per
 // special case.  Every lane first runs the common case unconditionally -- coordinate already in
@@ -1463,6 +1472,8 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     constexpr int SLAB1_PITCH = 36;  // floats per slab row (32 + 4)
     __shared__ __attribute__((aligned(16))) float s_slab1[2][2][LINES ? 8 * SLAB1_PITCH : 4];
     const int K = KFIX >= 0 ? KFIX : A.K;  // KFIX: SETTLS_order known at compile time (the iteration loop unrolls)
+    // the longitude wrap / clamp deferred like the latitude clamp (the two-seed kernel's DEFER_X, see there; order 1)
+    constexpr bool DEFER_X = ORDER == 1 && LCS_LDS2_DEFER_X != 0;
     typedef TileGeom<ORDER> G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
     constexpr int WIN = ORDER + 1;  // window edge in nodes
@@ -1608,13 +1619,13 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
                 e = euler_global<ORDER>(lvl, A, t);
             }
             f2 pn = dd * e + p;
-            bad |= x_needs_care(pn.x);
+            if (!DEFER_X) bad |= x_needs_care(pn.x);
             if (bad) {  // exact sequence
                 c0 = index_coords(A, p);
                 t = tap_of(c0);
                 e = euler_global<ORDER>(lvl, A, t);
                 pn = dd * e + p;
-                clamp_position_p(A, pn, ymax_v);
+                if (!DEFER_X) clamp_position_p(A, pn, ymax_v);
             }
             dprev = (pn - p) * sc;  // Euler displacement in index space
             p = pn;
@@ -1636,7 +1647,7 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
             // window origins floor(c) the common case accepts: inside the tile AND in [0, n-2] (no wrap)
             const int sox = ox - WOFF, soy = oy - WOFF;
             const int hx = min(sox + LT_COLS - WIN, A.nx_f - 2), hy = min(soy + LT_ROWS - WIN, A.ny_f - 2);
-            const int lx = max(sox, 0), ly = max(soy, 0);
+            const int lx = max(sox, DEFER_X ? 1 : 0), ly = max(soy, DEFER_X ? 1 : 0);  // (DEFER_X: origin 0 to the exact path, as in the two-seed kernel)
             if (hx >= lx && hy >= ly) {
                 lo_x = lx;
                 lo_y = ly;
@@ -1659,17 +1670,23 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
             bool bad = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
             const f2 ew = window_lds<ORDER, LT_PITCH, VERIFY>(base_addr, pitch_bytes, rx, ry, t, e);  // e + sample of ext[t]
             f2 pn = hd * ew + p;
-            bad |= x_needs_care(pn.x);
+            if (!DEFER_X) bad |= x_needs_care(pn.x);
             if (bad) {  // exact sequence, global gather
                 f2 pc = p;
-                pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
+                if (DEFER_X)
+                    clamp_position_c<CYCLIC>(A, pc, ymax_v);  // the deferred clamps of the previous update (Q7 / Q8 / Q9)
+                else
+                    pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
                 t = tap_of(index_coords(A, pc));
                 pn = hd * window_global<ORDER>(elv, A, t, e) + pc;
-                clamp_position_p(A, pn, ymax_v);
+                if (!DEFER_X) clamp_position_p(A, pn, ymax_v);
             }
             p = pn;
         }
-        p.y = __builtin_amdgcn_fmed3f(p.y, A.y_min, ymax_v);  // the level's one latitude clamp (stores, next Euler sample)
+        if (DEFER_X)
+            clamp_position_c<CYCLIC>(A, p, ymax_v);  // the level's one clamp of either kind (stores, next Euler sample)
+        else
+            p.y = __builtin_amdgcn_fmed3f(p.y, A.y_min, ymax_v);  // the level's one latitude clamp (stores, next Euler sample)
         if constexpr (VERIFY) {
             if (A.verify && K > 0) {
                 // the audit: every lane reads back the 16 bytes it staged for this level, after the last window read
@@ -1813,15 +1830,6 @@ constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byt
 // spills -- C3 measures 6.58-6.73 ms against 6.48-6.52 and config 5 302 against 299 ms: occupancy is not what either lacks.)
 #ifndef LCS_LDS2_MINWAVES
 #define LCS_LDS2_MINWAVES 1
-#endif
-// DEFER_X (round 6): the longitude wrap / clamp of trajectory.py:93-97,119-123 is deferred exactly as the latitude clamp
-// already was.  A longitude the reference would touch -- x <= -180 or x >= 180 (cyclic), x < x_min or x > x_max (not) -- maps
-// to an index outside [0, n-1), which the NEXT sample's window test flags by itself, and the exact-redo path starts by
-// applying both clamps to the position it was handed; the level ends with one clamp of each kind (stores, next Euler
-// sample).  Same values as clamping after every update (the clamps are pure functions of the position), one v_cmp + one
-// s_or fewer per sample: 10 VALU and 10 SALU of the 260 / 134 per wave-level.  -DLCS_LDS2_DEFER_X=0 is the round-5 form.
-#ifndef LCS_LDS2_DEFER_X
-#define LCS_LDS2_DEFER_X 1
 #endif
 // DIRECT LEVELS (round 6).  Which waves leave their tiles is not spread thin: on C3, 77 % of the wave-levels have no redo in
 // any of their four iterations and 17 % have one in ALL four (2.5 / 1.7 / 1.3 % in one / two / three), and a wave that had

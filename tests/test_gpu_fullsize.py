@@ -70,6 +70,31 @@ def test_config3_full_size_subset_vs_oracle(eng, c3, order):
                     (1e-4, 5e-4, 2e-3), interp_order=order)
 
 
+def test_config3_full_size_settls_order_0_subset_vs_oracle(eng, c3):
+    """SETTLS_order = 0 is the LIBRARY default (LCS/trajectory.py:14, LCS/LCS.py:26): one Euler sample per level and nothing to
+    stage a tile for, so configs[2]'s grid goes to the direct-gather kernel -- another code path than the K = 4 anchors above
+    (include/lcs_hip.h).  The same subset-vs-oracle anchor at 4096^2 seeds x 96 steps, the dispatched kernel asserted by name;
+    and K = 1, 2 (the two-seed kernel's run-time-K instance)."""
+    from oracle import lcs_oracle as O
+    from tests._fullsize import positions_check
+    u, v, lat, lon, slat, slon = c3
+    f = eng.prepare_field(u, v, lat, lon, 1)
+    rows, cols = _subset(4096, 40, 1), _subset(4096, 40, 0)
+    for K, kernel in ((0, "advect_kernel_f32<1>"), (1, "advect_lds2_kernel<-1, true, 0>"), (2, "advect_lds2_kernel<-1, true, 0>")):
+        x, y = eng.advect(f, slat, slon, -900.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=True)
+        assert eng.last_advect_kernel() == kernel, (K, eng.last_advect_kernel())
+        xg = x[rows][:, cols].cpu().numpy().astype(np.float64)
+        yg = y[rows][:, cols].cpu().numpy().astype(np.float64)
+        kw = dict(timestep=-900.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=True)
+        x32, y32 = O.parcel_propagation(u, v, lat, lon, seed_lat=slat[rows], seed_lon=slon[cols], **kw)
+        x64, y64 = O.parcel_propagation(u.astype(np.float64), v.astype(np.float64), lat.astype(np.float64),
+                                        lon.astype(np.float64), seed_lat=slat[rows].astype(np.float64),
+                                        seed_lon=slon[cols].astype(np.float64), **kw)
+        # (1 + K) position updates per step instead of 5: the floors scale with the updates made
+        positions_check(eng, f, slat, slon, rows, cols, xg, yg, (x32, y32), (x64, y64), f"C3 K={K}",
+                        (1e-4, 5e-4, 2e-3), interp_order=1, **({"K": K} if K != 4 else {}))
+
+
 def test_config3_sharded_equals_unsharded_full_size(eng, c3):
     u, v, lat, lon, slat, slon = c3
     f = eng.prepare_field(u[:9], v[:9], lat, lon, 1)
