@@ -32,6 +32,12 @@ def _assembly(src: str) -> str:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.run([HIPCC, *FLAGS, "-S", "--cuda-device-only", "-o", out + ".tmp", src], check=True, capture_output=True)
         os.replace(out + ".tmp", out)
+        # one listing per translation unit: the listings of earlier source states go (advect.hip's is 28 MB, and the tree
+        # travels to the GPU box as a snapshot with a size limit)
+        import glob
+        for old in glob.glob(os.path.join(os.path.dirname(out), os.path.basename(src) + ".*.s")):
+            if old != out:
+                os.remove(old)
     return out
 
 
