@@ -38,7 +38,7 @@ extern "C" {
  * client built against 100 must be rebuilt), lc_ctx_get_level_chunk, lc_ctx_set/get_f64_fidelity, lc_advect_ex and
  * lc_sample_raw added, lc_field_pack accepts packed_dev == NULL at order 1 (fused-level image only).  lc_version() returns the value the LIBRARY
  * was built with: compare it with this macro before any other call (tests/c/abi_smoke.c, _capi.load do). */
-#define LC_VERSION 104 /* 0.1.4: + lc_ctx_set_host_pipeline, lc_ctx_set_host_cache, lc_ctx_trim, lc_ctx_last_host_marks, lc_ctx_set_xcd_split (0.1.3: + lc_ctx_last_pack_kernel; 0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify, LC_F64_WIND_F32_LIN32) */
+#define LC_VERSION 104 /* 0.1.4: + lc_ctx_set_host_pipeline, lc_copy_to_device, lc_copy_to_host, lc_ctx_set_host_cache, lc_ctx_trim, lc_ctx_last_host_marks, lc_ctx_set_xcd_split (0.1.3: + lc_ctx_last_pack_kernel; 0.1.2: + lc_ctx_set_verify, lc_ctx_read_verify, LC_F64_WIND_F32_LIN32) */
 
 typedef struct lc_ctx lc_ctx;
 
@@ -177,6 +177,13 @@ int lc_ctx_get_f64_fidelity(const lc_ctx *ctx, int *mode_out);
  *   0            plain hipMemcpyAsync of the whole series on the context's stream, then pack, advect, sigma, copies back.
  * LCS_HOST_PIPELINE (0 / 1) sets the initial value, read ONCE in lc_ctx_create. */
 int lc_ctx_set_host_pipeline(lc_ctx *ctx, int on);
+/* Copies between a caller's ordinary (pageable) host array and device memory through the context's staging ring (see
+ * lc_ctx_set_host_pipeline; plain hipMemcpy with it switched off), ordered with the context's stream: work enqueued on the
+ * stream after lc_copy_to_device sees the data (the source may be reused as soon as the call returns); lc_copy_to_host sees
+ * everything enqueued before it and returns when the bytes are in `host`.  What the Python host moves large arrays with
+ * (numpy -> device tensor, results -> numpy): a first-touch hipMemcpy of pageable memory runs at 12-14 GB/s, these at the bus's 55. */
+int lc_copy_to_device(lc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int lc_copy_to_host(lc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 /* lc_lcs_host keeps the device buffers of its last call on the context (1, the default) and hands them to the next call that
  * fits them: hipMalloc + hipFree of BASELINE configs[2]'s 2.6 GB are 1.6 ms of a 21 ms call.  lc_ctx_trim frees what is kept
  * (device memory returns to the system; the next call allocates again), lc_ctx_destroy does too; 0 = allocate and free per call.

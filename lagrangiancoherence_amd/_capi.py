@@ -40,6 +40,8 @@ PROTOTYPES = {
     "lc_ctx_get_f64_fidelity": (_i, [_vp, C.POINTER(_i)]),
     "lc_ctx_set_host_pipeline": (_i, [_vp, _i]),
     "lc_ctx_last_host_marks": (_i, [_vp, C.POINTER(C.c_double)]),
+    "lc_copy_to_device": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "lc_copy_to_host": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "lc_ctx_set_host_cache": (_i, [_vp, _i]),
     "lc_ctx_trim": (_i, [_vp]),
     "lc_ctx_set_xcd_split": (_i, [_vp, _i]),

@@ -530,6 +530,79 @@ extern "C" int lc_ctx_trim(lc_ctx *ctx) {
     return LC_OK;
 }
 
+// The context's staging ring, created on first use; NULL (and nothing left in HIP's sticky error) when it cannot be had.
+static lc_host_xfer *host_xfer_of(lc_ctx *ctx) {
+    if (!ctx->host_pipeline) return nullptr;
+    if (!ctx->xfer) {
+        hipError_t e = hipSuccess;
+        ctx->xfer = lc_host_xfer::create(&e);
+        if (!ctx->xfer) (void)hipGetLastError();
+    }
+    return ctx->xfer;
+}
+
+// Staged copies between a caller's pageable host array and device memory, ordered with the context's stream: what the Python
+// host (Engine.to_device, the drop-in's results) moves large arrays with -- hipMemcpy from pages the runtime has not pinned
+// before runs at a quarter of the bus rate (hostxfer.h).  to_device: work enqueued on the context's stream after the call sees
+// the data.  to_host: sees everything enqueued on the context's stream before the call; returns when the bytes are in `host`.
+extern "C" int lc_copy_to_device(lc_ctx *ctx, void *dev, const void *host, size_t bytes) {
+    LC_REQUIRE(ctx && (bytes == 0 || (dev && host)), "lc_copy_to_device: null pointer");
+    if (!bytes) return LC_OK;
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    lc_host_xfer *hx = host_xfer_of(ctx);
+    if (!hx) {
+        LC_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // (a pageable source may be reused by the caller at once)
+        return LC_OK;
+    }
+    hipEvent_t ev = nullptr;
+    LC_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    struct Ev {
+        hipEvent_t e;
+        ~Ev() { (void)hipEventDestroy(e); }
+    } guard{ev};
+    LC_HIP_CHECK(hipEventRecord(ev, ctx->stream));            // the destination may still be in use by earlier work of the stream
+    LC_HIP_CHECK(hipStreamWaitEvent(hx->copy, ev, 0));
+    hipError_t e = hx->upload(dev, host, bytes);
+    if (e != hipSuccess) {
+        hx->drain();
+        lc_set_error("lc_copy_to_device: staged upload failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return LC_EHIP;
+    }
+    LC_HIP_CHECK(hipEventRecord(ev, hx->copy));
+    LC_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
+    return LC_OK;
+}
+
+extern "C" int lc_copy_to_host(lc_ctx *ctx, void *host, const void *dev, size_t bytes) {
+    LC_REQUIRE(ctx && (bytes == 0 || (dev && host)), "lc_copy_to_host: null pointer");
+    if (!bytes) return LC_OK;
+    LC_HIP_CHECK(hipSetDevice(ctx->device));
+    lc_host_xfer *hx = host_xfer_of(ctx);
+    if (!hx) {
+        LC_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return LC_OK;
+    }
+    hipEvent_t ev = nullptr;
+    LC_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    struct Ev {
+        hipEvent_t e;
+        ~Ev() { (void)hipEventDestroy(e); }
+    } guard{ev};
+    LC_HIP_CHECK(hipEventRecord(ev, ctx->stream));
+    LC_HIP_CHECK(hipStreamWaitEvent(hx->copy, ev, 0));
+    hipError_t e = hx->download(host, dev, bytes);
+    if (e != hipSuccess) {
+        hx->drain();
+        lc_set_error("lc_copy_to_host: staged download failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return LC_EHIP;
+    }
+    return LC_OK;
+}
+
 extern "C" int lc_ctx_set_host_cache(lc_ctx *ctx, int on) {
     LC_REQUIRE(ctx, "lc_ctx_set_host_cache: null context");
     LC_REQUIRE(on == 0 || on == 1, "lc_ctx_set_host_cache: 0 or 1");
@@ -638,15 +711,7 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     if (sigma_out) LC_TRY(sig.alloc(sbytes));
 
     // ---- transfers: the staging ring (hostxfer.h), or plain hipMemcpyAsync when it cannot be had / is switched off --------
-    lc_host_xfer *hx = nullptr;
-    if (ctx->host_pipeline) {
-        if (!ctx->xfer) {
-            hipError_t e = hipSuccess;
-            ctx->xfer = lc_host_xfer::create(&e);
-            if (!ctx->xfer) (void)hipGetLastError();  // (no pinned memory / stream to be had: the plain copies below)
-        }
-        hx = ctx->xfer;
-    }
+    lc_host_xfer *hx = host_xfer_of(ctx);  // (NULL: switched off, or no pinned memory / stream to be had -- the plain copies below)
     // whatever happens below, no DMA of this call is left running into / out of buffers that are about to be freed
     struct Drain {
         lc_host_xfer *hx;

@@ -101,7 +101,7 @@ def _sorted_tll(da, timedim):
 
 
 def _to_np(t):
-    return t.detach().cpu().numpy()
+    return get_engine().to_host(t)
 
 
 # ---------------------------------------------------------------------------

@@ -269,13 +269,33 @@ class Engine:
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         _capi.check(self.lib.lc_ctx_set_stream(self.ctx, C.c_void_p(s)), self.lib)
 
+    STAGED_COPY_FROM = 8 << 20   # bytes from which host <-> device copies go through the context's pinned staging ring
+
     def to_device(self, a, dtype: np.dtype):
         torch = self.torch
         if isinstance(a, torch.Tensor):
             t = a.to(device=self.device, dtype=getattr(torch, np.dtype(dtype).name))
-        else:
-            t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.device)
-        return t.contiguous()
+            return t.contiguous()
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if a.nbytes >= self.STAGED_COPY_FROM:
+            # a large pageable array (a reanalysis wind series): through the ring of pinned buffers, at the bus rate whatever
+            # state its pages are in (lc_copy_to_device; a first-touch pageable copy runs at a quarter of it)
+            t = torch.empty(a.shape, dtype=getattr(torch, np.dtype(dtype).name), device=self.device)
+            self._use_current_stream()
+            _capi.check(self.lib.lc_copy_to_device(self.ctx, C.c_void_p(t.data_ptr()), a.ctypes.data_as(C.c_void_p), a.nbytes), self.lib)
+            return t
+        return torch.from_numpy(a).to(self.device).contiguous()
+
+    def to_host(self, t) -> np.ndarray:
+        """A device tensor as a numpy array (results of the drop-in surface); large ones through the staging ring."""
+        t = t.detach()
+        if not t.is_cuda or t.numel() * t.element_size() < self.STAGED_COPY_FROM:
+            return t.cpu().numpy()
+        t = t.contiguous()
+        out = np.empty(tuple(t.shape), dtype=np.dtype(str(t.dtype).replace("torch.", "")))
+        self._use_current_stream()
+        _capi.check(self.lib.lc_copy_to_host(self.ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(t.data_ptr()), out.nbytes), self.lib)
+        return out
 
     def _empty(self, shape, dtype):
         t = self.torch.empty(shape, dtype=getattr(self.torch, np.dtype(dtype).name), device=self.device)

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "../../include/lcs_hip.h"
@@ -23,6 +25,9 @@ void fake_hip_fail_malloc_at(int n);
 void fake_hip_fail_memcpy_at(int n);
 void fake_hip_fail_host_malloc(int on);
 void fake_hip_reset_counts(void);
+// "device" memory of the stand-in runtime, for the staged-copy calls (hipError_t is an enum: 0 = success)
+int hipMalloc(void **p, size_t bytes);
+int hipFree(void *p);
 }
 
 static int g_checks = 0;
@@ -133,6 +138,31 @@ int main() {
         CHECK(lc_ctx_set_host_pipeline(ctx, 0) == LC_OK && w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK);     // plain copies on request
         CHECK(lc_ctx_set_host_pipeline(ctx, 3) == LC_EINVAL && lc_ctx_set_host_pipeline(ctx, 1) == LC_OK);
         CHECK(lc_ctx_set_xcd_split(ctx, 8) == LC_OK && lc_ctx_set_xcd_split(ctx, -2) == LC_EINVAL && lc_ctx_set_xcd_split(ctx, -1) == LC_OK);
+    }
+    {   // staged copies on their own (lc_copy_to_device / lc_copy_to_host): sizes below, at and across the ring's 32 MB pieces and
+        // longer than the whole ring; with the ring switched off; refusals; a failing DMA is reported and leaves nothing behind
+        const int before = LIVE_AFTER_TRIM();
+        for (size_t n : {(size_t)1, (size_t)4097, ((size_t)32 << 20), ((size_t)32 << 20) + 13, ((size_t)150 << 20) + 7}) {
+            std::vector<unsigned char> src(n), back(n, 0);
+            for (size_t i = 0; i < n; i += 4093) src[i] = (unsigned char)(i * 31 + 7);
+            src[n - 1] = 0xA5;
+            void *dev = nullptr;
+            CHECK(hipMalloc(&dev, n) == 0);
+            for (int on = 1; on >= 0; --on) {
+                std::fill(back.begin(), back.end(), 0);
+                CHECK(lc_ctx_set_host_pipeline(ctx, on) == LC_OK);
+                CHECK(lc_copy_to_device(ctx, dev, src.data(), n) == LC_OK && lc_copy_to_host(ctx, back.data(), dev, n) == LC_OK);
+                CHECK(std::memcmp(src.data(), back.data(), n) == 0);
+            }
+            CHECK(lc_ctx_set_host_pipeline(ctx, 1) == LC_OK);
+            fake_hip_fail_memcpy_at(2);
+            CHECK(lc_copy_to_device(ctx, dev, src.data(), n) != LC_OK || n <= ((size_t)32 << 20));   // (one piece: one copy, the second never happens)
+            fake_hip_fail_memcpy_at(0);
+            CHECK(lc_copy_to_device(ctx, dev, src.data(), n) == LC_OK);
+            CHECK(hipFree(dev) == 0);
+        }
+        CHECK(lc_copy_to_device(ctx, nullptr, nullptr, 0) == LC_OK && lc_copy_to_device(ctx, nullptr, nullptr, 8) == LC_EINVAL);
+        CHECK(lc_copy_to_host(nullptr, nullptr, nullptr, 8) == LC_EINVAL && LIVE_AFTER_TRIM() == before);
     }
     const int base = LIVE_AFTER_TRIM();
     {

@@ -1189,6 +1189,28 @@ def test_lcs_host_pipelined_route_is_bit_identical_to_the_serial_route(eng, dtyp
         assert np.array_equal(a[k], b[k], equal_nan=True), k
 
 
+def test_large_host_arrays_travel_through_the_staging_ring(eng):
+    """Engine.to_device / to_host move arrays of 8 MB or more through the context's pinned staging ring (lc_copy_to_device /
+    lc_copy_to_host: ordered with the current stream, the source reusable at once) -- the same bytes as torch's own copies, for
+    sizes across the ring's 32 MB pieces and longer than the ring, in both dtypes, with the ring switched off too."""
+    import torch
+    rng = np.random.default_rng(5)
+    for n, dtype in ((3 * 1024 * 1024 + 17, np.float32), (40 * 1024 * 1024 // 8 + 3, np.float64), (150 * 1024 * 1024 // 4 + 1, np.float32)):
+        a = rng.standard_normal(n).astype(dtype)
+        for on in (1, 0):
+            _capi_check = eng.lib.lc_ctx_set_host_pipeline(eng.ctx, on)
+            assert _capi_check == 0
+            t = eng.to_device(a, dtype)
+            a_keep = a.copy()
+            a[:] = 0                                       # the source may be reused as soon as to_device returns
+            assert torch.equal(t, torch.from_numpy(a_keep).to(t.device))
+            t2 = t * 2                                     # work enqueued on the stream after the copy sees the data
+            back = eng.to_host(t2)
+            assert back.dtype == dtype and np.array_equal(back, a_keep * 2)
+            a[:] = a_keep
+    eng.lib.lc_ctx_set_host_pipeline(eng.ctx, 1)
+
+
 @pytest.mark.parametrize("order", [1, 3])
 def test_float64_fused_levels_option(eng, O, order):
     """float64 default (fuse_levels=True): one sample of 2F[t]-F[t+1] per SETTLS iteration, index map by multiplication,
