@@ -28,6 +28,9 @@ class OracleEngine:
     def to_device(self, a, dtype):
         return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=dtype)))
 
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
     fuse_asked = []           # what the adapter asked of prepare_field (float64 fidelity rule of the drop-in surface)
 
     def f64_fuse_levels(self, dtype, n_seeds):
