@@ -856,7 +856,8 @@ def test_float64_order3_coefficients_do_not_depend_on_how_the_launch_cut_the_lev
     ny, nx, nt = 600, 130, 9
     u, v, lat, lon = _rand_field(4242, nt=nt, ny=ny, nx=nx, dtype=np.float64, scale=20.0)
     full = _np(eng.prepare_field(u, v, lat, lon, 3).cub).reshape(-1, ny + 3, nx + 3, 2)[:nt].copy()
-    assert eng.last_pack_kernel() == "prefilter_fused_stream_kernel<double>", eng.last_pack_kernel()
+    if os.environ.get("LCS_FUSED_PREFILTER", "1") != "0":      # (a suite run with the two-sweep fallback forced checks that one: it never cut)
+        assert eng.last_pack_kernel() == "prefilter_fused_stream_kernel<double>", eng.last_pack_kernel()
     assert np.isfinite(full).all()
     for n in (2, 3, 5):
         part = _np(eng.prepare_field(u[:n], v[:n], lat, lon, 3).cub).reshape(-1, ny + 3, nx + 3, 2)[:n]

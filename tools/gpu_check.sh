@@ -1,20 +1,9 @@
 #!/bin/bash
-set -o pipefail
-O=gpurun_out/r6l; mkdir -p $O
-python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/tests.rc; tail -4 $O/tests.log
-python - <<'PY'
-# first-touch upload of a reanalysis-sized series: torch's pageable copy against Engine.to_device (staging ring)
-import time, numpy as np, torch, sys
-sys.path.insert(0, '.')
-from lagrangiancoherence_amd.engine import Engine
-eng = Engine(0)
-for rep in range(3):
-    a = np.random.default_rng(rep).standard_normal((97, 720, 1440)).astype(np.float32)   # fresh pages every time
-    b = a.copy()
-    torch.cuda.synchronize(); t0 = time.perf_counter(); t = torch.from_numpy(a).to("cuda"); torch.cuda.synchronize(); t1 = time.perf_counter()
-    s = eng.to_device(b, np.float32); torch.cuda.synchronize(); t2 = time.perf_counter()
-    assert torch.equal(t, s)
-    r0 = time.perf_counter(); x = t.cpu().numpy(); r1 = time.perf_counter(); y = eng.to_host(s); r2 = time.perf_counter()
-    assert np.array_equal(x, y)
-    print(f"402 MB first touch: torch H2D {1e3*(t1-t0):.1f} ms, staged {1e3*(t2-t1):.1f} ms | torch D2H {1e3*(r1-r0):.1f} ms, staged {1e3*(r2-r1):.1f} ms", flush=True)
-PY
+# The GPU suite on the current build three ways (as at the end of round 5): plain, with every engine allocation NaN-poisoned
+# (LCS_DEBUG_POISON=1: an element a kernel forgot to write cannot look right), and with the round-6 host-side defaults switched
+# off (LCS_HOST_PIPELINE=0 LCS_HOST_CACHE=0: plain copies, allocate / free per call) next to the two-sweep prefilter fallback.
+# usage (on the GPU box): tools/gpu_check.sh <outdir under gpurun_out>
+O=gpurun_out/${1:-check}; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/tests_plain.log 2>&1; echo "plain rc=$?"; tail -2 $O/tests_plain.log
+LCS_DEBUG_POISON=1 python -m pytest tests -m gpu -x -q > $O/tests_poison.log 2>&1; echo "poison rc=$?"; tail -2 $O/tests_poison.log
+LCS_HOST_PIPELINE=0 LCS_HOST_CACHE=0 LCS_FUSED_PREFILTER=0 python -m pytest tests -m gpu -x -q > $O/tests_fallbacks.log 2>&1; echo "fallbacks rc=$?"; tail -2 $O/tests_fallbacks.log
