@@ -276,6 +276,16 @@ class Engine:
         if isinstance(a, torch.Tensor):
             t = a.to(device=self.device, dtype=getattr(torch, np.dtype(dtype).name))
             return t.contiguous()
+        a = np.asarray(a)
+        if a.ndim > 1 and not a.flags.c_contiguous and a.dtype == np.dtype(dtype) and a.nbytes >= self.STAGED_COPY_FROM:
+            # a transposed VIEW of a contiguous array (the reference's example builds u, v with dims (latitude, longitude,
+            # time) and the adapter asks for (time, latitude, longitude): LCS/LCS.py:101-104): making it contiguous on the host
+            # is a strided copy at ~1 GB/s.  The buffer travels as it lies in memory, the permutation runs on the device.
+            order = sorted(range(a.ndim), key=lambda i: -abs(a.strides[i]))
+            base = a.transpose(order)
+            if base.flags.c_contiguous:
+                inv = [order.index(i) for i in range(a.ndim)]
+                return self.to_device(base, dtype).permute(inv).contiguous()
         a = np.ascontiguousarray(a, dtype=dtype)
         if a.nbytes >= self.STAGED_COPY_FROM:
             # a large pageable array (a reanalysis wind series): through the ring of pinned buffers, at the bus rate whatever

@@ -1210,6 +1210,14 @@ def test_large_host_arrays_travel_through_the_staging_ring(eng):
             assert back.dtype == dtype and np.array_equal(back, a_keep * 2)
             a[:] = a_keep
     eng.lib.lc_ctx_set_host_pipeline(eng.ctx, 1)
+    # a transposed view of a contiguous array (the example's (latitude, longitude, time) winds asked for as (time, latitude,
+    # longitude)): the buffer travels as it lies, the permutation runs on the device -- same values, contiguous result
+    base = rng.standard_normal((90, 180, 200)).astype(np.float32)                       # (latitude, longitude, time), 13 MB
+    for view in (base.transpose(2, 0, 1), base.transpose(2, 1, 0), base.transpose(1, 0, 2), base[:, :, ::2].transpose(2, 0, 1)):
+        t = eng.to_device(view, np.float32)
+        assert t.is_contiguous() and tuple(t.shape) == view.shape and np.array_equal(t.cpu().numpy(), view)
+    t64 = eng.to_device(base.transpose(2, 0, 1), np.float64)                             # a dtype change: the ordinary path
+    assert t64.dtype == torch.float64 and np.array_equal(t64.cpu().numpy(), base.transpose(2, 0, 1).astype(np.float64))
 
 
 @pytest.mark.parametrize("order", [1, 3])
