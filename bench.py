@@ -707,6 +707,40 @@ def config1_dropin(flows, with_oracle: bool, reps: int = 5):
     return out
 
 
+def era5_slab_dropin(flows, nt: int = 25, reps: int = 3):
+    """What a reference user with a reanalysis slab sees: `trajectory.parcel_propagation(U, V, timestep=-900, SETTLS_order=4,
+    cyclic_xboundary=True)` -- the reference's default interp_order=3 -- on labelled arrays built the way the reference's example
+    builds them (dims (latitude, longitude, time), examples/ideal_vortex.py:124,203): a 0.25-degree field (720 x 1440 nodes =
+    seeds), `nt` levels, float32 winds on float64 coordinates (numpy's promotion rules: Q10).  Wall time of the Python call:
+    the adapter's sorting and labelling, the upload (the buffer travels as it lies in memory, the transposition runs on the
+    device: Engine.to_device), the float64 coefficient pack, the advection, the results' way back."""
+    import pandas as pd
+    try:
+        import xarray as xr
+        mk = lambda a, name: xr.DataArray(a, dims=['latitude', 'longitude', 'time'], coords=coords, name=name)
+        container = "xarray"
+    except ImportError:
+        from tests import labelled
+        mk = lambda a, name: labelled.DataArray(a, ['latitude', 'longitude', 'time'], coords, name=name)
+        container = "tests/labelled.py stand-in (no xarray in this image)"
+    from LagrangianCoherence.LCS import trajectory
+    u, v, lat, lon = flows.era5_like(nt=nt)
+    coords = {'latitude': lat.astype(np.float64), 'longitude': lon.astype(np.float64),
+              'time': pd.date_range('2000-01-01', periods=nt, freq='15min').values}
+    U, V = mk(np.ascontiguousarray(u.transpose(1, 2, 0)), 'u'), mk(np.ascontiguousarray(v.transpose(1, 2, 0)), 'v')
+    ts, keep = [], []
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        keep.append(trajectory.parcel_propagation(U, V, timestep=-900.0, propdim='time', SETTLS_order=4, cyclic_xboundary=True, verbose=False))
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.median(ts[1:]))
+    n = int(lat.size * lon.size) * (nt - 1)
+    return {"config": f"{lat.size}x{lon.size} nodes = seeds, {nt} levels ({nt - 1} steps of 15 min), float32 wind on float64 coordinates, "
+                      "SETTLS_order 4, interp_order 3 (the reference's default), cyclic; dims (latitude, longitude, time)",
+            "container": container, "parcel_propagation_ms": ms, "calls_ms": [round(t, 2) for t in ts],
+            "particle_timesteps_per_s": n / (ms / 1e3), "input_MB": 2 * u.nbytes / 1e6}
+
+
 def host_route_case(u, v, lat, lon, slat, slon, dt, K, order, nsteps, device, reps: int = 3):
     """The headline workload through the ONE-CALL HOST ROUTE, `lc_lcs_host`: numpy arrays in, numpy arrays out -- what a
     reference-side binding calls in place of LCS/LCS.py:129-157.  Never `value`: the wind crosses PCIe in
@@ -1387,6 +1421,10 @@ def main():
             out["secondary"]["c3 host route"] = host_route_case(u, v, lat, lon, slat, slon, dt, K, order, nsteps, local_rank)
         except Exception as exc:
             out["secondary"]["c3 host route"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        try:
+            out["secondary"]["era5 slab through the drop-in"] = era5_slab_dropin(flows)
+        except Exception as exc:
+            out["secondary"]["era5 slab through the drop-in"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         try:
             out["secondary"]["c1 through the drop-in"] = config1_dropin(flows, not args.no_cpu_baseline)
         except Exception as exc:
