@@ -234,6 +234,27 @@ def test_secondary_workloads_block_of_the_default_run():
     eng.close()
 
 
+def test_host_route_and_drop_in_cases_of_the_default_run():
+    """The default run's reference-facing cases on miniature inputs: the headline through lc_lcs_host (numpy in / out, the
+    pipelined form against the serial one, with the C side's marks), BASELINE configs[0] and a reanalysis-shaped slab through
+    the drop-in surface."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import numpy as np
+    from lagrangiancoherence_amd import flows
+    u, v, lat, lon = flows.era5_like(nt=41, ny=72, nx=144)
+    slat, slon = flows.seed_grid(256, 256, lat, lon)
+    h = bench.host_route_case(u, v, lat, lon, slat, slon, -900.0, 4, 1, 40, 0, reps=2)
+    assert h["value"] > 0 and h["ms_per_call"] > 0 and h["serial_form_ms_per_call"] > 0 and len(h["calls_ms"]) == 3
+    m = h["marks_ms"]
+    assert 0 <= m["buffers_allocated"] <= m["uploads_and_launches_issued"] <= m["kernels_done"] <= m["results_down"] <= h["ms_per_call"] + 1.0
+    assert abs(h["upload_MB"] - 2 * 41 * 72 * 144 * 4 / 1e6) < 1e-9 and abs(h["download_MB"] - 3 * 256 * 256 * 4 / 1e6) < 1e-9
+    c1 = bench.config1_dropin(flows, with_oracle=False, reps=2)
+    assert c1["LCS_call_ms"] > 0 and c1["parcel_propagation_return_traj_ms"] > 0 and "cpu_oracle_lcs_ms" not in c1
+    slab = bench.era5_slab_dropin(flows, nt=4, reps=1)
+    assert slab["parcel_propagation_ms"] > 0 and slab["particle_timesteps_per_s"] > 0 and abs(slab["input_MB"] - 2 * 4 * 720 * 1440 * 4 / 1e6) < 1e-9
+
+
 def test_live_counter_passes_of_the_default_run():
     """What the default one-GPU run adds to `roofline` from its own `rocprofv3 --pmc` child passes (here on a miniature
     workload): the dispatched kernel's HBM-side bytes per launch and its per-unit figures, counters only, no tracing."""
