@@ -1472,8 +1472,8 @@ __global__ void __launch_bounds__(BLOCK, ORDER == 3 ? LCS_O3_MINWAVES : 1)
     constexpr int SLAB1_PITCH = 36;  // floats per slab row (32 + 4)
     __shared__ __attribute__((aligned(16))) float s_slab1[2][2][LINES ? 8 * SLAB1_PITCH : 4];
     const int K = KFIX >= 0 ? KFIX : A.K;  // KFIX: SETTLS_order known at compile time (the iteration loop unrolls)
-    // the longitude wrap / clamp deferred like the latitude clamp (the two-seed kernel's DEFER_X, see there; order 1)
-    constexpr bool DEFER_X = ORDER == 1 && LCS_LDS2_DEFER_X != 0;
+    // the longitude wrap / clamp deferred like the latitude clamp (the two-seed kernel's DEFER_X, see there)
+    constexpr bool DEFER_X = LCS_LDS2_DEFER_X != 0;
     typedef TileGeom<ORDER> G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = G::ROWS, LT_PITCH = G::PITCH;
     constexpr int WIN = ORDER + 1;  // window edge in nodes
@@ -2365,6 +2365,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
     const AdvectArgs<float> A = for_member(A0);
     constexpr int ORDER = 3;
     constexpr bool WIDE = MODE == PATCH_WIDE, LINES = MODE == PATCH_LINES;
+    constexpr bool DEFER_X = LCS_LDS2_DEFER_X != 0;  // the longitude wrap / clamp deferred like the latitude clamp (see the order-1 kernel)
     const int K = KFIX >= 0 ? KFIX : A.K;
     typedef TileGeom<ORDER> G;
     typedef EulerGeom<ORDER> E;
@@ -2440,7 +2441,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
                 bad[q] |= ((unsigned)rx > (unsigned)(hx - lx)) | ((unsigned)ry > (unsigned)(hy - ly)) | (hx < lx) | (hy < ly);
                 e[q] = window_lds<ORDER, E::PITCH>(ebase, epitch_bytes, rx, ry, t0[q], zero);
                 pn[q] = L.dd[q] * e[q] + p[q];
-                bad[q] |= x_needs_care(pn[q].x);
+                if (!DEFER_X) bad[q] |= x_needs_care(pn[q].x);
                 anybad |= bad[q];
             }
         }
@@ -2451,7 +2452,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
                     const TapL t = tap_of(index_coords(A, p[q]));
                     e[q] = euler_global<ORDER>(lvl, A, t);
                     pn[q] = L.dd[q] * e[q] + p[q];
-                    clamp_position_p(A, pn[q], ymax_v);
+                    if (!DEFER_X) clamp_position_p(A, pn[q], ymax_v);
                 }
             }
         }
@@ -2478,7 +2479,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
             __builtin_amdgcn_wave_barrier();
             const int sox = ox - WOFF, soy = oy - WOFF;
             const int hx = min(sox + LT_COLS - WIN, A.nx_f - 2), hy = min(soy + LT_ROWS - WIN, A.ny_f - 2);
-            const int lx = max(sox, 0), ly = max(soy, 0);
+            const int lx = max(sox, DEFER_X ? 1 : 0), ly = max(soy, DEFER_X ? 1 : 0);  // (DEFER_X: origin 0 to the exact path, as at order 1)
             if (hx >= lx && hy >= ly) {
                 lo_x = lx;
                 lo_y = ly;
@@ -2498,7 +2499,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
                 bad[q] = ((unsigned)rx > (unsigned)lim_x) | ((unsigned)ry > (unsigned)lim_y);
                 const f2 ew = window_lds<ORDER, LT_PITCH>(base_addr, pitch_bytes, rx, ry, t, e[q]);  // e + sample of ext[t]
                 pn[q] = L.hd[q] * ew + p[q];
-                bad[q] |= x_needs_care(pn[q].x);
+                if (!DEFER_X) bad[q] |= x_needs_care(pn[q].x);
                 anybad |= bad[q];
             }
             if (anybad) {
@@ -2506,10 +2507,13 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
                 for (int q = 0; q < SPL; ++q) {
                     if (bad[q]) {  // exact sequence, global gather
                         f2 pc = p[q];
-                        pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
+                        if (DEFER_X)
+                            clamp_position_c<CYCLIC>(A, pc, ymax_v);  // the deferred clamps of the previous update (Q7 / Q8 / Q9)
+                        else
+                            pc.y = __builtin_amdgcn_fmed3f(pc.y, A.y_min, ymax_v);  // the deferred clamp (Q8)
                         const TapL t = tap_of(index_coords(A, pc));
                         pn[q] = L.hd[q] * window_global<ORDER>(elv, A, t, e[q]) + pc;
-                        clamp_position_p(A, pn[q], ymax_v);
+                        if (!DEFER_X) clamp_position_p(A, pn[q], ymax_v);
                     }
                 }
             }
@@ -2517,7 +2521,12 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_O3_MINWAVES) advect_lds2_o3_ke
             for (int q = 0; q < SPL; ++q) p[q] = pn[q];
         }
 #pragma unroll
-        for (int q = 0; q < SPL; ++q) p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);  // the level's one latitude clamp
+        for (int q = 0; q < SPL; ++q) {  // the level's one clamp of either kind
+            if (DEFER_X)
+                clamp_position_c<CYCLIC>(A, p[q], ymax_v);
+            else
+                p[q].y = __builtin_amdgcn_fmed3f(p[q].y, A.y_min, ymax_v);
+        }
         L.store_level(A, &s_slab[0][0][0], s);
         lvl += A.level_elems;
         elv += A.level_elems;
