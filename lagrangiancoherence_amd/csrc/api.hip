@@ -92,6 +92,10 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     for (double &m : c->host_marks) m = 0.0;
     c->host_pipeline = 1;
     if (const char *ev = getenv("LCS_HOST_PIPELINE")) c->host_pipeline = ev[0] != '0';  // read once, here
+    c->host_threads = -1;
+    c->host_piece_mb = 0;
+    if (const char *ev = getenv("LCS_HOST_THREADS")) c->host_threads = atoi(ev);
+    if (const char *ev = getenv("LCS_HOST_PIECE_MB")) c->host_piece_mb = std::min(std::max(atoi(ev), 1), 256);
     *out = c;
     return LC_OK;
 }
@@ -265,7 +269,7 @@ extern "C" int lc_ctx_destroy(lc_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     lc_trunc_cache_free(ctx->trunc);
-    lc_host_xfer::destroy(ctx->xfer);
+    lc_host_xfer::release(ctx->xfer);
     host_ws_destroy(ctx);
     if (ctx->verify_dev) (void)hipFree(ctx->verify_dev);
     (void)hipStreamDestroy(ctx->own_stream);
@@ -530,12 +534,12 @@ extern "C" int lc_ctx_trim(lc_ctx *ctx) {
     return LC_OK;
 }
 
-// The context's staging ring, created on first use; NULL (and nothing left in HIP's sticky error) when it cannot be had.
+// The context's staging ring (the device's one ring, shared: hostxfer.h), taken on first use; NULL (and nothing left in HIP's sticky error) when it cannot be had.
 static lc_host_xfer *host_xfer_of(lc_ctx *ctx) {
     if (!ctx->host_pipeline) return nullptr;
     if (!ctx->xfer) {
         hipError_t e = hipSuccess;
-        ctx->xfer = lc_host_xfer::create(&e);
+        ctx->xfer = lc_host_xfer::acquire(ctx->device, &e, ctx->host_threads, (size_t)ctx->host_piece_mb << 20);
         if (!ctx->xfer) (void)hipGetLastError();
     }
     return ctx->xfer;
@@ -555,6 +559,7 @@ extern "C" int lc_copy_to_device(lc_ctx *ctx, void *dev, const void *host, size_
         LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // (a pageable source may be reused by the caller at once)
         return LC_OK;
     }
+    std::lock_guard<std::mutex> ring(hx->use);
     hipEvent_t ev = nullptr;
     LC_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     struct Ev {
@@ -585,6 +590,7 @@ extern "C" int lc_copy_to_host(lc_ctx *ctx, void *host, const void *dev, size_t 
         LC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         return LC_OK;
     }
+    std::lock_guard<std::mutex> ring(hx->use);
     hipEvent_t ev = nullptr;
     LC_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     struct Ev {
@@ -712,6 +718,9 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
 
     // ---- transfers: the staging ring (hostxfer.h), or plain hipMemcpyAsync when it cannot be had / is switched off --------
     lc_host_xfer *hx = host_xfer_of(ctx);  // (NULL: switched off, or no pinned memory / stream to be had -- the plain copies below)
+    // the ring is the device's, shared by every context: this call's until it returns (declared before `drain`: released last)
+    std::unique_lock<std::mutex> ring;
+    if (hx) ring = std::unique_lock<std::mutex>(hx->use);
     // whatever happens below, no DMA of this call is left running into / out of buffers that are about to be freed
     struct Drain {
         lc_host_xfer *hx;

@@ -10,6 +10,12 @@
 // so that the pack and advect kernels of level chunk c run while chunk c + 1 is on the bus (api.hip: lc_lcs_host).
 // Downloads mirror it (DMA into the ring, threads copy out); the pages of the caller's fresh output arrays are touched by a
 // background thread during the upload, so the copy-out does not pay their faults.
+//
+// ONE ring per device and process, shared by every context (acquire / release, `use` held for the length of a transfer
+// sequence).  Measured (profiles/r06/host_route.txt): with two rings alive -- the Engine's context had staged an upload, the
+// one-call route's context then made its own -- the SECOND ring's copy stream moves the same bytes 25 % slower (805 MB up in
+// 18.0 instead of 14.2 ms, whichever context created it second; the first one's stays fast): the runtime gives a process's
+// later copy streams another DMA engine.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -43,6 +49,8 @@ struct lc_host_xfer {
     unsigned long generation = 0;
     int pending = 0;
     bool quit = false;
+    std::mutex use;  // held by the one transfer sequence that is using the ring (slots, `next`, the copy stream's order)
+    int refs = 0, device = -1;
 
     void worker(int id) {
         unsigned long seen = 0;
@@ -86,12 +94,14 @@ struct lc_host_xfer {
     }
 
     // ---- life cycle -------------------------------------------------------------------------------------------------
-    static lc_host_xfer *create(hipError_t *err) {
+    // threads < 0 / piece_bytes == 0: the defaults below (LCS_HOST_THREADS, LCS_HOST_PIECE_MB at context creation: experiments)
+    static lc_host_xfer *create(hipError_t *err, int threads = -1, size_t piece_bytes = 0) {
         lc_host_xfer *x = new (std::nothrow) lc_host_xfer;
         if (!x) {
             *err = hipErrorOutOfMemory;
             return nullptr;
         }
+        if (piece_bytes) x->piece = piece_bytes;
         hipError_t e = hipStreamCreateWithFlags(&x->copy, hipStreamNonBlocking);
         for (int i = 0; i < RING && e == hipSuccess; ++i) {
             e = hipHostMalloc((void **)&x->pin[i], x->piece, hipHostMallocDefault);
@@ -105,7 +115,7 @@ struct lc_host_xfer {
         unsigned hw = std::thread::hardware_concurrency();
         // + the calling thread.  Two threads already feed the bus on the way up (the DMA of piece k hides behind the copy of
         // k + 1); the way down ends with the copy-out of the last pieces, which is as fast as the threads are many
-        const int nw = hw >= 16 ? 7 : (hw >= 8 ? 3 : (hw >= 4 ? 1 : 0));
+        const int nw = threads >= 0 ? std::min(threads, 63) : (hw >= 16 ? 7 : (hw >= 8 ? 3 : (hw >= 4 ? 1 : 0)));
         x->slices.resize((size_t)nw);
         try {
             for (int i = 0; i < nw; ++i) x->workers.emplace_back(&lc_host_xfer::worker, x, i);
@@ -114,6 +124,41 @@ struct lc_host_xfer {
         }
         *err = hipSuccess;
         return x;
+    }
+
+    // the device's ring, created by the first context that asks (that context's thread / piece settings); NULL with *err set
+    // when it cannot be had.  Every acquire is paired with one release; the last one destroys the ring.
+    static constexpr int MAX_DEVICES = 64;
+    static std::mutex &registry_lock() {
+        static std::mutex m;
+        return m;
+    }
+    static lc_host_xfer **registry() {
+        static lc_host_xfer *rings[MAX_DEVICES] = {};
+        return rings;
+    }
+    static lc_host_xfer *acquire(int device, hipError_t *err, int threads = -1, size_t piece_bytes = 0) {
+        *err = hipSuccess;
+        if (device < 0 || device >= MAX_DEVICES) {
+            *err = hipErrorInvalidDevice;
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lk(registry_lock());
+        lc_host_xfer *&slot = registry()[device];
+        if (!slot) {
+            slot = create(err, threads, piece_bytes);
+            if (!slot) return nullptr;
+            slot->device = device;
+        }
+        ++slot->refs;
+        return slot;
+    }
+    static void release(lc_host_xfer *x) {
+        if (!x) return;
+        std::lock_guard<std::mutex> lk(registry_lock());
+        if (--x->refs > 0) return;
+        if (x->device >= 0 && x->device < MAX_DEVICES && registry()[x->device] == x) registry()[x->device] = nullptr;
+        destroy(x);
     }
 
     static void destroy(lc_host_xfer *x) {

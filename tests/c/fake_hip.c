@@ -6,8 +6,10 @@
  * whatever the buffers held: the tests look at status codes and at what was allocated and freed, not at numbers),
  * streams are opaque tokens.  hipMalloc / hipMallocAsync fail with hipErrorOutOfMemory at the call number
  * fake_hip_fail_malloc_at() names, and any copy at fake_hip_fail_memcpy_at(): every early-return path of the host routes
- * is then walked once.  Only what csrc/ *.hip call is here; a new call shows up as an undefined symbol at link time. */
+ * is then walked once.  Callable from several threads at once, as the real runtime is (the books behind one lock, the last error
+ * and the pushed launch configuration per thread).  Only what csrc/ *.hip call is here; a new call shows up as an undefined symbol at link time. */
 #include <hip/hip_runtime_api.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,9 +18,11 @@
 static void *g_live[MAX_LIVE];
 static size_t g_live_bytes[MAX_LIVE];
 static int g_nlive, g_mallocs, g_frees, g_launches, g_copies, g_fail_malloc_at, g_fail_memcpy_at, g_bad_free;
-static hipError_t g_last = hipSuccess;
+static _Thread_local hipError_t g_last = hipSuccess;
+static pthread_mutex_t g_books = PTHREAD_MUTEX_INITIALIZER;
+#define LOCKED(stmt) do { pthread_mutex_lock(&g_books); stmt; pthread_mutex_unlock(&g_books); } while (0)
 
-int fake_hip_live(void) { return g_nlive; }
+int fake_hip_live(void) { int n; LOCKED(n = g_nlive); return n; }
 int fake_hip_mallocs(void) { return g_mallocs; }
 int fake_hip_frees(void) { return g_frees; }
 int fake_hip_launches(void) { return g_launches; }
@@ -29,34 +33,34 @@ void fake_hip_fail_memcpy_at(int n) { g_fail_memcpy_at = n; }
 void fake_hip_reset_counts(void) { g_mallocs = g_frees = g_launches = g_copies = 0; }
 
 static hipError_t do_malloc(void **p, size_t bytes) {
-    ++g_mallocs;
-    if (g_fail_malloc_at > 0 && --g_fail_malloc_at == 0) {
-        *p = NULL;
-        return g_last = hipErrorOutOfMemory;
-    }
-    if (g_nlive == MAX_LIVE) return g_last = hipErrorOutOfMemory;
-    *p = malloc(bytes ? bytes : 1);
+    int refuse;
+    LOCKED(++g_mallocs; refuse = (g_fail_malloc_at > 0 && --g_fail_malloc_at == 0) || g_nlive == MAX_LIVE);
+    *p = refuse ? NULL : malloc(bytes ? bytes : 1);
     if (!*p) return g_last = hipErrorOutOfMemory;
-    g_live[g_nlive] = *p;
-    g_live_bytes[g_nlive++] = bytes;
+    LOCKED(g_live[g_nlive] = *p; g_live_bytes[g_nlive++] = bytes);
     return hipSuccess;
 }
 static hipError_t do_free(void *p) {
     if (!p) return hipSuccess;
-    for (int i = 0; i < g_nlive; ++i)
+    int found = 0;
+    pthread_mutex_lock(&g_books);
+    for (int i = 0; i < g_nlive && !found; ++i)
         if (g_live[i] == p) {
             g_live[i] = g_live[--g_nlive];
             g_live_bytes[i] = g_live_bytes[g_nlive];
             ++g_frees;
-            free(p);
-            return hipSuccess;
+            found = 1;
         }
-    ++g_bad_free; /* not ours, or freed twice */
-    return g_last = hipErrorInvalidValue;
+    if (!found) ++g_bad_free; /* not ours, or freed twice */
+    pthread_mutex_unlock(&g_books);
+    if (!found) return g_last = hipErrorInvalidValue;
+    free(p);
+    return hipSuccess;
 }
 static hipError_t do_copy(void *dst, const void *src, size_t n) {
-    ++g_copies;
-    if (g_fail_memcpy_at > 0 && --g_fail_memcpy_at == 0) return g_last = hipErrorInvalidValue;
+    int refuse;
+    LOCKED(++g_copies; refuse = g_fail_memcpy_at > 0 && --g_fail_memcpy_at == 0);
+    if (refuse) return g_last = hipErrorInvalidValue;
     if (n) memcpy(dst, src, n); /* an overrun of either side is ASan's to catch */
     return hipSuccess;
 }
@@ -94,13 +98,13 @@ hipError_t hipGetLastError(void) { hipError_t e = g_last; g_last = hipSuccess; r
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory (injected)" : "fake HIP error"); }
 hipError_t hipLaunchKernel(const void *f, dim3 grid, dim3 block, void **args, size_t shmem, hipStream_t st) {
     (void)f; (void)args; (void)shmem; (void)st;
-    ++g_launches;
+    LOCKED(++g_launches);
     if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x * block.y * block.z == 0 || block.x * block.y * block.z > 1024 || grid.y > 65535 || grid.z > 65535)
         return g_last = hipErrorInvalidConfiguration; /* what the real runtime refuses */
     return hipSuccess;
 }
 /* what hipcc's host stubs call */
-static struct { dim3 grid, block; size_t shmem; hipStream_t st; } g_cfg;
+static _Thread_local struct { dim3 grid, block; size_t shmem; hipStream_t st; } g_cfg;
 void **__hipRegisterFatBinary(const void *data) { (void)data; static void *h; return &h; }
 void __hipUnregisterFatBinary(void **h) { (void)h; }
 void __hipRegisterFunction(void **h, const void *host, char *dev, const char *name, int tl, void *a, void *b, void *c, void *d, int *e) {

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/lcs_hip.h"
@@ -121,6 +123,41 @@ int main() {
         fake_hip_fail_host_malloc(0);
         CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && LIVE_AFTER_TRIM() == before + 4);   // four pinned pieces
         CHECK(w.run(ctx, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && LIVE_AFTER_TRIM() == before + 4);   // ... once
+        // ONE ring per device, shared by the contexts: a second context's calls pin nothing more, destroying either context
+        // leaves the ring to the other, the last one takes it down (and the next context builds it again)
+        lc_ctx *other = nullptr;
+        CHECK(lc_ctx_create(0, &other) == LC_OK);
+        unsigned char bytes[64] = {1, 2, 3}, back[64] = {0};
+        void *dev = nullptr;
+        CHECK(hipMalloc(&dev, sizeof bytes) == 0);
+        const int with_dev = fake_hip_live();
+        CHECK(w.run(other, LC_F32, 4, 1, 1, 0.0, false) == LC_OK && lc_ctx_trim(other) == LC_OK && fake_hip_live() == with_dev);
+        CHECK(lc_copy_to_device(other, dev, bytes, sizeof bytes) == LC_OK && lc_copy_to_host(ctx, back, dev, sizeof bytes) == LC_OK);
+        CHECK(std::memcmp(bytes, back, sizeof bytes) == 0 && fake_hip_live() == with_dev);
+        CHECK(lc_ctx_destroy(other) == LC_OK && fake_hip_live() == with_dev);                           // the ring stays: `ctx` holds it
+        CHECK(lc_copy_to_host(ctx, back, dev, sizeof bytes) == LC_OK && hipFree(dev) == 0);
+        // ... and two threads, a context each, on that one ring at once: staged copies longer than a piece and the pipelined route
+        // (the ring's `use` lock takes them in turn; ThreadSanitizer watches the slots, the workers and the books)
+        CHECK(lc_ctx_create(0, &other) == LC_OK);
+        std::atomic<int> bad{0};
+        auto hammer = [&](lc_ctx *c, unsigned seed) {
+            const size_t n = ((size_t)40 << 20) + seed;
+            std::vector<unsigned char> src(n), got(n, 0);
+            for (size_t i = 0; i < n; i += 4099) src[i] = (unsigned char)(i * 13 + seed);
+            void *d = nullptr;
+            if (hipMalloc(&d, n) != 0) { ++bad; return; }
+            Case<float> mine(37, 24, 40, 33, 47);
+            for (int rep = 0; rep < 3; ++rep) {
+                if (lc_copy_to_device(c, d, src.data(), n) != LC_OK || lc_copy_to_host(c, got.data(), d, n) != LC_OK) ++bad;
+                if (std::memcmp(src.data(), got.data(), n) != 0) ++bad;
+                if (mine.run(c, LC_F32, 4, 1, 1, 0.0, false) != LC_OK) ++bad;
+            }
+            if (hipFree(d) != 0) ++bad;
+        };
+        std::thread t1(hammer, ctx, 1u), t2(hammer, other, 2u);
+        t1.join();
+        t2.join();
+        CHECK(bad.load() == 0 && lc_ctx_trim(other) == LC_OK && lc_ctx_destroy(other) == LC_OK && LIVE_AFTER_TRIM() == before + 4);
     }
     {   // the device buffers of a call stay on the context for the next one: the second call of a shape allocates nothing,
         // lc_ctx_trim returns them, lc_ctx_set_host_cache(0) stops keeping them
