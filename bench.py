@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 # environment variables that change which kernel runs or how it is launched without changing its name
 KERNEL_KNOBS = ("LCS_LIB", "LCS_LDS_TILES", "LCS_XCD_CHUNK_ROWS", "LCS_TILE_ORDER", "LCS_POLE_BLOCKS", "LCS_FIR_PREFILTER",
                 "LCS_SIGMA_MARCH", "LCS_LEVEL_CHUNK", "LCS_PATCH_MODE", "LCS_ENSEMBLE_CHUNK", "LCS_MEMBER_STREAMS", "LCS_NATIVE_HALO",
-                "LCS_EXT_IMAGE", "LCS_PIPELINE", "LCS_PIPELINE_CHUNK")
+                "LCS_EXT_IMAGE", "LCS_PIPELINE", "LCS_PIPELINE_CHUNK", "LCS_F64_WG_TILE")
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_VECTOR_TFLOPS = 157.3   # same guide: peak FP32 vector

@@ -80,6 +80,7 @@ struct AdvectArgs {
     int patch_mode;              // two-seed kernel: -1 by call (PATCH_LINES with trajectories, else PATCH_TALL), or a Patch value
     int xcd_rows;                // tile rows per XCD chunk (xcd_chunk = xcd_rows * ntx, recomputed when a launcher changes ntx)
     int xcd_split;               // > 0: a chunk is 1 / xcd_split of that (lcplan::xcd_chunk_tiles)
+    int wg64;                    // float64, order 1, fused levels: 1 = one LDS tile per workgroup (advect_wg64_kernel; LCS_F64_WG_TILE at creation)
     int ntx, ntiles;
     int xcd_chunk;  // tiles per chunk of the XCD-cyclic tile order; 0: one contiguous band of tiles per XCD
     int tile_order;  // 0 as stored, 1 last tile row first, 2 from the poles inwards (xcd_tile_id)
@@ -1970,7 +1971,6 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     const unsigned st_next = st_off + (st_col + 2 < LT_COLS ? 16u : 0u);
     // seed 0 of the lane in the patch's middle: row 8 of 16 (tall patches), row 4 of 8 and column 8 of 16 (PATCH_WIDE)
     constexpr int CENTRE = (WIDE || GROUP) ? TILE_W / 2 + TILE_W * 4 : TILE_W / 2 + TILE_W * 7;
-    const f2 zero = {0.0f, 0.0f};
     f2 dprev = {0.0f, 0.0f};
     // member groups: level iterations of this workgroup (a short last group stops with its last member's steps)
     const int nlev = GROUP ? lcplan::group_levels(A.nsteps, A.pair_l0, A.pair_n, A.pair_d, cnt) : A.nsteps;
@@ -2787,8 +2787,7 @@ __device__ __forceinline__ d2 sample_fast64(const double *__restrict__ lvl, cons
 // The same sample with the RAW planes of the level as the source (up = its u plane; lc_advect_ex): the window's rows are
 // two 16-byte loads per plane instead of one 32-byte load of interleaved nodes.  The image's pad node behind the last
 // node holds node n - 2 (mirror); the pair is loaded one node to the left there and swapped -- the same eight numbers.
-__device__ __forceinline__ d2 sample_fast64_raw(const double *__restrict__ up, const AdvectArgs<double> &A, double x, double y) {
-    const Loc64 t = locate_fast64(A, x, y);
+__device__ __forceinline__ void window_fast64_raw(const double *__restrict__ up, const AdvectArgs<double> &A, const Loc64 &t, d4 &a, d4 &b) {
     const double *vp = up + (A.v_raw - A.u_raw);
     const int xa = min(t.x0, A.nx_f - 2), y1 = t.y0 + 1 < A.ny_f ? t.y0 + 1 : A.ny_f - 2;
     const size_t r0 = (size_t)t.y0 * A.nx_f + xa, r1 = (size_t)y1 * A.nx_f + xa;
@@ -2798,8 +2797,13 @@ __device__ __forceinline__ d2 sample_fast64_raw(const double *__restrict__ up, c
     __builtin_memcpy(&u1, up + r1, 16);
     __builtin_memcpy(&v1, vp + r1, 16);
     const bool last = t.x0 > xa;  // x0 == nx_f - 1: window = {node n - 1, node n - 2}
-    const d4 a = last ? (d4){u0.y, v0.y, u0.x, v0.x} : (d4){u0.x, v0.x, u0.y, v0.y};
-    const d4 b = last ? (d4){u1.y, v1.y, u1.x, v1.x} : (d4){u1.x, v1.x, u1.y, v1.y};
+    a = last ? (d4){u0.y, v0.y, u0.x, v0.x} : (d4){u0.x, v0.x, u0.y, v0.y};
+    b = last ? (d4){u1.y, v1.y, u1.x, v1.x} : (d4){u1.x, v1.x, u1.y, v1.y};
+}
+__device__ __forceinline__ d2 sample_fast64_raw(const double *__restrict__ up, const AdvectArgs<double> &A, double x, double y) {
+    const Loc64 t = locate_fast64(A, x, y);
+    d4 a, b;
+    window_fast64_raw(up, A, t, a, b);
     return lerp_fast64(a, b, t.tx, t.ty);
 }
 
@@ -3145,6 +3149,16 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
         for (int k = 0; k < K; ++k) {
             const Loc64 t = locate_fast64(A, x, y);
             const bool in_tile = ((unsigned)(t.x0 - acc_x) <= (unsigned)acc_w) & ((unsigned)(t.y0 - acc_y) <= (unsigned)acc_h);
+#ifdef LCS_STAMPS
+            {   // g_stamps[4]: wave-samples, [5]: those with a lane outside the tile, [6]: lanes outside
+                const unsigned long long m = __ballot(!in_tile);
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&g_stamps[4], 1ull);
+                    atomicAdd(&g_stamps[5], m ? 1ull : 0ull);
+                    atomicAdd(&g_stamps[6], (unsigned long long)__popcll(m));
+                }
+            }
+#endif
             d4 a, b;
             if (in_tile) {
                 const d2 *w = tile + (t.y0 - lo_y) * T64_PITCH + (t.x0 - lo_x);
@@ -3181,6 +3195,288 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS64_MINWAVES)
             x = fma(hdtcx, d.x, x);
             clamp_position_fast64(A, x, y);
         }
+        if (live && A.traj_x) {
+            A.traj_x[(size_t)(s + 1) * plane + idx] = x;
+            A.traj_y[(size_t)(s + 1) * plane + idx] = y;
+        }
+        lvl += lstride;
+        if (!EXTRAW) elv += A.level_elems;
+    }
+    if (live) {
+        A.x_out[idx] = x;
+        A.y_out[idx] = y;
+    }
+}
+
+// float64, order 1, fused levels, ONE tile per WORKGROUP (round 6: the structural attempt the round-5 review allowed one of;
+// LCS_F64_WG_TILE=1 at context creation, off by default -- profiles/r06/c2_wg_tile_ab.txt says why).
+//
+// With seeds = nodes (config 2) the per-wave tile above stages 192 nodes for 64 seeds: 3 nodes per seed, 1.67 x the compulsory
+// bytes from HBM.  Here the four waves sit 2 x 2 (16 x 16 seeds per workgroup) and share one W64_COLS x W64_ROWS-node tile
+// of ext[t] (24 x 20 = 480 nodes: 1.9 per seed, the same +-3.5 / +-1.5 cells of margin around the patch), two tiles
+// alternating by level so that ONE workgroup barrier per level is enough (the tile of level s is written again at level
+// s + 2, which a wave reaches only through the barrier of level s + 1, i.e. after every wave's reads of level s: the scheme
+// of PATCH_LINES' slabs).  The anchor must be the workgroup's: the centre seed's thread predicts it ONE LEVEL AHEAD -- from
+// its position after the Euler step of level s it writes level s + 1's anchor before the barrier of level s (the K iterations
+// that follow move the parcel by about K Euler displacements: trajectory.py:100-120 accumulates) -- so the anchor costs no
+// second barrier.  Same locate / lerp / clamp functions, same fallback for a window outside the tile: bit-identical to
+// advect_lds64_kernel and to the direct kernel whatever the tile holds.
+#ifndef LCS_W64_COLS
+#define LCS_W64_COLS 24
+#endif
+#ifndef LCS_W64_ROWS
+#define LCS_W64_ROWS 20
+#endif
+#ifndef LCS_W64_PITCH
+#define LCS_W64_PITCH (LCS_W64_COLS + 1)
+#endif
+#ifndef LCS_W64_NEXT
+#define LCS_W64_NEXT 1   // raw planes only: keep the level-(t + 1) nodes of the staging as the next level's Euler tile
+#endif
+#ifndef LCS_W64_MINWAVES
+#define LCS_W64_MINWAVES 1
+#endif
+constexpr int W64_COLS = LCS_W64_COLS, W64_ROWS = LCS_W64_ROWS, W64_PITCH = LCS_W64_PITCH, W64_SIDE = 16;  // nodes; seeds per side
+template <int KFIX, bool CYCLIC, int SRC>
+__global__ void __launch_bounds__(BLOCK, LCS_W64_MINWAVES) advect_wg64_kernel(const AdvectArgs<double> A0) {
+#pragma clang fp contract(off)
+    constexpr bool RAW = SRC != SRC_IMAGES, EXTRAW = SRC == SRC_RAW_ALL, NEXT = EXTRAW && LCS_W64_NEXT != 0;
+    constexpr int NODES = W64_COLS * W64_ROWS;
+    const AdvectArgs<double> A = for_member(A0);
+    const int K = KFIX >= 0 ? KFIX : A.K;
+    __shared__ __attribute__((aligned(16))) d2 s_tile[2][W64_ROWS * W64_PITCH];
+    // raw planes only: the nodes of level t + 1 the staging loads anyway (ext = 2 F[t] - F[t+1]) are kept as a tile of their own --
+    // it is the NEXT level's Euler sample's field around where the parcels will be, so that sample is four LDS reads, not four gathers
+    __shared__ __attribute__((aligned(16))) d2 s_next[NEXT ? 2 : 1][NEXT ? W64_ROWS * W64_PITCH : 1];
+    __shared__ int s_anchor[2][2];
+    if (pole_block<double, RAW ? POLE_RAW : POLE_LIN>(A)) return;
+    const int tile_id = xcd_tile_id(A);
+    if (tile_id >= A.ntiles) return;  // whole block
+    const int tyi = tile_id / A.ntx, txi = tile_id - tyi * A.ntx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ix = txi * W64_SIDE + (wave & 1) * 8 + (lane & 7);
+    const int iy = tyi * W64_SIDE + (wave >> 1) * 8 + (lane >> 3);
+    bool live = ix < A.nx && iy < A.ny;
+    if (live) {
+        const int grow = A.row0 + iy;
+        if (grow < A.order || grow >= A.ny_global - A.order) {  // pole rows: generic path (Q3)
+            if (!A.pole_blocks) pole_seed<double, RAW ? POLE_RAW : POLE_LIN>(A, iy, ix);
+            live = false;
+        }
+    }
+    if (!__syncthreads_or(live)) return;  // whole WORKGROUP (every wave meets the level barriers below, seeds or none)
+    const int sx_i = min(ix, A.nx - 1), sy_i = min(iy, A.ny - 1);  // threads without a seed shadow a neighbour; stores masked
+    double x = start_x<double>(A, sy_i, sx_i), y = start_y<double>(A, sy_i, sx_i);
+    const double ys = A.seed_lat[sy_i];
+    const double cx_conv = 180.0 / ((3.141592653589793 * 6371000.0) * fabs(cos((ys * 3.141592653589793) / 180.0)));  // Q5
+    const double dtcx = A.dt * cx_conv, hdtcx = A.half_dt * cx_conv;
+    const size_t idx = live ? (size_t)iy * A.nx + ix : 0, plane = (size_t)A.ny * A.nx;
+    if (live && A.traj_x && !A.traj_skip0) {
+        A.traj_x[idx] = x;
+        A.traj_y[idx] = y;
+    }
+    const size_t lstride = RAW ? A.raw_plane : A.level_elems;
+    const double *lvl = (RAW ? A.u_raw : A.img) + (size_t)A.t0 * lstride;
+    const double *elv = EXTRAW ? nullptr : A.ext + (size_t)A.t0 * A.level_elems;
+    const int pad_cols = A.pitch, pad_rows = A.ny_f + LC_PAD;
+    // staging: thread t holds nodes t, t + 256, ... of the tile in row-major order (raw planes: the node PAIRS 2 t, 2 t + 1, ...:
+    // two neighbours of a plane are one 16-byte load)
+    static_assert(W64_COLS % 2 == 0, "a node pair lies in one tile row");
+    constexpr int PER = EXTRAW ? 2 : 1, NSLOT = (NODES / PER + BLOCK - 1) / BLOCK;
+    int st_row[NSLOT], st_col[NSLOT];
+    bool st_ok[NSLOT];
+#pragma unroll
+    for (int r = 0; r < NSLOT; ++r) {
+        const int n = ((int)threadIdx.x + r * BLOCK) * PER;
+        st_ok[r] = n < NODES;
+        st_row[r] = min(n, NODES - PER) / W64_COLS;
+        st_col[r] = min(n, NODES - PER) % W64_COLS;
+    }
+    int prev_ox = 0, prev_oy = 0;  // ... and its origin (padded)
+    bool has_prev = false;
+    int plo_x = 0, plo_y = 0, pacc_x = 0x40000000, pacc_y = 0x40000000, pacc_w = 0, pacc_h = 0;  // the previous level's tile window
+    const bool anchor_thread = threadIdx.x == 3 * 64;  // seed (8, 8) of the 16 x 16 patch: wave 3's first lane
+    const double kpred = 0.5 * (double)(K > 0 ? K - 1 : 0);
+    auto anchor_of = [&](double cax, double cay, int slot) {
+        s_anchor[slot][0] = (int)floor(fmin(fmax(cax, -4.0), 1.0e9));
+        s_anchor[slot][1] = (int)floor(fmin(fmax(cay, -4.0), 1.0e9));
+    };
+    if (anchor_thread) anchor_of((x - A.lon_min) * A.sx, (y - A.lat_min) * A.sy, 0);
+    __syncthreads();
+    for (int s = 0; s < A.nsteps; ++s) {
+        // ---- 1. the workgroup's anchor for this level (written one level ago), the tile's loads ---------------------
+        int ox = 0, oy = 0;
+        d2 stage[NSLOT * PER], keep[NEXT ? NSLOT * PER : 1];
+        d2 *tile = s_tile[s & 1];
+        if (K > 0) {
+            const int rxm = __builtin_amdgcn_readfirstlane(s_anchor[s & 1][0]);
+            const int rym = __builtin_amdgcn_readfirstlane(s_anchor[s & 1][1]);
+            // the anchor seed is number 8 of 16 per side: its window's origin goes to the tile's middle column / row
+            ox = min(max(rxm + LC_PAD_LO - W64_COLS / 2, 0), pad_cols - W64_COLS);
+            oy = min(max(rym + LC_PAD_LO - W64_ROWS / 2, 0), pad_rows - W64_ROWS);
+            if constexpr (EXTRAW) {
+                // the thread's node pair of levels t and t + 1 from the raw planes: padded (row, column) -> node index, mirrored
+                // where the image has pads (lc_field_pack's rule); 2 F[t] - F[t+1] as the pack forms it; F[t+1] kept
+                const ptrdiff_t dv = A.v_raw - A.u_raw;
+#pragma unroll
+                for (int r = 0; r < NSLOT; ++r) {
+                    int ca = ox + st_col[r] - LC_PAD_LO, cb = ca + 1, cy = oy + st_row[r] - LC_PAD_LO;
+                    ca = ca < 0 ? -ca : (ca > A.nx_f - 1 ? 2 * (A.nx_f - 1) - ca : ca);
+                    cb = cb < 0 ? -cb : (cb > A.nx_f - 1 ? 2 * (A.nx_f - 1) - cb : cb);
+                    cy = cy < 0 ? -cy : (cy > A.ny_f - 1 ? 2 * (A.ny_f - 1) - cy : cy);
+                    const double *row = lvl + (size_t)cy * A.nx_f;
+                    d2 ut, vt, un, vn;
+                    const bool whole = cb == ca + 1;  // (all but the pairs that straddle a mirrored edge)
+                    if (whole) {
+                        __builtin_memcpy(&un, row + A.raw_plane + ca, 16);
+                        __builtin_memcpy(&vn, row + A.raw_plane + dv + ca, 16);
+                    } else {
+                        un = (d2){row[A.raw_plane + ca], row[A.raw_plane + cb]};
+                        vn = (d2){row[A.raw_plane + dv + ca], row[A.raw_plane + dv + cb]};
+                    }
+                    // level t's nodes: the previous level kept them (as ITS level t + 1) where the two tiles overlap -- same padded
+                    // coordinates, same numbers; only the fringe the anchor moved onto comes from memory
+                    const int pr = st_row[r] + (oy - prev_oy), pc = st_col[r] + (ox - prev_ox);
+                    if (NEXT && has_prev && (unsigned)pr < (unsigned)W64_ROWS && pc >= 0 && pc + 1 < W64_COLS) {
+                        const d2 *w = s_next[(s + 1) & 1] + pr * W64_PITCH + pc;
+                        const d2 n0 = w[0], n1 = w[1];
+                        ut = (d2){n0.x, n1.x};
+                        vt = (d2){n0.y, n1.y};
+                    } else if (whole) {
+                        __builtin_memcpy(&ut, row + ca, 16);
+                        __builtin_memcpy(&vt, row + dv + ca, 16);
+                    } else {
+                        ut = (d2){row[ca], row[cb]};
+                        vt = (d2){row[dv + ca], row[dv + cb]};
+                    }
+                    stage[2 * r] = (d2){2.0 * ut.x - un.x, 2.0 * vt.x - vn.x};
+                    stage[2 * r + 1] = (d2){2.0 * ut.y - un.y, 2.0 * vt.y - vn.y};
+                    if constexpr (NEXT) {
+                        keep[2 * r] = (d2){un.x, vn.x};
+                        keep[2 * r + 1] = (d2){un.y, vn.y};
+                    }
+                }
+            } else {
+                const char *src = (const char *)elv + ((size_t)oy * pad_cols + ox) * 16;
+#pragma unroll
+                for (int r = 0; r < NSLOT; ++r)
+                    __builtin_memcpy(&stage[r], src + ((size_t)st_row[r] * pad_cols + st_col[r]) * 16, 16);
+            }
+        }
+        // ---- 2. Euler sample: direct gather; raw planes only: out of the tile of this level's nodes the previous level kept ----
+        const double x0p = x, y0p = y;
+        d2 e;
+        if constexpr (NEXT) {
+            const Loc64 t = locate_fast64(A, x, y);
+            const bool in_prev = ((unsigned)(t.x0 - pacc_x) <= (unsigned)pacc_w) & ((unsigned)(t.y0 - pacc_y) <= (unsigned)pacc_h);
+#ifdef LCS_STAMPS
+            {   // g_cause[0]: Euler wave-samples, [1]: those with a lane outside the kept tile, [2]: lanes outside
+                const unsigned long long m = __ballot(!in_prev);
+                if (lane == 0) {
+                    atomicAdd(&g_cause[0], 1ull);
+                    atomicAdd(&g_cause[1], m ? 1ull : 0ull);
+                    atomicAdd(&g_cause[2], (unsigned long long)__popcll(m));
+                }
+            }
+#endif
+            d4 a, b;
+            if (in_prev) {
+                const d2 *w = s_next[(s + 1) & 1] + (t.y0 - plo_y) * W64_PITCH + (t.x0 - plo_x);
+                const d2 n00 = w[0], n01 = w[1], n10 = w[W64_PITCH], n11 = w[W64_PITCH + 1];
+                a = (d4){n00.x, n00.y, n01.x, n01.y};
+                b = (d4){n10.x, n10.y, n11.x, n11.y};
+            } else {
+                window_fast64_raw(lvl, A, t, a, b);
+            }
+            e = lerp_fast64(a, b, t.tx, t.ty);
+        } else {
+            e = RAW ? sample_fast64_raw(lvl, A, x, y) : sample_fast64(lvl, A, x, y);   // trajectory.py:82-84
+        }
+        y = fma(A.dtcy, e.y, y);                        // :86
+        x = fma(dtcx, e.x, x);                          // :87
+        clamp_position_fast64(A, x, y);                // :89-97
+        // ---- 3. tile into LDS, the next level's anchor, the level's one barrier ---------------------------------------
+        int lo_x = 0, lo_y = 0, acc_x = 0x40000000, acc_y = 0x40000000, acc_w = 0, acc_h = 0;
+        if (K > 0) {
+#pragma unroll
+            for (int r = 0; r < NSLOT; ++r)
+                if (st_ok[r]) {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        tile[st_row[r] * W64_PITCH + st_col[r] + q] = stage[PER * r + q];
+                        if constexpr (NEXT) s_next[s & 1][st_row[r] * W64_PITCH + st_col[r] + q] = keep[PER * r + q];
+                    }
+                }
+            if (anchor_thread) {
+                // level s + 1 starts about K Euler displacements further on; its samples centre (1 + kpred) beyond that
+                const double ahead = (double)K + 1.0 + kpred;
+                anchor_of((x - A.lon_min) * A.sx + (x - x0p) * A.sx * ahead, (y - A.lat_min) * A.sy + (y - y0p) * A.sy * ahead, (s + 1) & 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int sox = ox - LC_PAD_LO, soy = oy - LC_PAD_LO;
+            const int hx = min(sox + W64_COLS - 2, A.nx_f - 2), hy = min(soy + W64_ROWS - 2, A.ny_f - 2);
+            const int lx = max(sox, 0), ly = max(soy, 0);
+            if (hx >= lx && hy >= ly) {
+                lo_x = sox;
+                lo_y = soy;
+                acc_x = lx;
+                acc_y = ly;
+                acc_w = hx - lx;
+                acc_h = hy - ly;
+            }
+        }
+        // ---- 4. K iterations out of LDS ---------------------------------------------------------------------------
+        for (int k = 0; k < K; ++k) {
+            const Loc64 t = locate_fast64(A, x, y);
+            const bool in_tile = ((unsigned)(t.x0 - acc_x) <= (unsigned)acc_w) & ((unsigned)(t.y0 - acc_y) <= (unsigned)acc_h);
+#ifdef LCS_STAMPS
+            {   // g_stamps[4]: wave-samples, [5]: those with a lane outside the tile, [6]: lanes outside
+                const unsigned long long m = __ballot(!in_tile);
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&g_stamps[4], 1ull);
+                    atomicAdd(&g_stamps[5], m ? 1ull : 0ull);
+                    atomicAdd(&g_stamps[6], (unsigned long long)__popcll(m));
+                }
+            }
+#endif
+            d4 a, b;
+            if (in_tile) {
+                const d2 *w = tile + (t.y0 - lo_y) * W64_PITCH + (t.x0 - lo_x);
+                const d2 n00 = w[0], n01 = w[1], n10 = w[W64_PITCH], n11 = w[W64_PITCH + 1];
+                a = (d4){n00.x, n00.y, n01.x, n01.y};
+                b = (d4){n10.x, n10.y, n11.x, n11.y};
+            } else if (EXTRAW) {  // the window left the tile: the same nodes from the raw planes of levels t, t + 1
+                const double *up = lvl, *vp = lvl + (A.v_raw - A.u_raw);
+                const int xa = min(t.x0, A.nx_f - 2), y1 = t.y0 + 1 < A.ny_f ? t.y0 + 1 : A.ny_f - 2;
+                const size_t r0 = (size_t)t.y0 * A.nx_f + xa, r1 = (size_t)y1 * A.nx_f + xa, lp = A.raw_plane;
+                d2 u0, v0, u1, v1, u0n, v0n, u1n, v1n;
+                __builtin_memcpy(&u0, up + r0, 16);
+                __builtin_memcpy(&v0, vp + r0, 16);
+                __builtin_memcpy(&u1, up + r1, 16);
+                __builtin_memcpy(&v1, vp + r1, 16);
+                __builtin_memcpy(&u0n, up + lp + r0, 16);
+                __builtin_memcpy(&v0n, vp + lp + r0, 16);
+                __builtin_memcpy(&u1n, up + lp + r1, 16);
+                __builtin_memcpy(&v1n, vp + lp + r1, 16);
+                u0 = 2.0 * u0 - u0n;
+                v0 = 2.0 * v0 - v0n;
+                u1 = 2.0 * u1 - u1n;
+                v1 = 2.0 * v1 - v1n;
+                const bool last = t.x0 > xa;
+                a = last ? (d4){u0.y, v0.y, u0.x, v0.x} : (d4){u0.x, v0.x, u0.y, v0.y};
+                b = last ? (d4){u1.y, v1.y, u1.x, v1.x} : (d4){u1.x, v1.x, u1.y, v1.y};
+            } else {  // the window left the tile: the same taps from global memory
+                const double *p = elv + ((size_t)(t.y0 + LC_PAD_LO) * A.pitch + (t.x0 + LC_PAD_LO)) * 2;
+                __builtin_memcpy(&a, p, 32);
+                __builtin_memcpy(&b, p + (size_t)A.pitch * 2, 32);
+            }
+            const d2 d = e + lerp_fast64(a, b, t.tx, t.ty);   // e + (2 F[t] - F[t+1])(x, y)
+            y = fma(A.hdtcy, d.y, y);
+            x = fma(hdtcx, d.x, x);
+            clamp_position_fast64(A, x, y);
+        }
+        prev_ox = ox, prev_oy = oy, has_prev = true;
+        plo_x = lo_x, plo_y = lo_y, pacc_x = acc_x, pacc_y = acc_y, pacc_w = acc_w, pacc_h = acc_h;
         if (live && A.traj_x) {
             A.traj_x[(size_t)(s + 1) * plane + idx] = x;
             A.traj_y[(size_t)(s + 1) * plane + idx] = y;
@@ -3439,6 +3735,30 @@ struct Lds64Launch<double> {
     // the wind is float32-valued (numpy promotion path), K = 0, or the field is smaller than a tile
     static const char *launch(const AdvectArgs<double> &A, int grid, hipStream_t st, int mode) {
         if (mode == 0 || A.wind_f32 || A.K == 0 || !(A.ext || A.ext_raw) || A.nx_f + LC_PAD < T64_COLS || A.ny_f + LC_PAD < T64_ROWS) return nullptr;
+        if (A.wg64 && A.nx_f + LC_PAD >= W64_COLS && A.ny_f + LC_PAD >= W64_ROWS) {   // one tile per workgroup (LCS_F64_WG_TILE=1: measured, off by default)
+            AdvectArgs<double> B = A;
+            B.ntx = (A.nx + W64_SIDE - 1) / W64_SIDE;
+            const int nty = (A.ny + W64_SIDE - 1) / W64_SIDE;
+            B.ntiles = B.ntx * nty;
+            B.xcd_chunk = lcplan::xcd_chunk_tiles(B.ntx, nty, A.xcd_rows, A.xcd_split);
+            const int gw = xcd_grid(B.ntiles, B.xcd_chunk) + B.pole_blocks;
+#define LC_WG64(KF, CY, SR, NAME)                                                                                   \
+    {                                                                                                               \
+        hipLaunchKernelGGL((advect_wg64_kernel<KF, CY, SR>), dim3(gw, nmem(B)), dim3(BLOCK), 0, st, B);             \
+        return NAME;                                                                                                \
+    }
+            const int sr = A.ext_raw ? 2 : (A.u_raw ? 1 : 0);
+            if (A.K == 4 && A.cyclic && sr == 2) LC_WG64(4, true, 2, "advect_wg64_kernel<4, true, 2>")
+            if (A.K == 4 && A.cyclic && sr == 1) LC_WG64(4, true, 1, "advect_wg64_kernel<4, true, 1>")
+            if (A.K == 4 && A.cyclic) LC_WG64(4, true, 0, "advect_wg64_kernel<4, true, 0>")
+            if (A.cyclic && sr == 2) LC_WG64(-1, true, 2, "advect_wg64_kernel<-1, true, 2>")
+            if (A.cyclic && sr == 1) LC_WG64(-1, true, 1, "advect_wg64_kernel<-1, true, 1>")
+            if (A.cyclic) LC_WG64(-1, true, 0, "advect_wg64_kernel<-1, true, 0>")
+            if (sr == 2) LC_WG64(-1, false, 2, "advect_wg64_kernel<-1, false, 2>")
+            if (sr == 1) LC_WG64(-1, false, 1, "advect_wg64_kernel<-1, false, 1>")
+            LC_WG64(-1, false, 0, "advect_wg64_kernel<-1, false, 0>")
+#undef LC_WG64
+        }
         // (names as a profiler prints them; the last argument: 0 = lin + ext images, 1 = raw planes for the Euler sample + ext
         // image, 2 = raw planes for both, the fused-level value formed node by node: lc_advect_ex)
 #define LC_LDS64(KF, CY, SR, NAME)                                                                                  \
@@ -3799,6 +4119,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     const int nty = (ny + TILE_H - 1) / TILE_H;
     A.ntiles = A.ntx * nty;
     A.xcd_chunk = lcplan::xcd_chunk_tiles(A.ntx, nty, ctx->xcd_chunk_rows, ctx->xcd_split);
+    A.wg64 = ctx->f64_wg_tile;
     A.tile_order = ctx->tile_order >= 0 ? ctx->tile_order : 1;
     A.tile_order_two_seed = ctx->tile_order >= 0 ? ctx->tile_order : 2;
     {   // leading workgroups for the global pole rows present in this block of seed rows

@@ -92,6 +92,8 @@ extern "C" int lc_ctx_create(int device, lc_ctx **out) {
     for (double &m : c->host_marks) m = 0.0;
     c->host_pipeline = 1;
     if (const char *ev = getenv("LCS_HOST_PIPELINE")) c->host_pipeline = ev[0] != '0';  // read once, here
+    c->f64_wg_tile = 0;
+    if (const char *ev = getenv("LCS_F64_WG_TILE")) c->f64_wg_tile = ev[0] == '1';  // read once, here
     c->host_threads = -1;
     c->host_piece_mb = 0;
     if (const char *ev = getenv("LCS_HOST_THREADS")) c->host_threads = atoi(ev);

@@ -40,6 +40,7 @@ struct lc_ctx {
     int host_cache;             // 1 (default): keep them; 0: hipMalloc / hipFree per call (LCS_HOST_CACHE at creation)
     double host_marks[4];       // the last lc_lcs_host call, ms since its entry: buffers allocated, uploads + launches issued, kernels done, results in the caller's buffers (lc_ctx_last_host_marks)
     int host_timing;            // lc_lcs_host: 1 = one line of wall-clock marks per call on stderr (LCS_HOST_TIMING at creation)
+    int f64_wg_tile;            // float64 order 1, fused levels: 1 = one LDS tile per workgroup (advect_wg64_kernel; LCS_F64_WG_TILE at creation; measured, off)
     int host_threads;           // staging ring: worker threads beside the caller (-1: by the host's core count; LCS_HOST_THREADS at creation)
     int host_piece_mb;          // staging ring: piece size in MB (0: 32; LCS_HOST_PIECE_MB at creation)
     int host_pipeline;          // lc_lcs_host: 1 (default) staged transfers, upload cut into level chunks and overlapped with pack + advect; 0 the serial round-5 form (LCS_HOST_PIPELINE at creation)

@@ -6,6 +6,8 @@ subset keeps the first/last `order` rows so the oracle's pole-row rule (by seed 
 LCS/tools.py:24-33) selects the same rows as in the full grid.  Plus size-independent
 properties: the uniform-wind known answer and sharded == unsharded at full size.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -133,7 +135,8 @@ def test_config2_full_size_subset_vs_oracle(eng):
     u, v, lat, lon = flows.config2()
     f = eng.prepare_field(u, v, lat, lon, 1)
     r = eng.lcs(f, lat, lon, -900.0, SETTLS_order=4, interp_order=1, cyclic_xboundary=True)
-    assert eng.last_advect_kernel() == "advect_lds64_kernel<4, true, 1>", eng.last_advect_kernel()   # (order-1 source: the raw planes)
+    family = "advect_wg64_kernel" if os.environ.get("LCS_F64_WG_TILE") == "1" else "advect_lds64_kernel"
+    assert eng.last_advect_kernel() == family + "<4, true, 1>", eng.last_advect_kernel()   # (order-1 source: the raw planes)
     rows, cols = _subset(1024, 24, 1), _subset(1024, 24, 0)
     xr_, yr_ = O.parcel_propagation(u, v, lat, lon, timestep=-900.0, SETTLS_order=4, interp_order=1,
                                     cyclic_xboundary=True, seed_lat=lat[rows], seed_lon=lon[cols])

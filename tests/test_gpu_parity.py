@@ -207,6 +207,41 @@ def test_float64_fused_levels_without_any_packed_image_equal_the_ext_image_bit_f
     assert ka == eng.last_advect_kernel() == "outer_substep_kernel" and np.array_equal(_np(xa), _np(xb)) and np.array_equal(_np(ya), _np(yb))
 
 
+@pytest.mark.parametrize("K,cyclic", [(4, True), (2, True), (4, False), (1, False)])
+def test_float64_workgroup_shared_tile_equals_the_per_wave_tiles_bit_for_bit(eng, monkeypatch, K, cyclic):
+    """advect_wg64_kernel (LCS_F64_WG_TILE=1 at context creation; round 6's structural attempt at config 2, off by default):
+    four waves 2 x 2 around ONE 24 x 20-node tile, the anchor predicted a level ahead, one barrier per level.  Same locate /
+    lerp / clamp functions and the same out-of-tile fallback, so the bits are advect_lds64_kernel's: every source form (lin +
+    ext images, raw planes + ext image, raw planes only), trajectories, a row block continued from level 3, pole rows, seed
+    grids that are the nodes, sparser, denser, and not a multiple of the 16 x 16 patch."""
+    from lagrangiancoherence_amd.engine import Engine
+    monkeypatch.setenv("LCS_F64_WG_TILE", "1")
+    wg = Engine(0)
+    monkeypatch.delenv("LCS_F64_WG_TILE")
+    try:
+        u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
+        u, v, lat, lon = (a.astype(np.float64) for a in (u * 2.0, v, lat, lon))
+        for ext_image, raw_tag in ((True, ", 1>"), (False, ", 2>")):
+            fa, fb = (e.prepare_field(u, v, lat, lon, 1, ext_image=ext_image) for e in (eng, wg))
+            for sny, snx in ((72, 144), (150, 200), (40, 60), (131, 77)):
+                slat, slon = (a.astype(np.float64) for a in flows.seed_grid(sny, snx, lat, lon))
+                out = []
+                for e, f in ((eng, fa), (wg, fb)):
+                    r = e.advect(f, slat, slon, -1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+                                 noncyclic_clamp="pointwise", return_traj=True)
+                    name = e.last_advect_kernel()
+                    lo, hi = 0, sny // 2
+                    rb = e.advect(f, slat[lo:hi], slon, -1800.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=cyclic,
+                                  noncyclic_clamp="pointwise", row0=lo, ny_global=sny, t0=3, nsteps=5, start=(r[2][3][lo:hi], r[3][3][lo:hi]))
+                    out.append(([_np(t) for t in r] + [_np(t) for t in rb], name))
+                (a, na), (b, nb) = out
+                assert na.startswith("advect_lds64_kernel") and nb.startswith("advect_wg64_kernel") and na.endswith(raw_tag) and nb.endswith(raw_tag), (na, nb)
+                for p, q in zip(a, b):
+                    assert np.array_equal(p, q), (sny, snx, ext_image, na, nb)
+    finally:
+        wg.close()
+
+
 @pytest.mark.parametrize("K,cyclic", [(4, True), (2, True), (4, False), (0, True)])
 def test_float64_order3_fused_levels_without_the_ext_image_equal_it_bit_for_bit(eng, K, cyclic):
     """lc_advect_args.fuse_levels_raw at order 3: float64 with the fused-level COEFFICIENTS 2 c[t] - c[t+1] formed from the
