@@ -1845,6 +1845,10 @@ constexpr int SLAB_PITCH = 36;  // floats per slab row (32 + 4: rows stay 16-byt
 // spent: a direct level gathers 2 x 16 bytes per sample for ALL 64 lanes of the wave where the redo path gathers for the
 // ~29 % that left the tile, and the vector L1 already answers 0.73 lookups per CU-cycle.  (A launch made of polar rows alone
 // does gain: rank 7 of 8 of C4, 14.2 -> 13.0 ms.)  Kept as a compile-time option, off.
+#ifndef LCS_LDS2_DPP_NEXT
+#define LCS_LDS2_DPP_NEXT 1   // node c+2 of the staging from the neighbouring lane (two DPP moves) instead of an 8-byte load: C3 5.98 -> 5.91 ms
+                             // (one vector-memory instruction of eight per wave-level less; profiles/r06/headline_kernel_ab.txt section 9).  0: the load
+#endif
 #ifndef LCS_LDS2_DIRECT_LEVELS
 #define LCS_LDS2_DIRECT_LEVELS 0
 #endif
@@ -1858,6 +1862,8 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
     constexpr int ORDER = 1;
     constexpr bool DEFER_X = LCS_LDS2_DEFER_X != 0;
     constexpr int DIRECT_LEVELS = DEFER_X ? LCS_LDS2_DIRECT_LEVELS : 0;
+    // (a DPP row is 16 lanes: the neighbouring lane holds the next nodes of the same tile row only when tile rows do not straddle DPP rows)
+    constexpr bool DPP_NEXT = LCS_LDS2_DPP_NEXT != 0 && 16 % Lds2Geom::LANES_PER_ROW == 0;
     const int K = KFIX >= 0 ? KFIX : A.K;
     typedef Lds2Geom G;
     constexpr int LT_COLS = G::COLS, LT_ROWS = LCS_LDS2_ROWS;
@@ -2030,7 +2036,7 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
 #pragma unroll
             for (int r = 0; r < NPASS; ++r) {
                 __builtin_memcpy(&stage[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_off, 16);
-                __builtin_memcpy(&stage_next[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_next, 8);
+                if (!DPP_NEXT) __builtin_memcpy(&stage_next[r], src + (size_t)(r * G::ROWS_PER_PASS) * pad_cols * 8 + st_next, 8);
             }
         }
         LCS_STAMP(0)  // anchor + tile load issue
@@ -2071,10 +2077,24 @@ __global__ void __launch_bounds__(BLOCK, LCS_LDS2_MINWAVES) __attribute__((amdgp
             __builtin_amdgcn_wave_barrier();  // the previous level's reads are done (LDS ops of a wave are in order)
 #pragma unroll
             for (int r = 0; r < NPASS; ++r) {
-                // this lane holds nodes (c, c+1) of a tile row and node c+2 in stage_next (loaded, not shuffled: two
-                // cross-lane moves of the .x and .y of one register pair -- v_mov_b32_dpp or ds_bpermute alike -- came
-                // out of hipcc 7.2 as ONE move feeding both halves; seen in the ISA and in wrong results)
-                const f2 nxt = stage_next[r];
+                // this lane holds nodes (c, c+1) of a tile row; node c+2 is the next lane's first node.  Two cross-lane moves of the
+                // .x and .y of one register pair written with the builtins (update_dpp or ds_bpermute alike) came out of hipcc 7.2 as
+                // ONE move feeding both halves (seen in the ISA and in wrong results: rounds 2-5 loaded the node instead, 8 more
+                // bytes per lane) -- so the two moves are spelled out: row_shl:1 within the 16 lanes of a DPP row; the last lane of a
+                // TILE row receives the next tile row's first node or zero, and its entry c+1 is never a window origin.  (s_nop 4:
+                // the five wait states a DPP instruction needs after a VALU write of EXEC, two after one of its source, whatever
+                // precedes the statement: tools/asm_hazards.py audits the sites.)
+                f2 nxt;
+                if constexpr (DPP_NEXT) {
+                    float nx0, nx1;
+                    const float s0 = stage[r].x, s1 = stage[r].y;
+                    asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                 "v_mov_b32_dpp %1, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                 : "=&v"(nx0), "=&v"(nx1) : "v"(s0), "v"(s1));
+                    nxt = (f2){nx0, nx1};
+                } else {
+                    nxt = stage_next[r];
+                }
                 f4 *dst = tile + (r * G::ROWS_PER_PASS + st_row) * LT_PITCH + st_col;
                 const f2 n0 = stage[r].xy, n1 = stage[r].zw, d0 = n1 - n0, d1 = nxt - n1;
                 dst[0] = (f4){n0.x, n0.y, d0.x, d0.y};

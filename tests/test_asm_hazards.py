@@ -57,6 +57,27 @@ def test_the_audit_finds_the_hazards_hipcc_leaves_in_the_probe(tmp_path):
     assert sites == 3
 
 
+def test_the_audit_knows_the_dpp_rules(tmp_path):
+    """Round 6 put two v_mov_b32_dpp into the two-seed kernel's staging: a DPP instruction needs two wait states after a VALU
+    write of its source and five after a VALU write of EXEC.  Hand-written listings: the audit flags the bare forms and accepts
+    the form the kernel uses (the asm statement carries `s_nop 4`)."""
+    import asm_hazards
+
+    def listing(pre, nop):
+        body = ["_Z4demov:", *("\t" + x for x in pre), "\t;;#ASMSTART", *(["\ts_nop %d" % nop] if nop is not None else []),
+                "\tv_mov_b32_dpp v3, v10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0", "\t;;#ASMEND", "\ts_endpgm"]
+        f = tmp_path / "demo.s"
+        f.write_text("\n".join(body) + "\n")
+        return asm_hazards.audit(str(f))[1]
+    kinds = lambda found: sorted(x["kind"].split(" (")[0] for x in found)
+    assert kinds(listing(["v_add_f32_e32 v10, v1, v2"], None)) == ["VALU-written VGPR read by asm DPP"]
+    assert kinds(listing(["v_add_f32_e32 v10, v1, v2", "s_mov_b32 s4, 0"], None)) == ["VALU-written VGPR read by asm DPP"]
+    assert kinds(listing(["v_add_f32_e32 v10, v1, v2"], 1)) == []
+    assert kinds(listing(["v_cmpx_gt_f32_e32 v1, v2", "s_mov_b32 s4, 0", "s_mov_b32 s5, 0"], None)) == ["VALU-written EXEC before asm DPP"]
+    assert kinds(listing(["v_cmpx_gt_f32_e32 v1, v2"], 1)) == ["VALU-written EXEC before asm DPP"]
+    assert kinds(listing(["v_cmpx_gt_f32_e32 v1, v2", "v_add_f32_e32 v10, v1, v2"], 4)) == []
+
+
 def test_only_advect_hip_holds_inline_asm_instructions():
     """The audit below covers advect.hip; no other translation unit may grow an asm instruction unaudited."""
     for f in sorted(os.listdir(CSRC)):

@@ -10,6 +10,8 @@ compiler (tools/asm_hazard_probe.hip, the listing is in profiles/r05/asm_hazard_
   VALU writes SGPR (v_readlane, v_cmp ...) -> VALU reads it        2          s_nop inserted      NOT inserted
   trans op (v_rcp, v_sqrt, ...) writes VGPR -> VALU reads it       1          s_nop inserted      NOT inserted
   VALU writes VGPR -> v_readlane / v_readfirstlane reads it        1          s_nop inserted      inserted (asm producer too)
+  VALU writes VGPR -> DPP instruction reads it                     2          s_nop inserted      (round 6: the asm carries its own s_nop)
+  VALU writes EXEC (v_cmpx ...) -> DPP instruction                 5          s_nop inserted      (round 6: the asm carries its own s_nop)
 
 This script walks the compiler's assembly (hipcc -S) kernel by kernel, finds every instruction between ;;#ASMSTART and
 ;;#ASMEND, and reports each one whose source registers were written inside the hazard window by a producer of the
@@ -95,11 +97,13 @@ def audit(path: str, kernel_re: str | None = None):
             need_s = {r for r in srcs if r[0] == "s"}
             need_v = {r for r in srcs if r[0] == "v"}
             seen = set()
+            dpp = "_dpp" in op or any(re.search(r"\b(row_|quad_perm|wave_|bank_mask|row_mask)", o) for o in operands)
+            limit = 5 if dpp else 2
 
             def walk(j, ws):
                 """Backwards from body[j] with ``ws`` wait states already between it and the asm instruction; follows
                 every predecessor at a label (the fall-through and each branch that targets it)."""
-                while j >= 0 and ws < 2:
+                while j >= 0 and ws < limit:
                     if (j, ws) in seen:
                         return
                     seen.add((j, ws))
@@ -112,7 +116,13 @@ def audit(path: str, kernel_re: str | None = None):
                         j -= 1
                         continue
                     d = dest_regs(pop, poperands)
-                    if pop.startswith("v_") and (d & need_s):
+                    if dpp and ws < 2 and pop.startswith("v_") and (d & need_v):
+                        findings.append({"kernel": kern, "line": ln, "asm": f"{op} {', '.join(operands)}", "kind": "VALU-written VGPR read by asm DPP (needs 2)",
+                                         "producer": f"{pop} {', '.join(poperands)}", "producer_line": pln, "wait_states_seen": ws})
+                    if dpp and pop.startswith("v_cmpx"):
+                        findings.append({"kernel": kern, "line": ln, "asm": f"{op} {', '.join(operands)}", "kind": "VALU-written EXEC before asm DPP (needs 5)",
+                                         "producer": f"{pop} {', '.join(poperands)}", "producer_line": pln, "wait_states_seen": ws})
+                    if ws < 2 and pop.startswith("v_") and (d & need_s):
                         findings.append({"kernel": kern, "line": ln, "asm": f"{op} {', '.join(operands)}", "kind": "VALU-written SGPR read by asm VALU (needs 2)",
                                          "producer": f"{pop} {', '.join(poperands)}", "producer_line": pln, "wait_states_seen": ws})
                     if ws < 1 and TRANS.match(pop) and (d & need_v):
