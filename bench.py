@@ -600,6 +600,9 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
             e["algorithmic_over_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBPS
     case("c3 order 3", ny * nx * (nt - 1), K, 3, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 3),
          lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 3, True), sig32)
+    # ... and both at once: interp_order=3, SETTLS_order=0 are the reference's DEFAULT arguments (LCS/trajectory.py:14-16)
+    case("c3 order 3 K=0", ny * nx * (nt - 1), 0, 3, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 3),
+         lambda f: eng.advect(f, slat_d, slon_d, -900.0, 0, 3, True), sig32)
     case("c3 return_traj", ny * nx * (nt - 1), K, 1, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 1),
          lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 1, True, return_traj=True), sig32)
     try:

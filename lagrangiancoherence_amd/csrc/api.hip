@@ -906,8 +906,10 @@ extern "C" int lc_lcs_host(lc_ctx *ctx, const void *u_host, const void *v_host, 
     ctx->host_marks[2] = hx ? t_kernels : 0.0;
     ctx->host_marks[3] = ms_since();
     if (ctx->host_timing)
-        std::fprintf(stderr, "lc_lcs_host: %s, buffers allocated %.2f ms, uploads and launches issued %.2f, kernels done %.2f, results down %.2f\n",
-                     piped ? "pipelined" : (hx ? "staged" : "plain copies"), t_alloc, t_up, t_kernels, ms_since());
+        std::fprintf(stderr, "lc_lcs_host: %s, buffers allocated %.2f ms, uploads and launches issued %.2f, kernels done %.2f, results down %.2f"
+                             " (download: %.2f waiting for DMAs, %.2f copying out of the ring)\n",
+                     piped ? "pipelined" : (hx ? "staged" : "plain copies"), t_alloc, t_up, t_kernels, ms_since(),
+                     hx ? hx->last_down_wait_ms : 0.0, hx ? hx->last_down_copy_ms : 0.0);
     return LC_OK;  // `drain` waits for both streams, then the DevBuf destructors free
 }
 

@@ -18,9 +18,12 @@
 // later copy streams another DMA engine.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdint>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -49,6 +52,7 @@ struct lc_host_xfer {
     unsigned long generation = 0;
     int pending = 0;
     bool quit = false;
+    double last_down_wait_ms = 0.0, last_down_copy_ms = 0.0;  // the last download(): waiting for DMAs / copying out of the ring
     std::mutex use;  // held by the one transfer sequence that is using the ring (slots, `next`, the copy stream's order)
     int refs = 0, device = -1;
 
@@ -231,12 +235,19 @@ struct lc_host_xfer {
             hipError_t e = issue(i);
             if (e != hipSuccess) return e;
         }
+        using clk = std::chrono::steady_clock;
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        last_down_wait_ms = last_down_copy_ms = 0.0;
         for (size_t j = 0; j < np; ++j) {
             const int s = (int)(j % RING);
+            const auto t0 = clk::now();
             hipError_t e = hipEventSynchronize(dma_done[s]);
             if (e != hipSuccess) return e;
             in_flight[s] = false;
+            const auto t1 = clk::now();
             parallel_copy(pieces[j].host, pin[s], pieces[j].n);
+            last_down_wait_ms += ms(t0, t1);
+            last_down_copy_ms += ms(t1, clk::now());
             if (j + RING < np) {
                 e = issue(j + RING);
                 if (e != hipSuccess) return e;
@@ -254,25 +265,49 @@ struct lc_host_xfer {
     }
 };
 
-// Touches every page of a caller's output buffer from a background thread (a fresh numpy array is unfaulted: the copy-out
-// would pay 4 KB faults at a quarter of the copy rate).  Joined by the destructor.
+// Populates the pages of a caller's output buffers from background threads (a fresh numpy array is unfaulted: the copy-out
+// would pay 4 KB faults at a quarter of the copy rate).  What populating costs is the kernel ZEROING the pages -- 201 MB of
+// results is 20 ms of one thread, longer than the upload it hides behind -- so the ranges are cut between a few threads.
+// Joined by the destructor.
 struct lc_prefault {
-    std::thread t;
+    std::vector<std::thread> ts;
+    static void populate(char *b, size_t n) {
+        volatile char *p = (volatile char *)b;
+        if (!p || !n) return;
+#ifdef MADV_POPULATE_WRITE
+        // whole pages inside the range in one call (Linux 5.14: no fault per page); the partial pages at either end, and
+        // everything when the call is refused, by touching
+        const uintptr_t lo = ((uintptr_t)b + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)b + n) & ~(uintptr_t)4095;
+        if (hi > lo && madvise((void *)lo, hi - lo, MADV_POPULATE_WRITE) == 0) {
+            p[0] = 0;
+            p[n - 1] = 0;
+            return;
+        }
+#endif
+        for (size_t o = 0; o < n; o += 4096) p[o] = 0;
+        p[n - 1] = 0;
+    }
     void start(std::vector<std::pair<void *, size_t>> ranges) {
-        try {
-            t = std::thread([ranges] {
-                for (auto &r : ranges) {
-                    volatile char *p = (volatile char *)r.first;
-                    if (!p) continue;
-                    for (size_t o = 0; o < r.second; o += 4096) p[o] = 0;
-                    if (r.second) p[r.second - 1] = 0;
-                }
-            });
-        } catch (...) {  // no thread: the copy-out pays the faults
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t parts = hw >= 16 ? 4 : (hw >= 4 ? 2 : 1);
+        for (size_t k = 0; k < parts; ++k) {
+            try {
+                ts.emplace_back([ranges, k, parts] {
+                    for (auto &r : ranges) {
+                        if (!r.first) continue;
+                        const size_t per = ((r.second + parts - 1) / parts + 4095) & ~(size_t)4095;
+                        const size_t b = std::min(r.second, k * per), e = std::min(r.second, (k + 1) * per);
+                        populate((char *)r.first + b, e - b);
+                    }
+                });
+            } catch (...) {  // no thread: the copy-out pays the faults of this part
+            }
         }
     }
     void join() {
-        if (t.joinable()) t.join();
+        for (auto &t : ts)
+            if (t.joinable()) t.join();
+        ts.clear();
     }
     ~lc_prefault() { join(); }
 };

@@ -217,7 +217,7 @@ def test_secondary_workloads_block_of_the_default_run():
                                     long_nt=25, c3_long_nt=11, c4_n=320, c5=(128, 4, 20))
     # ... and (round 5) north_star's own target shape and the other BASELINE configurations on one GPU
     # ... and (round 6) SETTLS_order 0 (the library default: the direct-gather kernel), 1 and 2 on the headline field
-    assert list(sec) == ["c3 K=0", "c3 K=1", "c3 K=2", "c3 order 3", "c3 return_traj", "c2", "c2 order 3", "c3 x 10 steps",
+    assert list(sec) == ["c3 K=0", "c3 K=1", "c3 K=2", "c3 order 3", "c3 order 3 K=0", "c3 return_traj", "c2", "c2 order 3", "c3 x 10 steps",
                          "c4 on one GPU", "c5 on one GPU"]
     assert sec["c3 K=0"]["kernel"] == "advect_kernel_f32<1>", sec["c3 K=0"]      # K = 0 has nothing to stage a tile for
     for K in (0, 1, 2):
