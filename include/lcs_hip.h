@@ -166,13 +166,15 @@ enum lc_f64_fidelity { LC_F64_AUTO = 0, LC_F64_EXACT_ORDER = 1, LC_F64_FAST = 2 
 int lc_ctx_set_f64_fidelity(lc_ctx *ctx, int mode);
 int lc_ctx_get_f64_fidelity(const lc_ctx *ctx, int *mode_out);
 /* How the one-call host routes move their host buffers (no reference counterpart: LCS/LCS.py:129-157 runs on host arrays).
- *   1 (default)  through a ring of four 32 MB pinned staging buffers filled / emptied by a few host threads (kept on the context
- *                from the first call that needs it: 128 MB of pinned memory, freed by lc_ctx_destroy): pageable caller memory
+ *   1 (default)  through a ring of four 32 MB pinned staging buffers filled / emptied by a few host threads (ONE ring per device
+ *                and process, shared by its contexts -- a process's second copy stream runs 25 % slower --, taken by a context's
+ *                first staged transfer, released by lc_ctx_destroy, freed with the last context that holds it; transfers of
+ *                different contexts take turns): pageable caller memory
  *                then travels at the bus rate whatever state its pages are in (hipMemcpy from pages the runtime has not pinned
  *                before runs at a quarter of it), the upload is cut at time-level boundaries and the pack + advect kernels of level
  *                chunk c run while chunk c + 1 is on the bus (cyclic_x = LC_X_CYCLIC, fused levels, no trajectories, 32 steps or
  *                more; lc_advect_from continuation: bit-identical to the serial form), only the levels [t0, t0 + nsteps] travel,
- *                and the caller's output pages are touched by a background thread meanwhile.  A host with no pinned memory to
+ *                and the caller's output pages are populated by background threads meanwhile.  A host with no pinned memory to
  *                give falls back to 0 by itself.
  *   0            plain hipMemcpyAsync of the whole series on the context's stream, then pack, advect, sigma, copies back.
  * LCS_HOST_PIPELINE (0 / 1) sets the initial value, read ONCE in lc_ctx_create. */
