@@ -1387,7 +1387,7 @@ def main():
         "advect_particle_timesteps_per_s": pts_launch * n_launch * world / (ms["advect"] / 1e3),
         "ftle_mcells_per_s": (hi - lo) * nx * n_launch * world / (ms["sigma"] / 1e3) / 1e6,
         "kernel_ms": ms,
-        "roofline": {**roofline(advect_kernel, "valu" if "lds" in advect_kernel else "tcp", pts_launch, adv_ms, K, order,
+        "roofline": {**roofline(advect_kernel, "valu" if ("lds" in advect_kernel and K > 0) else "tcp", pts_launch, adv_ms, K, order,
                                 s_p, s_f, True, comp, wl, csrc,
                                 # level-major: the launches the ensemble call made (the member-pair path walks
                                 # nsteps + stride levels; the per-member fallback makes one launch per chunk and call)

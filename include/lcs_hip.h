@@ -115,8 +115,9 @@ int lc_sync(lc_ctx *ctx);
 /* Kernel choice of lc_advect: -1 = what lc_ctx_create set (LCS_LDS_TILES, else the default): per-wave LDS tiles -- float32
  * orders 1 and 3 with two seeds per lane from 2^23 seeds per call upwards and one seed per lane below (smaller launches
  * want the waves), float64 order 1 with packed_ext one seed per lane; 1 = LDS tiles, two seeds per lane whatever the
- * size; 2 = LDS tiles, one seed per lane; 0 = direct gathers (float32 and float64).  SETTLS_order = 0 takes direct
- * gathers at order 1 and the LDS kernels at order 3.  The environment variable LCS_LDS_TILES (0/1/2) sets the initial
+ * size; 2 = LDS tiles, one seed per lane; 0 = direct gathers (float32 and float64).  SETTLS_order = 0 stages no tile at
+ * order 1: direct gathers, two seeds per lane from 2^23 seeds per call upwards (the two-seed kernel compiled without its tile
+ * and iteration blocks), one per lane below; the LDS kernels at order 3.  The environment variable LCS_LDS_TILES (0/1/2) sets the initial
  * value, read ONCE in lc_ctx_create (profiling A/B; results are bit-identical either way).  No reference counterpart. */
 int lc_ctx_set_lds_tiles(lc_ctx *ctx, int mode);
 /* Kernel choice of lc_sigma for float32 sigma-only calls on grids of even width: 1 = marching kernel (a wave walks

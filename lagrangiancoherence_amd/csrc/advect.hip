@@ -2560,7 +2560,9 @@ static inline bool two_seeds_per_lane(const AdvectArgs<float> &A, int mode) {
     return mode == 1 || (mode == 3 && (long long)A.nx * A.ny * (long long)nmem(A) >= (1ll << 23));
 }
 static inline bool order1_two_seed_applies(const AdvectArgs<float> &A, int mode) {
-    return two_seeds_per_lane(A, mode) && A.ext && A.K > 0 && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16;
+    // SETTLS_order = 0 (the library default, LCS/trajectory.py:14) stages no tile and needs no ext image; two seeds per lane and
+    // packed position arithmetic still pay (round 6: C3 at K = 0, 2.21 -> 1.72 ms against the one-seed direct kernel)
+    return two_seeds_per_lane(A, mode) && (A.K == 0 || A.ext) && A.nx_f + LC_PAD >= 32 && A.ny_f + LC_PAD >= 16;
 }
 template <typename T>
 static inline bool order1_two_seed_applies(const AdvectArgs<T> &, int) { return false; }
@@ -2627,6 +2629,8 @@ struct LdsLaunch<float, ORDER> {
                 if (A.cyclic) LC_LDS2(-1, true, PATCH_WIDE, "advect_lds2_kernel<-1, true, 1>")
                 LC_LDS2(-1, false, PATCH_WIDE, "advect_lds2_kernel<-1, false, 1>")
             }
+            // (SETTLS_order = 0, the library default, compiled as such: no tile, no iteration blocks -- C3 1.73 -> 1.69 ms against the run-time-K instance)
+            if (A.K == 0 && A.cyclic) LC_LDS2(0, true, PATCH_TALL, "advect_lds2_kernel<0, true, 0>")
             if (A.K == 4 && A.cyclic) LC_LDS2(4, true, PATCH_TALL, "advect_lds2_kernel<4, true, 0>")
             if (A.K == 4) LC_LDS2(4, false, PATCH_TALL, "advect_lds2_kernel<4, false, 0>")
             if (A.cyclic) LC_LDS2(-1, true, PATCH_TALL, "advect_lds2_kernel<-1, true, 0>")
@@ -2665,6 +2669,9 @@ struct LdsLaunch<float, ORDER> {
                 if (A.cyclic) LC_LDS2O3(-1, true, PATCH_WIDE, "advect_lds2_o3_kernel<-1, true, 1>")
                 LC_LDS2O3(-1, false, PATCH_WIDE, "advect_lds2_o3_kernel<-1, false, 1>")
             }
+#ifdef LCS_O3_K0_INSTANCE
+            if (A.K == 0 && A.cyclic) LC_LDS2O3(0, true, PATCH_TALL, "advect_lds2_o3_kernel<0, true, 0>")
+#endif
             if (A.K == 4 && A.cyclic) LC_LDS2O3(4, true, PATCH_TALL, "advect_lds2_o3_kernel<4, true, 0>")
             if (A.K == 4) LC_LDS2O3(4, false, PATCH_TALL, "advect_lds2_o3_kernel<4, false, 0>")
             if (A.cyclic) LC_LDS2O3(-1, true, PATCH_TALL, "advect_lds2_o3_kernel<-1, true, 0>")
@@ -4263,7 +4270,7 @@ int advect_impl(lc_ctx *ctx, const void *packed_lin, const void *packed_cub, con
     // (four members per lane -- 99 VGPRs, the members of a lane up to 3 d levels of travel apart -- measured 480 ms on
     // config 5 against 280 for pairs: in the jets three steps are 6 cells, nearly every wave-sample has a lane outside the tile)
     const bool pairs_ok = n_members > 1 && order == 1 && !outer && !traj_x && use_lds &&
-                          (ctx->patch_mode < 0 || ctx->patch_mode == PATCH_PAIR) && order1_two_seed_applies(A, ctx->lds_tiles);
+                          (ctx->patch_mode < 0 || ctx->patch_mode == PATCH_PAIR) && K > 0 && order1_two_seed_applies(A, ctx->lds_tiles);
     const lcplan::Groups G = lcplan::member_groups(n_members, t0_stride, nsteps, pairs_ok);
     const int total = G.total;
     if (G.g) {

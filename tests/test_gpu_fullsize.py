@@ -74,15 +74,15 @@ def test_config3_full_size_subset_vs_oracle(eng, c3, order):
 
 def test_config3_full_size_settls_order_0_subset_vs_oracle(eng, c3):
     """SETTLS_order = 0 is the LIBRARY default (LCS/trajectory.py:14, LCS/LCS.py:26): one Euler sample per level and nothing to
-    stage a tile for, so configs[2]'s grid goes to the direct-gather kernel -- another code path than the K = 4 anchors above
-    (include/lcs_hip.h).  The same subset-vs-oracle anchor at 4096^2 seeds x 96 steps, the dispatched kernel asserted by name;
-    and K = 1, 2 (the two-seed kernel's run-time-K instance)."""
+    stage a tile for -- the two-seed kernel compiled for K = 0, no tile and no iteration blocks (round 6; below 2^23
+    seeds the one-seed direct-gather kernel): another code path than the K = 4 anchors above (include/lcs_hip.h).  The same
+    subset-vs-oracle anchor at 4096^2 seeds x 96 steps, the dispatched kernel asserted by name; and K = 1, 2."""
     from oracle import lcs_oracle as O
     from tests._fullsize import positions_check
     u, v, lat, lon, slat, slon = c3
     f = eng.prepare_field(u, v, lat, lon, 1)
     rows, cols = _subset(4096, 40, 1), _subset(4096, 40, 0)
-    for K, kernel in ((0, "advect_kernel_f32<1>"), (1, "advect_lds2_kernel<-1, true, 0>"), (2, "advect_lds2_kernel<-1, true, 0>")):
+    for K, kernel in ((0, "advect_lds2_kernel<0, true, 0>"), (1, "advect_lds2_kernel<-1, true, 0>"), (2, "advect_lds2_kernel<-1, true, 0>")):
         x, y = eng.advect(f, slat, slon, -900.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=True)
         assert eng.last_advect_kernel() == kernel, (K, eng.last_advect_kernel())
         xg = x[rows][:, cols].cpu().numpy().astype(np.float64)
@@ -95,6 +95,32 @@ def test_config3_full_size_settls_order_0_subset_vs_oracle(eng, c3):
         # (1 + K) position updates per step instead of 5: the floors scale with the updates made
         positions_check(eng, f, slat, slon, rows, cols, xg, yg, (x32, y32), (x64, y64), f"C3 K={K}",
                         (1e-4, 5e-4, 2e-3), interp_order=1, **({"K": K} if K != 4 else {}))
+
+
+def test_settls_order_0_two_seed_kernel_equals_the_direct_kernel_bit_for_bit(eng, c3):
+    """Round 6: from 2^23 seeds per call SETTLS_order = 0 runs on the two-seed kernel (compiled for K = 0 when cyclic, the
+    run-time-K instance otherwise) instead of the one-seed direct-gather kernel -- the same Euler sample, update and clamps, so
+    the same bits: 2048 x 4096 seeds x 24 levels, cyclic and not, with the trajectory."""
+    u, v, lat, lon, slat, slon = c3
+    f = eng.prepare_field(u[:25], v[:25], lat, lon, 1)
+    rows = slat[1024:3072]
+    for cyclic, name in ((True, "advect_lds2_kernel<0, true, 0>"), (False, "advect_lds2_kernel<-1, false, 0>")):
+        kw = dict(SETTLS_order=0, interp_order=1, cyclic_xboundary=cyclic, noncyclic_clamp="pointwise", row0=1024, ny_global=4096)
+        a = eng.advect(f, rows, slon, -900.0, **kw)
+        assert eng.last_advect_kernel() == name, eng.last_advect_kernel()
+        try:
+            eng.set_lds_tiles(0)
+            b = eng.advect(f, rows, slon, -900.0, **kw)
+            assert eng.last_advect_kernel() == "advect_kernel_f32<1>", eng.last_advect_kernel()
+        finally:
+            eng.set_lds_tiles(-1)
+        for p_, q_ in zip(a, b):
+            assert bool((p_ == q_).all()), (cyclic, name)
+    # ... and with the trajectory (whole-line stores: the run-time-K instance of the line-store patch mode)
+    t = eng.advect(f, rows, slon, -900.0, SETTLS_order=0, interp_order=1, cyclic_xboundary=True, return_traj=True, row0=1024, ny_global=4096)
+    assert eng.last_advect_kernel() == "advect_lds2_kernel<-1, true, 2>", eng.last_advect_kernel()
+    c = eng.advect(f, rows, slon, -900.0, SETTLS_order=0, interp_order=1, cyclic_xboundary=True, row0=1024, ny_global=4096)
+    assert bool((t[0] == c[0]).all() and (t[1] == c[1]).all() and (t[2][-1] == c[0]).all() and (t[3][-1] == c[1]).all())
 
 
 def test_config3_sharded_equals_unsharded_full_size(eng, c3):
