@@ -810,12 +810,22 @@ class Engine:
         current stream (an event per chunk), each advect continuing in place from the previous one (``lc_advect_from``:
         bit-identical to one call, LCS/trajectory.py:80-126 carries only positions from level to level).  The level shared
         by two chunks is packed by both (same values; the earlier chunk's advect never reads it).  Results are
-        bit-identical to the serial form; the field returned is complete and reusable."""
+        bit-identical to the serial form; the field returned is reusable (with ``SETTLS_order=0`` it holds no fused-level image)."""
         torch = self.torch
         lat_f, lon_f = np.asarray(lat_f), np.asarray(lon_f)
         dtype = common_dtype(u, v, lat_f, lon_f)
         if fuse_levels is None:
             fuse_levels = True
+        if int(SETTLS_order) == 0 and fuse_levels and ext_image is None:
+            # SETTLS_order = 0 (the library default, LCS/trajectory.py:14) takes one Euler sample per level and never reads the
+            # fused-level image: it is not built.  float64: the kernels' no-image forms (the same Euler sample, bit for bit --
+            # at order 1 no packed image at all, at order 3 the coefficients only); float32: the order-1 / coefficient image only.
+            # configs[1] at K = 0: pack 1.29 -> 0 ms (order 1), 3.17 -> 1.85 ms (order 3).  The field returned holds what THIS
+            # call needed: advected again with SETTLS_order > 0 it takes the two-sample form.
+            if dtype != np.dtype(np.float32):
+                ext_image = False
+            else:
+                fuse_levels = False
         nt = int(u.shape[0])
         ny, nx = len(seed_lat), len(seed_lon)
         if pipeline is None:

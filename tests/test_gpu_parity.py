@@ -207,6 +207,31 @@ def test_float64_fused_levels_without_any_packed_image_equal_the_ext_image_bit_f
     assert ka == eng.last_advect_kernel() == "outer_substep_kernel" and np.array_equal(_np(xa), _np(xb)) and np.array_equal(_np(ya), _np(yb))
 
 
+@pytest.mark.parametrize("dtype,order", [(np.float64, 1), (np.float64, 3), (np.float32, 1), (np.float32, 3)])
+def test_settls_order_0_one_call_form_builds_no_fused_level_image_and_gives_the_same_bits(eng, dtype, order):
+    """Engine.pack_and_advect(SETTLS_order=0) -- what the drop-in calls for the library's default SETTLS_order -- does not build
+    the fused-level image nothing would read (float64 at order 1: no packed image at all; order 3: the coefficients only;
+    float32: the order-1 / coefficient image only) and returns the bits of prepare_field() + advect(): cyclic and not, with
+    the trajectory, dense and sparse seeds.  An explicit ext_image / fuse_levels is respected."""
+    u, v, lat, lon = flows.era5_like(nt=9, ny=72, nx=144)
+    u, v, lat, lon = (a.astype(dtype) for a in (u * 2.0, v, lat, lon))
+    full = eng.prepare_field(u, v, lat, lon, order)
+    assert full.ext is not None
+    for sny, snx in ((72, 144), (150, 200), (40, 60)):
+        slat, slon = (a.astype(dtype) for a in flows.seed_grid(sny, snx, lat, lon))
+        for cyclic in (True, False):
+            kw = dict(cyclic_xboundary=cyclic, noncyclic_clamp="pointwise", return_traj=True)
+            a = eng.advect(full, slat, slon, -1800.0, SETTLS_order=0, interp_order=order, **kw)
+            f, *b = eng.pack_and_advect(u, v, lat, lon, slat, slon, -1800.0, 0, order, **kw)
+            assert f.ext is None and (f.lin is None) == (dtype == np.float64 or order == 3)
+            if dtype == np.float64 and order == 1:
+                assert f.cub is None and f.fuse_raw
+            for p_, q_ in zip(a, b):
+                assert np.array_equal(_np(p_), _np(q_)), (sny, snx, cyclic, eng.last_advect_kernel())
+    f, *_ = eng.pack_and_advect(u, v, lat, lon, slat, slon, -1800.0, 0, order, ext_image=True)
+    assert f.ext is not None
+
+
 @pytest.mark.parametrize("K,cyclic", [(4, True), (2, True), (4, False), (1, False)])
 def test_float64_workgroup_shared_tile_equals_the_per_wave_tiles_bit_for_bit(eng, monkeypatch, K, cyclic):
     """advect_wg64_kernel (LCS_F64_WG_TILE=1 at context creation; round 6's structural attempt at config 2, off by default):
