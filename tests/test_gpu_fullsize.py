@@ -76,13 +76,13 @@ def test_config3_full_size_settls_order_0_subset_vs_oracle(eng, c3):
     """SETTLS_order = 0 is the LIBRARY default (LCS/trajectory.py:14, LCS/LCS.py:26): one Euler sample per level and nothing to
     stage a tile for -- the two-seed kernel compiled for K = 0, no tile and no iteration blocks (round 6; below 2^23
     seeds the one-seed direct-gather kernel): another code path than the K = 4 anchors above (include/lcs_hip.h).  The same
-    subset-vs-oracle anchor at 4096^2 seeds x 96 steps, the dispatched kernel asserted by name; and K = 1, 2."""
+    subset-vs-oracle anchor at 4096^2 seeds x 96 steps, the dispatched kernel asserted by name; and K = 1, 2 (their own instances)."""
     from oracle import lcs_oracle as O
     from tests._fullsize import positions_check
     u, v, lat, lon, slat, slon = c3
     f = eng.prepare_field(u, v, lat, lon, 1)
     rows, cols = _subset(4096, 40, 1), _subset(4096, 40, 0)
-    for K, kernel in ((0, "advect_lds2_kernel<0, true, 0>"), (1, "advect_lds2_kernel<-1, true, 0>"), (2, "advect_lds2_kernel<-1, true, 0>")):
+    for K, kernel in ((0, "advect_lds2_kernel<0, true, 0>"), (1, "advect_lds2_kernel<1, true, 0>"), (2, "advect_lds2_kernel<2, true, 0>")):
         x, y = eng.advect(f, slat, slon, -900.0, SETTLS_order=K, interp_order=1, cyclic_xboundary=True)
         assert eng.last_advect_kernel() == kernel, (K, eng.last_advect_kernel())
         xg = x[rows][:, cols].cpu().numpy().astype(np.float64)
@@ -116,6 +116,18 @@ def test_settls_order_0_two_seed_kernel_equals_the_direct_kernel_bit_for_bit(eng
             eng.set_lds_tiles(-1)
         for p_, q_ in zip(a, b):
             assert bool((p_ == q_).all()), (cyclic, name)
+    # ... SETTLS_order 1, 2, 3: instances of their own too; the one-seed LDS kernel (what a row shard below 2^23 seeds runs) gives the same bits
+    for K in (1, 2, 3):
+        kw = dict(SETTLS_order=K, interp_order=1, cyclic_xboundary=True, row0=1024, ny_global=4096)
+        a = eng.advect(f, rows, slon, -900.0, **kw)
+        assert eng.last_advect_kernel() == f"advect_lds2_kernel<{K}, true, 0>", eng.last_advect_kernel()
+        try:
+            eng.set_lds_tiles(2)
+            b = eng.advect(f, rows, slon, -900.0, **kw)
+            assert eng.last_advect_kernel().startswith("advect_lds_kernel<1"), eng.last_advect_kernel()
+        finally:
+            eng.set_lds_tiles(-1)
+        assert bool((a[0] == b[0]).all() and (a[1] == b[1]).all()), K
     # ... interp_order = 3 with SETTLS_order = 0, the reference's DEFAULT arguments (LCS/trajectory.py:14-16): its own instance too
     f3 = eng.prepare_field(u[:25], v[:25], lat, lon, 3)
     kw = dict(SETTLS_order=0, interp_order=3, cyclic_xboundary=True, row0=1024, ny_global=4096)
