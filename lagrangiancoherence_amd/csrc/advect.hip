@@ -2631,6 +2631,7 @@ struct LdsLaunch<float, ORDER> {
             }
             // (SETTLS_order = 0, the library default, compiled as such: no tile, no iteration blocks -- C3 1.73 -> 1.69 ms against the run-time-K instance)
             if (A.K == 0 && A.cyclic) LC_LDS2(0, true, PATCH_TALL, "advect_lds2_kernel<0, true, 0>")
+            if (A.K == 0) LC_LDS2(0, false, PATCH_TALL, "advect_lds2_kernel<0, false, 0>")   // (cyclic_xboundary=False is the reference's default too)
             // (SETTLS_order 1, 2, 3 compiled as such too: the iteration loop unrolls and the kernel keeps the K = 4 instance's 59 registers
             // instead of the run-time-K instance's 71 -- C3 at K = 1: 3.28 -> 2.91 ms, K = 2: 4.26 -> 3.93)
             if (A.K == 1 && A.cyclic) LC_LDS2(1, true, PATCH_TALL, "advect_lds2_kernel<1, true, 0>")
@@ -2677,6 +2678,7 @@ struct LdsLaunch<float, ORDER> {
             // (interp_order = 3 with SETTLS_order = 0 are the reference's DEFAULT arguments: compiled as such, 85 registers instead of
             // 94 + scratch and no iteration blocks -- C3 3.26 -> 3.10 ms against the run-time-K instance)
             if (A.K == 0 && A.cyclic) LC_LDS2O3(0, true, PATCH_TALL, "advect_lds2_o3_kernel<0, true, 0>")
+            if (A.K == 0) LC_LDS2O3(0, false, PATCH_TALL, "advect_lds2_o3_kernel<0, false, 0>")   // (... with cyclic_xboundary=False, its default)
             // (order-3 instances for K = 1, 2: measured, < 1 %)
             if (A.K == 4 && A.cyclic) LC_LDS2O3(4, true, PATCH_TALL, "advect_lds2_o3_kernel<4, true, 0>")
             if (A.K == 4) LC_LDS2O3(4, false, PATCH_TALL, "advect_lds2_o3_kernel<4, false, 0>")

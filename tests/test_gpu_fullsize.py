@@ -104,7 +104,7 @@ def test_settls_order_0_two_seed_kernel_equals_the_direct_kernel_bit_for_bit(eng
     u, v, lat, lon, slat, slon = c3
     f = eng.prepare_field(u[:25], v[:25], lat, lon, 1)
     rows = slat[1024:3072]
-    for cyclic, name in ((True, "advect_lds2_kernel<0, true, 0>"), (False, "advect_lds2_kernel<-1, false, 0>")):
+    for cyclic, name in ((True, "advect_lds2_kernel<0, true, 0>"), (False, "advect_lds2_kernel<0, false, 0>")):
         kw = dict(SETTLS_order=0, interp_order=1, cyclic_xboundary=cyclic, noncyclic_clamp="pointwise", row0=1024, ny_global=4096)
         a = eng.advect(f, rows, slon, -900.0, **kw)
         assert eng.last_advect_kernel() == name, eng.last_advect_kernel()
@@ -131,15 +131,17 @@ def test_settls_order_0_two_seed_kernel_equals_the_direct_kernel_bit_for_bit(eng
     # ... interp_order = 3 with SETTLS_order = 0, the reference's DEFAULT arguments (LCS/trajectory.py:14-16): its own instance too
     f3 = eng.prepare_field(u[:25], v[:25], lat, lon, 3)
     kw = dict(SETTLS_order=0, interp_order=3, cyclic_xboundary=True, row0=1024, ny_global=4096)
-    a3 = eng.advect(f3, rows, slon, -900.0, **kw)
-    assert eng.last_advect_kernel() == "advect_lds2_o3_kernel<0, true, 0>", eng.last_advect_kernel()
-    try:    # (the one-seed LDS kernel, what a row shard below 2^23 seeds runs: bit for bit; the order-3 direct-gather kernel agrees to rounding only)
-        eng.set_lds_tiles(2)
-        b3 = eng.advect(f3, rows, slon, -900.0, **kw)
-        assert eng.last_advect_kernel().startswith("advect_lds_kernel<3"), eng.last_advect_kernel()
-    finally:
-        eng.set_lds_tiles(-1)
-    assert bool((a3[0] == b3[0]).all() and (a3[1] == b3[1]).all()), eng.last_advect_kernel()
+    for cyclic, name in ((True, "advect_lds2_o3_kernel<0, true, 0>"), (False, "advect_lds2_o3_kernel<0, false, 0>")):
+        kw.update(cyclic_xboundary=cyclic, noncyclic_clamp="pointwise")
+        a3 = eng.advect(f3, rows, slon, -900.0, **kw)
+        assert eng.last_advect_kernel() == name, eng.last_advect_kernel()
+        try:    # (the one-seed LDS kernel, what a row shard below 2^23 seeds runs: bit for bit; the order-3 direct-gather kernel agrees to rounding only)
+            eng.set_lds_tiles(2)
+            b3 = eng.advect(f3, rows, slon, -900.0, **kw)
+            assert eng.last_advect_kernel().startswith("advect_lds_kernel<3"), eng.last_advect_kernel()
+        finally:
+            eng.set_lds_tiles(-1)
+        assert bool((a3[0] == b3[0]).all() and (a3[1] == b3[1]).all()), eng.last_advect_kernel()
     del f3, a3, b3
     # ... and with the trajectory (whole-line stores: the run-time-K instance of the line-store patch mode)
     t = eng.advect(f, rows, slon, -900.0, SETTLS_order=0, interp_order=1, cyclic_xboundary=True, return_traj=True, row0=1024, ny_global=4096)
