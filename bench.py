@@ -589,8 +589,10 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
     sig32 = lambda r: eng.sigma(r[0], r[1], slat_d, dlat, dlon)
     # SETTLS_order 0 (the LIBRARY default, LCS/trajectory.py:14, LCS/LCS.py:26: one Euler sample per level, the direct-gather
     # kernel -- include/lcs_hip.h), 1 and 2 on the headline field ("also report K=0 and order 3")
+    # (SETTLS_order 0 reads no fused-level image: its pack is what Engine.pack_and_advect -- the drop-in's route -- builds for it,
+    #  the order-1 / coefficient image alone; until the second session of round 6 these two cases packed the unused image too)
     for Kx in (0, 1, 2):
-        case(f"c3 K={Kx}", ny * nx * (nt - 1), Kx, 1, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 1),
+        case(f"c3 K={Kx}", ny * nx * (nt - 1), Kx, 1, 4, lambda Kx=Kx: eng.prepare_field(ud, vd, lat, lon, 1, fuse_levels=Kx > 0),
              lambda f, Kx=Kx: eng.advect(f, slat_d, slon_d, -900.0, Kx, 1, True), sig32)
         if "error" not in out[f"c3 K={Kx}"]:
             e = out[f"c3 K={Kx}"]
@@ -601,7 +603,7 @@ def secondary_workloads(torch, flows, eng, ud, vd, lat, lon, slat_d, slon_d, dla
     case("c3 order 3", ny * nx * (nt - 1), K, 3, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 3),
          lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 3, True), sig32)
     # ... and both at once: interp_order=3, SETTLS_order=0 are the reference's DEFAULT arguments (LCS/trajectory.py:14-16)
-    case("c3 order 3 K=0", ny * nx * (nt - 1), 0, 3, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 3),
+    case("c3 order 3 K=0", ny * nx * (nt - 1), 0, 3, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 3, fuse_levels=False),
          lambda f: eng.advect(f, slat_d, slon_d, -900.0, 0, 3, True), sig32)
     case("c3 return_traj", ny * nx * (nt - 1), K, 1, 4, lambda: eng.prepare_field(ud, vd, lat, lon, 1),
          lambda f: eng.advect(f, slat_d, slon_d, -900.0, K, 1, True, return_traj=True), sig32)
@@ -1163,7 +1165,7 @@ def main():
         cur = torch.cuda.current_stream()
         pack = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
         pack[0].record()
-        field = eng.prepare_field(ud, vd, lat, lon, order)
+        field = eng.prepare_field(ud, vd, lat, lon, order, fuse_levels=None if K > 0 else False)   # (--settls 0 reads no fused-level image)
         pack[1].record()
         res, mm = None, []
         if level_major:
