@@ -1,9 +1,10 @@
 """A/B helper: positions of the headline workload (configs[2]: 4096^2 seeds, 96 steps, K = 4, order 1) from the library named
 by LCS_LIB, saved as a SHA-256 of all 2 x 4096^2 floats + a 64 x 64 sample, so that two library variants can be compared
 bit for bit across processes.
-usage: LCS_LIB=$PWD/build/ab/variant.so python tools/dump_positions.py out.npz
+usage: LCS_LIB=$PWD/build/ab/variant.so [LCS_DUMP_K=0] python tools/dump_positions.py out.npz      (LCS_DUMP_K: SETTLS_order, default 4)
        python tools/dump_positions.py --compare a.npz b.npz"""
 import hashlib
+import os
 import sys
 
 import numpy as np
@@ -26,7 +27,8 @@ u, v, lat, lon = flows.era5_like(nt=97, ny=720, nx=1440)
 slat, slon = flows.seed_grid(4096, 4096, lat, lon)
 eng = Engine(0)
 f = eng.prepare_field(eng.to_device(u, np.float32), eng.to_device(v, np.float32), lat, lon, 1)
-x, y = eng.advect(f, eng.to_device(slat, np.float32), eng.to_device(slon, np.float32), -900.0, 4, 1, True)[:2]
+K = int(os.environ.get("LCS_DUMP_K", "4"))
+x, y = eng.advect(f, eng.to_device(slat, np.float32), eng.to_device(slon, np.float32), -900.0, K, 1, True)[:2]
 torch.cuda.synchronize()
 xh, yh = x.cpu().numpy(), y.cpu().numpy()
 h = hashlib.sha256(xh.tobytes() + yh.tobytes()).hexdigest()
